@@ -1,0 +1,115 @@
+/*
+ * libssdhip -- C ABI of the MI355X (gfx950) draft->verify hot path.
+ *
+ * The reference (tanishqkumar/ssd) has no FFI of its own: its hot ops are Python call sites into
+ * third-party CUDA wheels (torch/cuBLAS, Inductor, Triton, sgl-kernel FA3, flashinfer).  Each entry point
+ * below replaces one such call site; the citation names the reference file:line it stands in for.
+ * INTEGRATION.md shows the ctypes stub a maintainer would add at that call site.
+ *
+ * Conventions
+ *   - every function returns 0 (SSD_OK) or a negative error code; nothing throws, allocates, or
+ *     synchronises; all work is enqueued on `stream` (a hipStream_t passed as void*), so every call is
+ *     hipGraph-capturable.
+ *   - all pointers are DEVICE pointers owned by the caller; bf16 tensors are raw 16-bit words.
+ *   - "rows"  = row-major [M][K] bf16.
+ *     "frag"  = fragment-major [ceil(M/16)][K/32][64 lanes][8] bf16: 16x32 tiles of 1 KiB stored in
+ *               MFMA-16x16x32 lane order, lane = (row & 15) + 16 * ((col & 31) >> 3).  Weights are
+ *               pre-shuffled into this layout once at load (ssd_rows_to_frag); activations are
+ *               produced in it directly by the kernel that feeds a GEMM.
+ *   - token ids / positions are int64, every other index is int32 (as the reference,
+ *     ssd/engine/helpers/runner_helpers.py:99-106).
+ *   - KV cache layout per layer and per K/V: [num_blocks][n_kv_heads][block_size][head_dim] bf16;
+ *     slot = block_id * block_size + pos_in_block, slot -1 = do not store (reference semantics,
+ *     ssd/layers/attention.py:23-25).
+ */
+#ifndef SSD_HIP_H
+#define SSD_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSD_OK 0
+#define SSD_ERR_SHAPE (-1)
+#define SSD_ERR_LAUNCH (-2)
+#define SSD_ERR_ARG (-3)
+
+/* GEMM epilogues */
+#define SSD_EPI_ROWS 0      /* y rows bf16 [M][ldy]                                             */
+#define SSD_EPI_SILU_FRAG 1 /* W row groups alternate gate/up; y = frag bf16 [M][N/2] = silu(g)*u */
+#define SSD_EPI_ROWS_F32 2  /* y rows fp32 [M][ldy] (diagnostics: logits before the bf16 rounding) */
+
+int ssd_abi_version(void);
+
+/* Layout conversion.  mode 0: identity; mode 1: source rows are [gate ; up] halves and destination
+ * 16-row groups alternate gate/up (MergedColumnParallelLinear, ssd/layers/linear.py:101-122). */
+int ssd_rows_to_frag(const void* src_rows, void* dst_frag, int R, int K, int mode, void* stream);
+int ssd_frag_to_rows(const void* src_frag, void* dst_rows, int R, int K, void* stream);
+
+/* VocabParallelEmbedding.forward -- ssd/layers/embed_head.py:49-57 (rows outside
+ * [vocab_start, vocab_start+vocab_count) produce zeros, the TP-masked form). */
+int ssd_embedding(const int64_t* ids, const void* table_rows, void* out_rows, int T, int H, long vocab_start,
+                  long vocab_count, void* stream);
+
+/* RMSDNorm.norm_forward / add_norm_forward -- ssd/layers/layernorm.py:64-88 (as compiled: fp32 math,
+ * res_out = bf16(x+res), y = bf16((x+res) * rsqrt(mean^2 + eps) * w)).  res_in/res_out/out_rows/out_frag
+ * may be NULL; gather_rows (int32[T], optional) selects input rows (prefill last-token logits,
+ * ssd/layers/embed_head.py:81-84). */
+int ssd_rmsnorm(const void* x_rows, const void* res_in, void* res_out, const void* weight, float eps,
+                void* out_rows, void* out_frag, const int32_t* gather_rows, int T, int H, void* stream);
+
+/* F.linear(x, W, b) -- ssd/layers/linear.py:65,98,196; ssd/layers/embed_head.py:88,95,111.
+ * x_frag [M][K] frag, w_frag [N][K] frag, bias bf16[N] or NULL.  M <= 128 per call.
+ * SSD_EPI_SILU_FRAG additionally fuses SiluAndMul.forward -- ssd/layers/activation.py:11-14. */
+int ssd_gemm_wf(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K, int ldy,
+                int epilogue, void* stream);
+/* Same with an explicit decomposition: nt = 16-row groups per workgroup (1,2,4), waves = K-split (1..16). */
+int ssd_gemm_wf_cfg(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K, int ldy,
+                    int epilogue, int nt, int waves, void* stream);
+
+/* (RMSHeadNorm q/k, Qwen3: ssd/models/qwen3.py:96-104) + RotaryEmbedding.forward
+ * (ssd/layers/rotary_embedding.py:40-60) + store_kvcache (ssd/layers/attention.py:10-41).
+ * qkv_rows [T][(nh+2nkv)*hd]; cos_sin fp32 [max_pos][hd] (cos || sin); q_norm_w/k_norm_w bf16[hd] or NULL. */
+int ssd_rope_store_kv(const void* qkv_rows, const int64_t* positions, const float* cos_sin,
+                      const int32_t* slot_mapping, void* q_out_rows, void* k_cache, void* v_cache,
+                      const void* q_norm_w, const void* k_norm_w, float eps, int T, int nh, int nkv, int hd,
+                      int block_size, void* stream);
+
+/* Attention.forward, all branches -- ssd/layers/attention.py:73-134.
+ *   mode 0: causal, bottom-right aligned over context_lens (prefill :90-93, verify/glue :105-111,
+ *           single-query decode :126-131).  cu_q int32[B+1] or NULL (then q_per_seq queries per sequence).
+ *   mode 1: draft-tree decode (:113-125): tree_mq queries per sequence, structural mask of
+ *           ssd/engine/helpers/mask_helpers.py:12-21 at tree step `tree_step`; tree_jidx int32[B][tree_mq]
+ *           gives each branch's glue position (NULL -> branch / tree_F).
+ * splits = key-range splits per (sequence, kv head) (static per launch; ranges derive from context_lens on
+ * device).  ws_o fp32[T*nh*splits*hd], ws_ml fp32[T*nh*splits*2] needed when splits > 1.
+ * flags bit0: use scalar LDS gathers instead of ds_read_b64_tr_b16 (diagnostic). */
+int ssd_attn_paged(const void* q_rows, const void* k_cache, const void* v_cache, const int32_t* block_tables,
+                   int max_blocks, const int32_t* context_lens, const int32_t* cu_q, int q_per_seq, int B, int T,
+                   int max_q, int nh, int nkv, int hd, int block_size, float scale, int mode, int tree_K,
+                   int tree_mq, int tree_step, int tree_F, const int32_t* tree_jidx, int splits, int flags,
+                   void* ws_o, void* ws_ml, void* out_rows, void* out_frag, void* stream);
+
+/* Sampler.forward at temperature 0 -- ssd/layers/sampler.py:15-20; verify.py:34.  out2 optional copy. */
+int ssd_argmax_rows(const void* logits_rows, long ld, int T, int V, int64_t* out, int64_t* out2, void* stream);
+
+/* verify(), greedy branch -- ssd/utils/verify.py:28-48.  preds/speculations int64 [B][K+1]. */
+int ssd_verify_greedy(const int64_t* preds, const int64_t* speculations, int B, int K, int32_t* accept_len,
+                      int64_t* recovery, void* stream);
+
+/* get_forked_recovery_tokens_from_logits -- ssd/utils/async_helpers/async_spec_helpers.py:26-78.
+ * counts/offsets int32 [B][K+1]: fan-out and output offset of each glue position. */
+int ssd_fork_topf(const void* logits_rows, long ld, int V, const int64_t* returned_tokens, const int32_t* counts,
+                  const int32_t* offsets, int B, int K, int mq, int64_t* out, void* stream);
+
+/* Device-side replacement for the host loop body of SpeculatorSync.speculate --
+ * ssd/engine/speculator_sync.py:47-66 (+ runner_helpers.py:59-75): append the sampled token, bump
+ * position / context length, recompute the KV slot from the block table. */
+int ssd_draft_advance(const int64_t* next, int64_t* input_ids, int64_t* positions, int32_t* slots,
+                      int32_t* context_lens, const int32_t* block_tables, int max_blocks, int block_size,
+                      int64_t* spec, int K, int32_t* step, int B, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

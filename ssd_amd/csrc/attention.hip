@@ -1,0 +1,300 @@
+// Paged attention for every decode-side shape of the draft->verify loop, plus varlen causal prefill:
+//   * single-query decode           (reference ssd/layers/attention.py:126-131, flash_attn_with_kvcache)
+//   * K+1-query verify / glue       (reference ssd/layers/attention.py:105-111, bottom-right causal)
+//   * branched draft-tree decode    (reference ssd/layers/attention.py:113-125 flashinfer custom mask;
+//                                    mask definition ssd/engine/helpers/mask_helpers.py:12-21) -- here the
+//                                    mask is STRUCTURAL (computed from branch index / step), no mask
+//                                    tensor, no plan(), graph-capturable.
+//   * varlen causal prefill         (reference ssd/layers/attention.py:90-93) -- reads the just-stored
+//                                    K/V through the page table, which also covers prefix-cache hits.
+// One wave per (16*RT query rows of one kv-head group, key split).  Query rows of a kv head are the
+// (token, q-head-in-group) pairs, token-major, so GQA shares every K/V byte across the group.
+// Math per 32-key tile (all MFMA 16x16x32 bf16, fp32 accumulate):
+//   S^T[key][row] = K . Q^T      (A = K rows straight from the paged cache, B = Q fragments in VGPRs)
+//   online softmax in registers  (row statistics: 8 local values + 2 cross-lane steps)
+//   O^T[d][row]  += V^T . P^T    (A = V^T via ds_read_b64_tr_b16 from an LDS-staged V tile,
+//                                 B = P^T, which is exactly the S^T accumulator layout -> no shuffles)
+// Split-KV partials (m, l, O) are merged by attn_combine_kernel in a fixed order.
+#include "common.h"
+
+struct AttnParams {
+  const bf16_t* q;
+  const bf16_t* kc;
+  const bf16_t* vc;
+  const int32_t* block_tables;
+  const int32_t* context_lens;
+  const int32_t* cu_q;
+  const int32_t* tree_jidx;  // [B][tree_mq] glue position of each branch, or null -> branch / fan_out
+  float* ws_o;               // [T*nh][splits][HD]
+  float* ws_ml;              // [T*nh][splits][2]
+  bf16_t* out_rows;          // [T][nh*HD] or null
+  u32x2_t* out_frag;         // fragment-major [T][nh*HD] or null
+  int max_blocks, q_per_seq, nh, nkv, bs;
+  int mode;                  // 0 = causal (bottom-right aligned), 1 = tree
+  int tree_K, tree_mq, tree_step, tree_F;
+  int splits, use_tr;
+  float scale_log2e;
+};
+
+template <int HD>
+__device__ __forceinline__ const bf16_t* kv_row(const bf16_t* base, const int32_t* bt, int key, int h, int nkv, int bs) {
+  const int page = bt[key / bs];
+  return base + (((size_t)page * nkv + h) * bs + (key % bs)) * HD;
+}
+
+template <int HD, int RT>
+__global__ void __launch_bounds__(64) attn_kernel(const AttnParams p) {
+  __shared__ __attribute__((aligned(16))) bf16_t vlds[32 * HD];
+  constexpr int DS = HD / 32;  // k-steps of QK^T
+  constexpr int DT = HD / 16;  // 16-wide output d tiles
+  const int lane = threadIdx.x, r16 = lane & 15, g4 = lane >> 4;
+  const int b = blockIdx.y / p.nkv, h = blockIdx.y % p.nkv;
+  const int G = p.nh / p.nkv;
+  const int q0 = p.cu_q ? p.cu_q[b] : b * p.q_per_seq;
+  const int Tq = p.cu_q ? (p.cu_q[b + 1] - q0) : p.q_per_seq;
+  const int rows = Tq * G;
+  const int tile_base = blockIdx.x * RT;
+  if (tile_base * 16 >= rows) return;
+  const int ctx = p.context_lens[b];
+  const int32_t* bt = p.block_tables + (size_t)b * p.max_blocks;
+  const int z = blockIdx.z;
+
+  // ---- per-lane query-row descriptors and Q fragments ----
+  u32x4_t qf[RT][DS];
+  int tl[RT], hq[RT];
+  bool rvalid[RT];
+  int lim[RT];       // causal: keys [0, lim) visible.  tree: prefix length P
+  int tj[RT];        // tree: glue position j of the branch
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int rho = (tile_base + rt) * 16 + r16;
+    rvalid[rt] = rho < rows;
+    const int rr = rvalid[rt] ? rho : 0;
+    tl[rt] = rr / G;
+    hq[rt] = h * G + (rr % G);
+    const bf16_t* qp = p.q + ((size_t)(q0 + tl[rt]) * p.nh + hq[rt]) * HD + g4 * 8;
+#pragma unroll
+    for (int ds = 0; ds < DS; ++ds) qf[rt][ds] = *reinterpret_cast<const u32x4_t*>(qp + ds * 32);
+    if (p.mode == 0) {
+      lim[rt] = ctx - (Tq - 1 - tl[rt]);
+      tj[rt] = 0;
+    } else {
+      lim[rt] = ctx - (p.tree_K + 1) - (p.tree_step + 1) * p.tree_mq;
+      tj[rt] = p.tree_jidx ? p.tree_jidx[b * p.tree_mq + tl[rt]] : (tl[rt] / p.tree_F);
+    }
+  }
+
+  // ---- key range of this split (derived on device so the grid is capture-static) ----
+  int chunk = (ctx + p.splits - 1) / p.splits;
+  chunk = ((chunk + 31) >> 5) << 5;
+  const int k_begin = z * chunk;
+  int k_end = min(ctx, k_begin + chunk);
+  if (p.mode == 0) {  // rows of this tile never look past the last row's causal limit
+    const int last_row = min(rows - 1, (tile_base + RT) * 16 - 1);
+    k_end = min(k_end, ctx - (Tq - 1 - last_row / G));
+  }
+
+  float m[RT], lsum[RT];
+  f32x4_t o[RT][DT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    m[rt] = -INFINITY; lsum[rt] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[rt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+
+  for (int k0 = k_begin; k0 < k_end; k0 += 32) {
+    // -- stage the V tile [32 keys][HD] into LDS as DT sub-tiles of [32 keys][16 d] (tr-read image) --
+    constexpr int CH = HD / 8;  // 16-byte chunks per key row
+#pragma unroll
+    for (int it = 0; it < (32 * CH) / 64; ++it) {
+      const int c = it * 64 + lane;
+      const int key = c / CH, d8 = c % CH;
+      const int kk = min(k0 + key, ctx - 1);
+      const u32x4_t v = *reinterpret_cast<const u32x4_t*>(kv_row<HD>(p.vc, bt, kk, h, p.nkv, p.bs) + d8 * 8);
+      *reinterpret_cast<u32x4_t*>(vlds + ((d8 >> 1) * 32 + key) * 16 + (d8 & 1) * 8) = v;
+    }
+    // -- S^T = K . Q^T --
+    f32x4_t st[2][RT];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int kk = min(k0 + hf * 16 + r16, ctx - 1);
+      const bf16_t* kp = kv_row<HD>(p.kc, bt, kk, h, p.nkv, p.bs) + g4 * 8;
+      u32x4_t kf[DS];
+#pragma unroll
+      for (int ds = 0; ds < DS; ++ds) kf[ds] = *reinterpret_cast<const u32x4_t*>(kp + ds * 32);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        st[hf][rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ds = 0; ds < DS; ++ds) st[hf][rt] = mfma16(kf[ds], qf[rt][ds], st[hf][rt]);
+      }
+    }
+    // -- mask + online softmax; P^T stays in the accumulator layout --
+    u32x4_t pf[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      float s[8];
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = k0 + hf * 16 + g4 * 4 + r;
+          bool ok = rvalid[rt] && key < k_end;
+          if (p.mode == 0) {
+            ok = ok && key < lim[rt];
+          } else {
+            const int P = lim[rt];
+            const int rel = key - P;
+            bool vis = rel < 0;                                            // trunk prefix
+            vis = vis || (rel <= p.tree_K && rel <= tj[rt]);                // glue columns 0..j
+            vis = vis || (rel > p.tree_K && ((rel - p.tree_K - 1) % p.tree_mq) == tl[rt]);  // own branch diagonal
+            ok = ok && vis;
+          }
+          const float v = ok ? st[hf][rt][r] * p.scale_log2e : -INFINITY;
+          s[hf * 4 + r] = v;
+          tmax = fmaxf(tmax, v);
+        }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float mnew = fmaxf(m[rt], tmax);
+      const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+      const float alpha = exp2f(m[rt] - msafe);
+      float ps = 0.f;
+      float pv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { pv[i] = exp2f(s[i] - msafe); ps += pv[i]; }
+      lsum[rt] = lsum[rt] * alpha + ps;
+      m[rt] = mnew;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) o[rt][dt] *= alpha;
+      pf[rt] = u32x4_t{pack_bf2(pv[0], pv[1]), pack_bf2(pv[2], pv[3]), pack_bf2(pv[4], pv[5]), pack_bf2(pv[6], pv[7])};
+    }
+    __syncthreads();
+    // -- O^T += V^T . P^T ; V^T fragments by transpose-read from the staged tile --
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      u32x4_t vf;
+      if (p.use_tr) {
+        // lane (r16, g4) supplies the address of row 4*g4 + (r16 >> 2), column quad (r16 & 3) of the
+        // [32 keys][16 d] sub-tile; the hardware returns column r16 of rows 4*g4 .. 4*g4+3.
+        const bf16_t* a0 = vlds + (dt * 32 + g4 * 4 + (r16 >> 2)) * 16 + (r16 & 3) * 4;
+        typedef s16x4_t __attribute__((address_space(3))) * lds_v4_t;
+        const s16x4_t t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(a0));
+        const s16x4_t t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(a0 + 16 * 16));
+        u32x2_t lo = __builtin_bit_cast(u32x2_t, t0), hi = __builtin_bit_cast(u32x2_t, t1);
+        vf = u32x4_t{lo[0], lo[1], hi[0], hi[1]};
+      } else {
+        uint32_t e[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int key = (i < 4) ? (g4 * 4 + i) : (16 + g4 * 4 + (i - 4));
+          e[i] = vlds[(dt * 32 + key) * 16 + r16];
+        }
+        vf = u32x4_t{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) o[rt][dt] = mfma16(vf, pf[rt], o[rt][dt]);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    float l = lsum[rt];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (!rvalid[rt]) continue;
+    const size_t row = (size_t)(q0 + tl[rt]) * p.nh + hq[rt];
+    if (p.splits == 1) {
+      const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int d = dt * 16 + g4 * 4;
+        const u32x2_t v = {pack_bf2(o[rt][dt][0] * inv, o[rt][dt][1] * inv), pack_bf2(o[rt][dt][2] * inv, o[rt][dt][3] * inv)};
+        if (p.out_rows) *reinterpret_cast<u32x2_t*>(p.out_rows + row * HD + d) = v;
+        if (p.out_frag) {
+          const int kcol = hq[rt] * HD + d;
+          p.out_frag[frag_chunk(q0 + tl[rt], kcol >> 3, (p.nh * HD) >> 5) * 2 + ((kcol >> 2) & 1)] = v;
+        }
+      }
+    } else {
+      float* wo = p.ws_o + (row * p.splits + z) * HD;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4_t*>(wo + dt * 16 + g4 * 4) = o[rt][dt];
+      if (g4 == 0) {
+        p.ws_ml[(row * p.splits + z) * 2] = m[rt];
+        p.ws_ml[(row * p.splits + z) * 2 + 1] = l;
+      }
+    }
+  }
+}
+
+// Merge split-KV partials: out = sum_s 2^(m_s - M) O_s / sum_s 2^(m_s - M) l_s, splits visited in order.
+template <int HD>
+__global__ void attn_combine_kernel(const float* __restrict__ ws_o, const float* __restrict__ ws_ml, int splits,
+                                    int nh, bf16_t* __restrict__ out_rows, u32x2_t* __restrict__ out_frag) {
+  const int row = blockIdx.x;  // token * nh + head
+  const int d = threadIdx.x * 4;
+  float M = -INFINITY;
+  for (int s = 0; s < splits; ++s) M = fmaxf(M, ws_ml[((size_t)row * splits + s) * 2]);
+  const float Ms = (M == -INFINITY) ? 0.f : M;
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  float L = 0.f;
+  for (int s = 0; s < splits; ++s) {
+    const float w = exp2f(ws_ml[((size_t)row * splits + s) * 2] - Ms);
+    L += w * ws_ml[((size_t)row * splits + s) * 2 + 1];
+    acc += w * *reinterpret_cast<const f32x4_t*>(ws_o + ((size_t)row * splits + s) * HD + d);
+  }
+  const float inv = L > 0.f ? 1.0f / L : 0.f;
+  const u32x2_t v = {pack_bf2(acc[0] * inv, acc[1] * inv), pack_bf2(acc[2] * inv, acc[3] * inv)};
+  if (out_rows) *reinterpret_cast<u32x2_t*>(out_rows + (size_t)row * HD + d) = v;
+  if (out_frag) {
+    const int token = row / nh, head = row % nh;
+    const int kcol = head * HD + d;
+    out_frag[frag_chunk(token, kcol >> 3, (nh * HD) >> 5) * 2 + ((kcol >> 2) & 1)] = v;
+  }
+}
+
+template <int HD>
+static int attn_launch(const AttnParams& p, int B, int T, int max_q, hipStream_t st) {
+  const int G = p.nh / p.nkv;
+  const int row_tiles = (max_q * G + 15) / 16;
+  const int rt = row_tiles >= 2 ? 2 : 1;
+  dim3 grid((row_tiles + rt - 1) / rt, B * p.nkv, p.splits);
+  if (rt == 2) hipLaunchKernelGGL((attn_kernel<HD, 2>), grid, dim3(64), 0, st, p);
+  else hipLaunchKernelGGL((attn_kernel<HD, 1>), grid, dim3(64), 0, st, p);
+  if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
+  if (p.splits > 1) {
+    hipLaunchKernelGGL((attn_combine_kernel<HD>), dim3(T * p.nh), dim3(HD / 4), 0, st, p.ws_o, p.ws_ml, p.splits, p.nh,
+                       p.out_rows, p.out_frag);
+    if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
+  }
+  return SSD_OK;
+}
+
+extern "C" int ssd_attn_paged(const void* q_rows, const void* k_cache, const void* v_cache,
+                              const int32_t* block_tables, int max_blocks, const int32_t* context_lens,
+                              const int32_t* cu_q, int q_per_seq, int B, int T, int max_q, int nh, int nkv, int hd,
+                              int block_size, float scale, int mode, int tree_K, int tree_mq, int tree_step,
+                              int tree_F, const int32_t* tree_jidx, int splits, int flags, void* ws_o, void* ws_ml,
+                              void* out_rows, void* out_frag, void* stream) {
+  if (B <= 0 || T <= 0 || max_q <= 0 || nh <= 0 || nkv <= 0 || nh % nkv) return SSD_ERR_SHAPE;
+  if (hd != 64 && hd != 128) return SSD_ERR_SHAPE;
+  if (((nh * hd) & 31) != 0) return SSD_ERR_SHAPE;
+  if (splits < 1) return SSD_ERR_ARG;
+  if (splits > 1 && (!ws_o || !ws_ml)) return SSD_ERR_ARG;
+  if (mode == 1 && (tree_mq <= 0 || tree_F <= 0)) return SSD_ERR_ARG;
+  AttnParams p;
+  p.q = (const bf16_t*)q_rows; p.kc = (const bf16_t*)k_cache; p.vc = (const bf16_t*)v_cache;
+  p.block_tables = block_tables; p.context_lens = context_lens; p.cu_q = cu_q; p.tree_jidx = tree_jidx;
+  p.ws_o = (float*)ws_o; p.ws_ml = (float*)ws_ml; p.out_rows = (bf16_t*)out_rows; p.out_frag = (u32x2_t*)out_frag;
+  p.max_blocks = max_blocks; p.q_per_seq = q_per_seq; p.nh = nh; p.nkv = nkv; p.bs = block_size;
+  p.mode = mode; p.tree_K = tree_K; p.tree_mq = tree_mq; p.tree_step = tree_step; p.tree_F = tree_F;
+  p.splits = splits; p.use_tr = (flags & 1) ? 0 : 1;
+  p.scale_log2e = scale * 1.4426950408889634f;
+  hipStream_t st = (hipStream_t)stream;
+  return hd == 128 ? attn_launch<128>(p, B, T, max_q, st) : attn_launch<64>(p, B, T, max_q, st);
+}

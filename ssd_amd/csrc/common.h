@@ -1,0 +1,58 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels of libssdhip.
+// Everything here is wave64 / MFMA-16x16x32 specific; there is no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits (row-major tensors are passed as plain pointers)
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+#define SSD_OK 0
+#define SSD_ERR_SHAPE -1
+#define SSD_ERR_LAUNCH -2
+#define SSD_ERR_ARG -3
+
+__device__ __forceinline__ float bf2f(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
+
+// fp32 -> bf16, round-to-nearest-even (the rounding every torch bf16 store performs).
+__device__ __forceinline__ uint32_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return f2bf(lo) | (f2bf(hi) << 16); }
+
+// Round an fp32 value through bf16 (models "store bf16, reload" between two reference kernels).
+__device__ __forceinline__ float round_bf(float f) { return bf2f(f2bf(f)); }
+
+// "Fragment-major" (XF / WF) layout shared by activations and weights.
+// A logical [R][K] bf16 matrix (K % 32 == 0) is cut into 16-row x 32-col tiles of 1 KiB; inside a
+// tile the 64 16-byte chunks are stored in MFMA-16x16x32 lane order:
+//   lane l = (r & 15) + 16 * ((k & 31) >> 3) holds row r, columns (k & ~7) .. +7.
+// Tiles are ordered [row_tile][k_tile], so one wave streaming along K for a fixed row tile reads
+// contiguous memory with fully coalesced 1 KiB wave loads that ARE the MFMA operand.
+// Returns the chunk (16-byte unit) index of (row r, 8-column group k8 = k / 8).
+__device__ __forceinline__ size_t frag_chunk(int r, int k8, int KT) {
+  return ((size_t)((r >> 4) * KT + (k8 >> 2)) << 6) + (size_t)((r & 15) + ((k8 & 3) << 4));
+}
+
+__device__ __forceinline__ f32x4_t mfma16(u32x4_t a, u32x4_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                 __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,229 @@
+// Skinny bf16 GEMM  y[M,N] = x[M,K] . W[N,K]^T  for the draft/verify/tree forwards (M = B*(K+1) <= ~32,
+// and chunked for prefill).  Replaces cuBLAS F.linear at reference ssd/layers/linear.py:65,98,196 and
+// ssd/layers/embed_head.py:88,95,111.
+//
+// MI355X design (HBM-bound weight streaming):
+//  * W is stored "fragment-major" (common.h): each 16x32 tile is 1 KiB in MFMA lane order, tiles of
+//    one 16-row group contiguous along K.  One wave load = 1 KiB contiguous = one MFMA A operand.
+//    No LDS round trip for weights (guide: "GEMV / M <= 16: load straight to VGPRs").
+//  * x is stored in the same fragment-major layout by its producer kernel (rmsnorm / attention /
+//    the SiLU epilogue below), so the B operand is also a coalesced 1 KiB wave load (L2 resident).
+//  * One workgroup owns NT adjacent 16-row groups of W for the WHOLE K; its waves split K and
+//    combine through LDS in a fixed order (deterministic, no atomics, no inter-workgroup traffic).
+//  * Weight loads are non-temporal (each byte is read exactly once per forward).
+#include "common.h"
+
+enum { EPI_ROWS = 0, EPI_SILU_FRAG = 1, EPI_ROWS_F32 = 2 };
+
+template <int MT, int NT>
+struct Stage {
+  u32x4_t a[NT];
+  u32x4_t b[MT];
+};
+
+template <int MT, int NT, int EPI>
+__global__ void __launch_bounds__(1024)
+gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
+               const bf16_t* __restrict__ bias, void* __restrict__ Yv, int M, int N, int K, int ldy) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nw = blockDim.x >> 6;
+  const int KT = K >> 5;
+  const int tile0 = blockIdx.x * NT;
+  const int kt0 = (int)(((long)KT * wave) / nw);
+  const int kt1 = (int)(((long)KT * (wave + 1)) / nw);
+
+  f32x4_t acc[NT][MT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const u32x4_t* wp = Wf + ((size_t)tile0 * KT << 6) + lane;
+  const u32x4_t* xp = Xf + lane;
+  const size_t wstride = (size_t)KT << 6;  // chunks between adjacent row groups
+  const size_t xstride = (size_t)KT << 6;
+
+  constexpr int U = (MT + NT <= 3) ? 4 : ((MT + NT <= 6) ? 2 : 1);
+  Stage<MT, NT> cur[U], nxt[U];
+
+  auto load = [&](Stage<MT, NT>(&s)[U], int kt) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        s[u].a[nt] = __builtin_nontemporal_load(wp + nt * wstride + ((size_t)(kt + u) << 6));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) s[u].b[mt] = xp[mt * xstride + ((size_t)(kt + u) << 6)];
+    }
+  };
+  auto compute = [&](Stage<MT, NT>(&s)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mfma16(s[u].a[nt], s[u].b[mt], acc[nt][mt]);
+  };
+
+  int kt = kt0;
+  const int kmain = kt0 + ((kt1 - kt0) / U) * U;
+  if (kt < kmain) {
+    load(cur, kt);
+    for (; kt + U < kmain; kt += U) {
+      load(nxt, kt + U);
+      compute(cur);
+#pragma unroll
+      for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+    }
+    compute(cur);
+    kt += U;
+  }
+  for (; kt < kt1; ++kt) {  // K-range remainder (< U tiles)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      u32x4_t a = __builtin_nontemporal_load(wp + nt * wstride + ((size_t)kt << 6));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mfma16(a, xp[mt * xstride + ((size_t)kt << 6)], acc[nt][mt]);
+    }
+  }
+
+  // ---- cross-wave split-K combine through LDS, fixed order ----
+  f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);  // [nw][NT*MT][64]
+  constexpr int ITEMS = NT * MT;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) red[((wave * ITEMS) + nt * MT + mt) * 64 + lane] = acc[nt][mt];
+  __syncthreads();
+
+  const int mcol = lane & 15;   // D column j  -> token row m
+  const int nrow = (lane >> 4) * 4;  // D rows i = nrow + r -> output feature n
+  if (EPI == EPI_SILU_FRAG) {
+    // W row groups come in (gate, up) pairs (interleaved at weight-shuffle time).  act = silu(g)*u with
+    // both rounded to bf16 first (the reference's F.linear stores bf16, ssd/layers/activation.py:11-14
+    // then computes in fp32 with one final rounding).  Output goes straight to the fragment-major
+    // input buffer of down_proj (K' = N/2).
+    constexpr int PAIRS = NT / 2;
+    const int KT2 = (N >> 1) >> 5;
+    u32x2_t* out = reinterpret_cast<u32x2_t*>(Yv);
+    for (int item = wave; item < PAIRS * MT; item += nw) {
+      const int pr = item / MT, mt = item % MT;
+      f32x4_t g = f32x4_t{0.f, 0.f, 0.f, 0.f}, u = g;
+      for (int w = 0; w < nw; ++w) {
+        g += red[((w * ITEMS) + (2 * pr) * MT + mt) * 64 + lane];
+        u += red[((w * ITEMS) + (2 * pr + 1) * MT + mt) * 64 + lane];
+      }
+      const int m = mt * 16 + mcol;
+      const int n = ((tile0 >> 1) + pr) * 16 + nrow;  // feature index in [0, N/2)
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float gb = g[r], ub = u[r];
+        if (bias) { gb += bf2f(bias[(tile0 + 2 * pr) * 16 + nrow + r]); ub += bf2f(bias[(tile0 + 2 * pr + 1) * 16 + nrow + r]); }
+        gb = round_bf(gb); ub = round_bf(ub);
+        o[r] = (gb / (1.0f + __expf(-gb))) * ub;
+      }
+      if (m < M) {
+        u32x2_t v = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+        out[frag_chunk(m, n >> 3, KT2) * 2 + ((n >> 2) & 1)] = v;
+      }
+    }
+  } else {
+    for (int item = wave; item < ITEMS; item += nw) {
+      const int nt = item / MT, mt = item % MT;
+      f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int w = 0; w < nw; ++w) s += red[((w * ITEMS) + item) * 64 + lane];
+      const int m = mt * 16 + mcol;
+      const int n = (tile0 + nt) * 16 + nrow;
+      if (bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] += bf2f(bias[n + r]);
+      }
+      if (m < M) {
+        if (EPI == EPI_ROWS_F32) {
+          *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(Yv) + (size_t)m * ldy + n) = s;
+        } else {
+          u32x2_t v = {pack_bf2(s[0], s[1]), pack_bf2(s[2], s[3])};
+          *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(Yv) + (size_t)m * ldy + n) = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Launch heuristics.  waves/block * blocks should put >= ~8-16 waves on each of the 256 CUs while
+// each wave still streams a few KiB contiguously.
+// ---------------------------------------------------------------------------------------------
+template <int MT, int NT, int EPI>
+static int launch_t(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int ldy,
+                    int waves, hipStream_t st) {
+  const int blocks = (N / 16) / NT;
+  const size_t lds = (size_t)waves * NT * MT * 64 * sizeof(f32x4_t);
+  auto kern = gemm_wf_kernel<MT, NT, EPI>;
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return SSD_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, st, (const u32x4_t*)w, (const u32x4_t*)x,
+                     (const bf16_t*)bias, y, M, N, K, ldy);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
+template <int MT, int EPI>
+static int launch_nt(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int ldy,
+                     int nt, int waves, hipStream_t st) {
+  if (nt == 1) {
+    if constexpr (EPI == EPI_SILU_FRAG) return SSD_ERR_ARG;
+    else return launch_t<MT, 1, EPI>(x, w, bias, y, M, N, K, ldy, waves, st);
+  }
+  if (nt == 2) return launch_t<MT, 2, EPI>(x, w, bias, y, M, N, K, ldy, waves, st);
+  if (nt == 4) {
+    if constexpr (MT > 2) return SSD_ERR_ARG;
+    else return launch_t<MT, 4, EPI>(x, w, bias, y, M, N, K, ldy, waves, st);
+  }
+  return SSD_ERR_ARG;
+}
+
+extern "C" int ssd_gemm_wf_cfg(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N,
+                               int K, int ldy, int epilogue, int nt, int waves, void* stream) {
+  if (M <= 0 || M > 128 || (N & 15) || (K & 31) || N <= 0 || K <= 0) return SSD_ERR_SHAPE;
+  if (waves < 1 || waves > 16) return SSD_ERR_ARG;
+  if (((N / 16) % nt) != 0) return SSD_ERR_ARG;
+  if (epilogue == EPI_SILU_FRAG && (nt & 1)) return SSD_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int mt = (M + 15) / 16;
+#define DISPATCH_MT(MTV)                                                                                         \
+  switch (epilogue) {                                                                                            \
+    case EPI_ROWS: return launch_nt<MTV, EPI_ROWS>(x_frag, w_frag, bias, y, M, N, K, ldy, nt, waves, st);         \
+    case EPI_SILU_FRAG: return launch_nt<MTV, EPI_SILU_FRAG>(x_frag, w_frag, bias, y, M, N, K, ldy, nt, waves, st); \
+    case EPI_ROWS_F32: return launch_nt<MTV, EPI_ROWS_F32>(x_frag, w_frag, bias, y, M, N, K, ldy, nt, waves, st); \
+    default: return SSD_ERR_ARG;                                                                                 \
+  }
+  if (mt == 1) { DISPATCH_MT(1) }
+  if (mt == 2) { DISPATCH_MT(2) }
+  if (mt <= 4) { DISPATCH_MT(4) }
+  { DISPATCH_MT(8) }
+#undef DISPATCH_MT
+}
+
+// Default configuration: pick (row groups per workgroup, waves per workgroup) from the shape.
+extern "C" int ssd_gemm_wf(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N,
+                           int K, int ldy, int epilogue, void* stream) {
+  if ((N & 15) || (K & 31) || N <= 0 || K <= 0) return SSD_ERR_SHAPE;
+  const int groups = N / 16, KT = K / 32, mt = (M + 15) / 16;
+  int nt = 1;
+  if (epilogue == EPI_SILU_FRAG) nt = 2;
+  else if (mt >= 4 && groups % 2 == 0) nt = 2;          // amortise the larger x operand
+  else if (groups >= 2048 && groups % 2 == 0) nt = 2;   // plenty of workgroups anyway
+  // waves: each wave should stream >= 4 k-tiles per row group; 16 waves/CU wanted when blocks ~ CUs.
+  int waves = 16;
+  while (waves > 1 && KT / waves < 4) waves >>= 1;
+  const int blocks = groups / nt;
+  if (blocks >= 1024 && waves > 8) waves = 8;
+  if (mt >= 4 && waves > 8) waves = 8;  // LDS for the combine: waves*nt*mt KiB
+  if (mt >= 8 && waves > 4) waves = 4;
+  return ssd_gemm_wf_cfg(x_frag, w_frag, bias, y, M, N, K, ldy, epilogue, nt, waves, stream);
+}

@@ -1,0 +1,40 @@
+// Small device-side state kernels that keep the draft->verify loop free of host round trips.
+#include "common.h"
+
+#define SSD_HIP_ABI_VERSION 1
+
+extern "C" int ssd_abi_version(void) { return SSD_HIP_ABI_VERSION; }
+
+// After one single-token draft forward + argmax (`next[b]`): record the token as speculation step+1 and
+// turn the static decode inputs into the inputs of the next draft step -- what the reference does on the
+// host between graph replays (ssd/engine/speculator_sync.py:47-66 + ssd/engine/helpers/runner_helpers.py:59-75,
+// each iteration a `.tolist()` sync).  Here the K+1 draft forwards are enqueued back to back.
+__global__ void draft_advance_kernel(const int64_t* __restrict__ next, int64_t* __restrict__ input_ids,
+                                     int64_t* __restrict__ positions, int32_t* __restrict__ slots,
+                                     int32_t* __restrict__ ctx, const int32_t* __restrict__ block_tables,
+                                     int max_blocks, int bs, int64_t* __restrict__ spec, int K, int32_t* step, int B) {
+  const int b = threadIdx.x;
+  const int s = *step;
+  __syncthreads();
+  if (b < B) {
+    const int64_t tok = next[b];
+    if (s + 1 <= K) spec[(size_t)b * (K + 1) + s + 1] = tok;
+    input_ids[b] = tok;
+    const long pos = positions[b] + 1;
+    positions[b] = pos;
+    ctx[b] += 1;
+    const int blk = block_tables[(size_t)b * max_blocks + (int)(pos / bs)];
+    slots[b] = blk >= 0 ? blk * bs + (int)(pos % bs) : -1;
+  }
+  if (b == 0) *step = s + 1;
+}
+
+extern "C" int ssd_draft_advance(const int64_t* next, int64_t* input_ids, int64_t* positions, int32_t* slots,
+                                 int32_t* context_lens, const int32_t* block_tables, int max_blocks, int block_size,
+                                 int64_t* spec, int K, int32_t* step, int B, void* stream) {
+  if (B <= 0 || B > 1024) return SSD_ERR_SHAPE;
+  const int threads = ((B + 63) / 64) * 64;
+  hipLaunchKernelGGL(draft_advance_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, next, input_ids, positions,
+                     slots, context_lens, block_tables, max_blocks, block_size, spec, K, step, B);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}

@@ -1,0 +1,97 @@
+// Embedding gather and fused (residual-add +) RMSNorm.
+//  * ssd_embedding  replaces VocabParallelEmbedding.forward, reference ssd/layers/embed_head.py:49-57
+//  * ssd_rmsnorm    replaces RMSDNorm.norm_forward / add_norm_forward, reference
+//                   ssd/layers/layernorm.py:64-88 (as run under torch.compile: fp32 throughout, one
+//                   rounding at each store: res_out = bf16(x32), y = bf16(x32 * rsqrt(mean(x32^2)+eps) * w32)).
+// The normalised output can be written row-major and/or directly in the fragment-major layout that
+// the next skinny GEMM consumes (common.h), so no separate re-layout pass exists on the hot path.
+#include "common.h"
+
+__global__ void embedding_kernel(const int64_t* __restrict__ ids, const u32x4_t* __restrict__ table,
+                                 u32x4_t* __restrict__ out, int H8, long vocab_start, long vocab_count) {
+  const int t = blockIdx.x;
+  const long id = ids[t] - vocab_start;
+  const bool ok = id >= 0 && id < vocab_count;
+  const u32x4_t* src = table + (size_t)(ok ? id : 0) * H8;
+  for (int c = threadIdx.x; c < H8; c += blockDim.x) {
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (ok) v = src[c];
+    out[(size_t)t * H8 + c] = v;
+  }
+}
+
+extern "C" int ssd_embedding(const int64_t* ids, const void* table, void* out_rows, int T, int H,
+                             long vocab_start, long vocab_count, void* stream) {
+  if (T <= 0 || H <= 0 || (H & 7)) return SSD_ERR_SHAPE;
+  int threads = H / 8; if (threads > 256) threads = 256; if (threads < 64) threads = 64;
+  hipLaunchKernelGGL(embedding_kernel, dim3(T), dim3(threads), 0, (hipStream_t)stream, ids,
+                     (const u32x4_t*)table, (u32x4_t*)out_rows, H / 8, vocab_start, vocab_count);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
+constexpr int NORM_THREADS = 256;
+constexpr int NORM_MAXC = 8;  // chunks of 8 elements per thread -> H <= 256*8*8 = 16384
+
+__global__ void __launch_bounds__(NORM_THREADS)
+rmsnorm_kernel(const u32x4_t* __restrict__ x, const u32x4_t* __restrict__ res_in, u32x4_t* __restrict__ res_out,
+               const u32x4_t* __restrict__ w, float eps, u32x4_t* __restrict__ out_rows,
+               u32x4_t* __restrict__ out_frag, const int32_t* __restrict__ gather, int H) {
+  __shared__ float red[NORM_THREADS / 64];
+  const int row_out = blockIdx.x;
+  const int row_in = gather ? gather[row_out] : row_out;
+  const int H8 = H >> 3;
+  const int KT = H >> 5;
+  float v[NORM_MAXC][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_MAXC; ++i) {
+    const int c = threadIdx.x + i * NORM_THREADS;
+    if (c < H8) {
+      const u32x4_t xv = x[(size_t)row_in * H8 + c];
+      u32x4_t rv = {0u, 0u, 0u, 0u};
+      if (res_in) rv = res_in[(size_t)row_in * H8 + c];
+      u32x4_t ro;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float lo = bf2f(xv[j] & 0xffffu), hi = bf2f(xv[j] >> 16);
+        if (res_in) { lo += bf2f(rv[j] & 0xffffu); hi += bf2f(rv[j] >> 16); }
+        v[i][2 * j] = lo; v[i][2 * j + 1] = hi;
+        ro[j] = pack_bf2(lo, hi);
+        ss += lo * lo; ss += hi * hi;
+      }
+      if (res_out) res_out[(size_t)row_out * H8 + c] = ro;
+    }
+  }
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_THREADS / 64; ++i) tot += red[i];
+  const float rs = 1.0f / sqrtf(tot / (float)H + eps);
+#pragma unroll
+  for (int i = 0; i < NORM_MAXC; ++i) {
+    const int c = threadIdx.x + i * NORM_THREADS;
+    if (c < H8) {
+      const u32x4_t wv = w[c];
+      u32x4_t o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float lo = (v[i][2 * j] * rs) * bf2f(wv[j] & 0xffffu);
+        const float hi = (v[i][2 * j + 1] * rs) * bf2f(wv[j] >> 16);
+        o[j] = pack_bf2(lo, hi);
+      }
+      if (out_rows) out_rows[(size_t)row_out * H8 + c] = o;
+      if (out_frag) out_frag[frag_chunk(row_out, c, KT)] = o;
+    }
+  }
+}
+
+extern "C" int ssd_rmsnorm(const void* x_rows, const void* res_in, void* res_out, const void* weight, float eps,
+                           void* out_rows, void* out_frag, const int32_t* gather_rows, int T, int H, void* stream) {
+  if (T <= 0 || H <= 0 || (H & 31) || H > NORM_THREADS * NORM_MAXC * 8) return SSD_ERR_SHAPE;
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3(T), dim3(NORM_THREADS), 0, (hipStream_t)stream, (const u32x4_t*)x_rows,
+                     (const u32x4_t*)res_in, (u32x4_t*)res_out, (const u32x4_t*)weight, eps, (u32x4_t*)out_rows,
+                     (u32x4_t*)out_frag, gather_rows, H);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}

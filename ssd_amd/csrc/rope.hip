@@ -1,0 +1,95 @@
+// Fused (optional per-head RMSNorm) + neox RoPE + paged KV-cache store.
+// Replaces, in one launch:
+//   * RMSHeadNorm q_norm/k_norm (Qwen3 only), reference ssd/models/qwen3.py:96-104, ssd/layers/layernorm.py:16-40
+//   * RotaryEmbedding.forward, reference ssd/layers/rotary_embedding.py:6-60 (fp32 math from the fp32
+//     cos||sin table gathered by `positions`, one rounding to bf16)
+//   * the Triton store_kvcache kernel, reference ssd/layers/attention.py:10-41 (slot == -1 -> skip)
+// KV cache layout here is [num_blocks][n_kv_heads][block_size][head_dim] per layer and per K/V
+// ("HND"): one (page, kv-head) is a contiguous 64 KiB run, which is what the attention kernel streams.
+// The reference's slot semantics are kept: slot = block_id * block_size + pos_in_block.
+#include "common.h"
+
+__global__ void rope_store_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ positions,
+                                  const float* __restrict__ cos_sin, const int32_t* __restrict__ slots,
+                                  bf16_t* __restrict__ q_out, bf16_t* __restrict__ k_cache,
+                                  bf16_t* __restrict__ v_cache, const bf16_t* __restrict__ qn_w,
+                                  const bf16_t* __restrict__ kn_w, float eps, int nh, int nkv, int hd, int bs) {
+  const int t = blockIdx.x;
+  const int c16 = hd >> 4;                 // threads per rotated head (each owns 8+8 elements)
+  const int rot_items = (nh + nkv) * c16;  // q and k heads
+  const int v_items = nkv * (hd >> 3);
+  const int row_w = (nh + 2 * nkv) * hd;
+  const bf16_t* row = qkv + (size_t)t * row_w;
+  const long pos = positions[t];
+  const int slot = slots ? slots[t] : -1;
+  const float* cs = cos_sin + (size_t)pos * hd;
+  const int half = hd >> 1;
+  long kv_base = -1;
+  if (slot >= 0) kv_base = ((long)(slot / bs) * nkv) * bs + (slot % bs);  // + kvh*bs, then * hd
+
+  for (int it = threadIdx.x; it < rot_items + v_items; it += blockDim.x) {
+    if (it < rot_items) {
+      const int head = it / c16, c = it % c16;
+      const bool is_q = head < nh;
+      const bf16_t* src = row + (size_t)head * hd;  // q heads then k heads are contiguous in qkv
+      const u32x4_t a = *reinterpret_cast<const u32x4_t*>(src + c * 8);
+      const u32x4_t b = *reinterpret_cast<const u32x4_t*>(src + half + c * 8);
+      float x1[8], x2[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x1[2 * j] = bf2f(a[j] & 0xffffu); x1[2 * j + 1] = bf2f(a[j] >> 16);
+        x2[2 * j] = bf2f(b[j] & 0xffffu); x2[2 * j + 1] = bf2f(b[j] >> 16);
+      }
+      const bf16_t* nw = is_q ? qn_w : kn_w;
+      if (nw) {  // per-head RMSNorm, rounded to bf16 before the rotation (separate kernels in the reference)
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ss += x1[j] * x1[j]; ss += x2[j] * x2[j]; }
+        for (int o = 1; o < c16; o <<= 1) ss += __shfl_xor(ss, o, 64);
+        const float rs = 1.0f / sqrtf(ss / (float)hd + eps);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          x1[j] = round_bf((x1[j] * rs) * bf2f(nw[c * 8 + j]));
+          x2[j] = round_bf((x2[j] * rs) * bf2f(nw[half + c * 8 + j]));
+        }
+      }
+      float y1[8], y2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float co = cs[c * 8 + j], si = cs[half + c * 8 + j];
+        y1[j] = __fsub_rn(__fmul_rn(x1[j], co), __fmul_rn(x2[j], si));
+        y2[j] = __fadd_rn(__fmul_rn(x2[j], co), __fmul_rn(x1[j], si));
+      }
+      const u32x4_t o1 = {pack_bf2(y1[0], y1[1]), pack_bf2(y1[2], y1[3]), pack_bf2(y1[4], y1[5]), pack_bf2(y1[6], y1[7])};
+      const u32x4_t o2 = {pack_bf2(y2[0], y2[1]), pack_bf2(y2[2], y2[3]), pack_bf2(y2[4], y2[5]), pack_bf2(y2[6], y2[7])};
+      if (is_q) {
+        bf16_t* dst = q_out + ((size_t)t * nh + head) * hd;
+        *reinterpret_cast<u32x4_t*>(dst + c * 8) = o1;
+        *reinterpret_cast<u32x4_t*>(dst + half + c * 8) = o2;
+      } else if (kv_base >= 0) {
+        bf16_t* dst = k_cache + (size_t)(kv_base + (long)(head - nh) * bs) * hd;
+        *reinterpret_cast<u32x4_t*>(dst + c * 8) = o1;
+        *reinterpret_cast<u32x4_t*>(dst + half + c * 8) = o2;
+      }
+    } else if (kv_base >= 0) {
+      const int vi = it - rot_items;
+      const int kvh = vi / (hd >> 3), c = vi % (hd >> 3);
+      const u32x4_t v = *reinterpret_cast<const u32x4_t*>(row + (size_t)(nh + nkv + kvh) * hd + c * 8);
+      *reinterpret_cast<u32x4_t*>(v_cache + (size_t)(kv_base + (long)kvh * bs) * hd + c * 8) = v;
+    }
+  }
+}
+
+extern "C" int ssd_rope_store_kv(const void* qkv_rows, const int64_t* positions, const float* cos_sin,
+                                 const int32_t* slot_mapping, void* q_out_rows, void* k_cache, void* v_cache,
+                                 const void* q_norm_w, const void* k_norm_w, float eps, int T, int nh, int nkv,
+                                 int hd, int block_size, void* stream) {
+  if (T <= 0 || nh <= 0 || nkv <= 0 || (hd != 64 && hd != 128 && hd != 256) || block_size <= 0) return SSD_ERR_SHAPE;
+  const int items = (nh + nkv) * (hd / 16) + nkv * (hd / 8);
+  int threads = ((items + 63) / 64) * 64;
+  if (threads > 512) threads = 512;
+  hipLaunchKernelGGL(rope_store_kernel, dim3(T), dim3(threads), 0, (hipStream_t)stream, (const bf16_t*)qkv_rows,
+                     positions, cos_sin, slot_mapping, (bf16_t*)q_out_rows, (bf16_t*)k_cache, (bf16_t*)v_cache,
+                     (const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w, eps, nh, nkv, hd, block_size);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}

@@ -1,0 +1,132 @@
+// Greedy sampling, accept/reject and tree-fork selection kernels.
+//  * ssd_argmax_rows    replaces Sampler.forward at temperature 0 (reference ssd/layers/sampler.py:15-20)
+//                       and `logits_p.argmax(dim=-1)` (reference ssd/utils/verify.py:34).  Ties resolve to
+//                       the lowest index (what torch's CPU argmax returns).
+//  * ssd_verify_greedy  replaces the greedy branch of verify() (reference ssd/utils/verify.py:28-48):
+//                       first mismatch between draft tokens and target argmax via wave ballot +
+//                       count-trailing-zeros, recovery token gathered at that position.
+//  * ssd_fork_topf      replaces get_forked_recovery_tokens_from_logits (reference
+//                       ssd/utils/async_helpers/async_spec_helpers.py:26-78): top-F per glue position with
+//                       the draft's own next token excluded for positions 0..K-1.
+#include "common.h"
+
+struct ArgBest { float v; int i; };
+
+__device__ __forceinline__ ArgBest better(ArgBest a, ArgBest b) {
+  if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
+  return a;
+}
+
+// Block-wide argmax of one bf16 row with up to NEX excluded indices.
+template <int THREADS>
+__device__ ArgBest block_row_argmax(const bf16_t* __restrict__ row, int V, const int* excl, int nex, ArgBest* sm) {
+  ArgBest best = {-INFINITY, 0x7fffffff};
+  const int V8 = V >> 3;
+  for (int c = threadIdx.x; c < V8; c += THREADS) {
+    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(row + (size_t)c * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float lo = bf2f(v[j] & 0xffffu), hi = bf2f(v[j] >> 16);
+      const int i0 = c * 8 + 2 * j;
+      bool e0 = false, e1 = false;
+      for (int e = 0; e < nex; ++e) { e0 |= (excl[e] == i0); e1 |= (excl[e] == i0 + 1); }
+      if (!e0 && (lo > best.v || (lo == best.v && i0 < best.i))) best = {lo, i0};
+      if (!e1 && (hi > best.v || (hi == best.v && i0 + 1 < best.i))) best = {hi, i0 + 1};
+    }
+  }
+  for (int i = V8 * 8 + threadIdx.x; i < V; i += THREADS) {  // tail (V % 8)
+    bool ex = false;
+    for (int e = 0; e < nex; ++e) ex |= (excl[e] == i);
+    const float x = bf2f(row[i]);
+    if (!ex && (x > best.v || (x == best.v && i < best.i))) best = {x, i};
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ArgBest other = {__shfl_xor(best.v, o, 64), __shfl_xor(best.i, o, 64)};
+    best = better(best, other);
+  }
+  __syncthreads();  // protect sm reuse across calls
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = best;
+  __syncthreads();
+  ArgBest r = sm[0];
+  for (int w = 1; w < THREADS / 64; ++w) r = better(r, sm[w]);
+  return r;
+}
+
+constexpr int ARG_THREADS = 1024;
+
+__global__ void __launch_bounds__(ARG_THREADS)
+argmax_rows_kernel(const bf16_t* __restrict__ logits, long ld, int V, int64_t* __restrict__ out, int64_t* __restrict__ out2) {
+  __shared__ ArgBest sm[ARG_THREADS / 64];
+  const ArgBest r = block_row_argmax<ARG_THREADS>(logits + (size_t)blockIdx.x * ld, V, nullptr, 0, sm);
+  if (threadIdx.x == 0) {
+    out[blockIdx.x] = r.i;
+    if (out2) out2[blockIdx.x] = r.i;
+  }
+}
+
+extern "C" int ssd_argmax_rows(const void* logits, long ld, int T, int V, int64_t* out, int64_t* out2, void* stream) {
+  if (T <= 0 || V <= 0 || (ld & 7)) return SSD_ERR_SHAPE;
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(T), dim3(ARG_THREADS), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, V,
+                     out, out2);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
+// One wave per sequence.  speculations[b] = [recovery, x_1 .. x_K]; preds[b][i] = argmax of target row i.
+// accept_len[b] = number of accepted draft tokens n (0..K); recovery[b] = preds[b][n];
+// out_suffix[b] (optional, [K+2] per seq) = [n+1, recovery_prev, x_1..x_n ...] packed for one D2H copy.
+__global__ void verify_greedy_kernel(const int64_t* __restrict__ preds, const int64_t* __restrict__ spec, int K,
+                                     int32_t* __restrict__ accept_len, int64_t* __restrict__ recovery) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  bool mismatch = false;
+  if (lane < K) mismatch = spec[(size_t)b * (K + 1) + lane + 1] != preds[(size_t)b * (K + 1) + lane];
+  const unsigned long long mask = __ballot(mismatch);
+  const int n = mask ? (int)__builtin_ctzll(mask) : K;
+  if (lane == 0) {
+    accept_len[b] = n;
+    recovery[b] = preds[(size_t)b * (K + 1) + n];
+  }
+}
+
+extern "C" int ssd_verify_greedy(const int64_t* preds, const int64_t* speculations, int B, int K, int32_t* accept_len,
+                                 int64_t* recovery, void* stream) {
+  if (B <= 0 || K < 0 || K > 63) return SSD_ERR_SHAPE;
+  hipLaunchKernelGGL(verify_greedy_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, preds, speculations, K, accept_len,
+                     recovery);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
+// logits [B*(K+1)][ld]; returned [B][K+1] = (rec, x_1..x_K); counts [B][K+1] fan-out per position
+// (hit or miss list already selected per sequence); out [B][mq] flattened in position order.
+constexpr int FORK_THREADS = 1024;
+constexpr int FORK_MAXF = 16;
+__global__ void __launch_bounds__(FORK_THREADS)
+fork_topf_kernel(const bf16_t* __restrict__ logits, long ld, int V, const int64_t* __restrict__ returned,
+                 const int32_t* __restrict__ counts, const int32_t* __restrict__ offsets, int K, int mq,
+                 int64_t* __restrict__ out) {
+  __shared__ ArgBest sm[FORK_THREADS / 64];
+  __shared__ int excl[FORK_MAXF + 1];
+  const int b = blockIdx.x / (K + 1), j = blockIdx.x % (K + 1);
+  const int cnt = counts[b * (K + 1) + j];
+  int nex = 0;
+  if (threadIdx.x == 0 && j < K) excl[0] = (int)returned[(size_t)b * (K + 1) + j + 1];
+  if (j < K) nex = 1;
+  __syncthreads();
+  for (int f = 0; f < cnt; ++f) {
+    const ArgBest r = block_row_argmax<FORK_THREADS>(logits + (size_t)blockIdx.x * ld, V, excl, nex, sm);
+    if (threadIdx.x == 0) {
+      out[(size_t)b * mq + offsets[b * (K + 1) + j] + f] = r.i;
+      excl[nex] = r.i;
+    }
+    ++nex;
+    __syncthreads();
+  }
+}
+
+extern "C" int ssd_fork_topf(const void* logits, long ld, int V, const int64_t* returned_tokens, const int32_t* counts,
+                             const int32_t* offsets, int B, int K, int mq, int64_t* out, void* stream) {
+  if (B <= 0 || K < 0 || V <= 0 || (ld & 7)) return SSD_ERR_SHAPE;
+  hipLaunchKernelGGL(fork_topf_kernel, dim3(B * (K + 1)), dim3(FORK_THREADS), 0, (hipStream_t)stream,
+                     (const bf16_t*)logits, ld, V, returned_tokens, counts, offsets, K, mq, out);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}

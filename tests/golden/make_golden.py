@@ -1,0 +1,433 @@
+"""Generate the committed golden vectors by running the REFERENCE's own code on CPU.
+
+Run in the build container only (needs /root/reference):  ``python tests/golden/make_golden.py``
+Everything executed here is the reference's module code (imported through oracle/ref_shim.py, which stubs
+only the un-vendored CUDA wheels); the outputs are what tests/test_oracle_golden.py replays through
+oracle/ and what the GPU parity tests compare the HIP path against.
+
+Fixtures written next to this file:
+  ops_golden.npz     per-op vectors: RMSDNorm / RMSHeadNorm (compiled), RotaryEmbedding (compiled),
+                     SiluAndMul (compiled), linears, embedding, LM head, Sampler(temp 0)
+  logic_golden.npz   verify() greedy cases, tree fork, custom tree masks
+  tiny_llama.npz     tiny LlamaForCausalLM: weights, prefill / decode / verify / tree-decode logits
+  tiny_qwen3.npz     tiny Qwen3ForCausalLM: weights, prefill / verify logits
+  engine_golden.npz  greedy AR token stream and sync-SD accepted-suffix trace driven by reference modules
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle.ref_shim import load_reference, TreeShim  # noqa: E402
+from oracle.io import save_npz  # noqa: E402
+
+ref = load_reference()
+from ssd.layers.layernorm import RMSDNorm, RMSHeadNorm  # noqa: E402
+from ssd.layers.rotary_embedding import RotaryEmbedding  # noqa: E402
+from ssd.layers.activation import SiluAndMul  # noqa: E402
+from ssd.layers.linear import QKVParallelLinear, MergedColumnParallelLinear, RowParallelLinear  # noqa: E402
+from ssd.layers.embed_head import VocabParallelEmbedding, ParallelLMHead  # noqa: E402
+from ssd.layers.sampler import Sampler  # noqa: E402
+from ssd.utils.verify import verify  # noqa: E402
+from ssd.utils.context import set_context, get_context, reset_context  # noqa: E402
+from ssd.utils.async_helpers.async_spec_helpers import get_forked_recovery_tokens_from_logits  # noqa: E402
+from ssd.engine.helpers.mask_helpers import get_custom_mask  # noqa: E402
+from ssd.models.llama3 import LlamaForCausalLM  # noqa: E402
+from ssd.models.qwen3 import Qwen3ForCausalLM  # noqa: E402
+import ssd.layers.rotary_embedding as rope_mod  # noqa: E402
+
+BF = torch.bfloat16
+
+
+def gen_ops():
+    torch.manual_seed(1234)
+    out = {}
+    torch.set_default_dtype(BF)
+    # ---- RMSDNorm (hidden norm) ----
+    H = 512
+    norm = RMSDNorm(H, eps=1e-5)
+    norm.weight.data = (1.0 + 0.1 * torch.randn(H)).to(BF)
+    x = torch.randn(7, H).to(BF)
+    res = torch.randn(7, H).to(BF)
+    out["norm_w"], out["norm_x"], out["norm_res"] = norm.weight.data.clone(), x.clone(), res.clone()
+    out["norm_y"] = norm(x.clone()).clone()
+    y, r = norm(x.clone(), res.clone())
+    out["addnorm_y"], out["addnorm_res"] = y.clone(), r.clone()
+    # ---- RMSHeadNorm (Qwen3 q/k norm) ----
+    hn = RMSHeadNorm(64, eps=1e-6)
+    hn.weight.data = (1.0 + 0.1 * torch.randn(64)).to(BF)
+    xh = torch.randn(7 * 4, 64).to(BF)
+    out["hnorm_w"], out["hnorm_x"], out["hnorm_y"] = hn.weight.data.clone(), xh.clone(), hn(xh.clone()).clone()
+    # ---- RoPE ----
+    rot = RotaryEmbedding(64, 64, 512, 500000.0)
+    pos = torch.tensor([0, 1, 5, 17, 130, 255, 511], dtype=torch.int64)
+    q = torch.randn(7, 4 * 64).to(BF)
+    k = torch.randn(7, 2 * 64).to(BF)
+    qo, ko = rot(pos, q.clone(), k.clone())
+    out["rope_pos"], out["rope_q"], out["rope_k"] = pos, q, k
+    out["rope_qo"], out["rope_ko"] = qo.clone(), ko.clone()
+    out["rope_cache"] = rot.cos_sin_cache.float().clone()
+    # ---- SiluAndMul ----
+    act = SiluAndMul()
+    xa = (2.0 * torch.randn(7, 2 * 256)).to(BF)
+    out["silu_x"], out["silu_y"] = xa, act(xa.clone()).clone()
+    # ---- linears (TP=1) ----
+    qkv = QKVParallelLinear(256, 64, 4, 2, bias=False)
+    qkv.weight.data = (0.05 * torch.randn(qkv.weight.shape)).to(BF)
+    xl = torch.randn(7, 256).to(BF)
+    out["qkv_w"], out["lin_x"], out["qkv_y"] = qkv.weight.data.clone(), xl, qkv(xl).clone()
+    gu = MergedColumnParallelLinear(256, [512, 512])
+    gu.weight.data = (0.05 * torch.randn(gu.weight.shape)).to(BF)
+    out["gu_w"], out["gu_y"] = gu.weight.data.clone(), gu(xl).clone()
+    out["gu_act"] = act(gu(xl)).clone()
+    dn = RowParallelLinear(512, 256)
+    dn.weight.data = (0.05 * torch.randn(dn.weight.shape)).to(BF)
+    xd = torch.randn(7, 512).to(BF)
+    out["dn_w"], out["dn_x"], out["dn_y"] = dn.weight.data.clone(), xd, dn(xd).clone()
+    # ---- embedding + LM head + greedy sampler ----
+    emb = VocabParallelEmbedding(1000, 256)
+    emb.weight.data = torch.randn(1000, 256).to(BF)
+    ids = torch.tensor([0, 999, 5, 77, 500, 1, 2], dtype=torch.int64)
+    out["emb_w"], out["emb_ids"], out["emb_y"] = emb.weight.data.clone(), ids, emb(ids).clone()
+    head = ParallelLMHead(1000, 256)
+    head.weight.data = (0.05 * torch.randn(1000, 256)).to(BF)
+    reset_context()
+    lg = head(xl)
+    out["head_w"], out["head_logits"] = head.weight.data.clone(), lg.clone()
+    samp = Sampler()
+    out["sample_tokens"] = samp(lg, torch.zeros(7, dtype=torch.float32)).clone()
+    torch.set_default_dtype(torch.float32)
+    save_npz(os.path.join(HERE, "ops_golden.npz"), out)
+    print("ops_golden.npz written")
+
+
+def gen_logic():
+    torch.manual_seed(99)
+    out = {}
+    # ---- verify(), greedy ----
+    B, K, V = 5, 6, 300
+    logits_p = torch.randn(B, K + 1, V).to(BF)
+    preds = logits_p.argmax(-1)
+    spec = torch.randint(0, V, (B, K + 1), dtype=torch.int64)
+    spec[0, 1:] = preds[0, :-1]                 # all accepted
+    spec[1, 1:4] = preds[1, :3]                 # first mismatch at 3 (unless random collision)
+    spec[1, 4] = (preds[1, 3] + 1) % V
+    spec[2, 1] = (preds[2, 0] + 1) % V          # mismatch at 0
+    spec[3, 1:] = preds[3, :-1]
+    spec[3, K] = (preds[3, K - 1] + 1) % V      # mismatch at last
+    temps = torch.zeros(B)
+    logits_q = torch.randn(B, K, V).to(BF)
+    suffixes, rec = verify(logits_p, logits_q, spec, temps, temps, cache_hits=torch.ones(B, dtype=torch.int64))
+    out["v_logits_p"], out["v_spec"] = logits_p, spec
+    out["v_suffix_len"] = torch.tensor([len(s) for s in suffixes])
+    flat = torch.full((B, K + 1), -1, dtype=torch.int64)
+    for b, s in enumerate(suffixes):
+        flat[b, :len(s)] = torch.tensor(s)
+    out["v_suffix"], out["v_rec"] = flat, torch.tensor(rec)
+    # ---- tree fork ----
+    Kf, F = 3, 2
+    cfg = types.SimpleNamespace(speculate_k=Kf, fan_out_list=[2, 2, 3, 1], fan_out_list_miss=[3, 2, 2, 1], max_model_len=256,
+                                async_fan_out=F)
+    lg = torch.randn(2, Kf + 1, 500).to(BF)
+    returned = torch.stack([torch.cat([torch.tensor([7]), lg[b, :-1].argmax(-1)]) for b in range(2)])  # draft took argmax
+    hits = torch.tensor([1, 0])
+    idx = get_forked_recovery_tokens_from_logits(cfg, lg, hits, returned, None)
+    out["f_logits"], out["f_returned"], out["f_hits"], out["f_idx"] = lg, returned, hits, idx
+    out["f_list_hit"], out["f_list_miss"] = torch.tensor(cfg.fan_out_list), torch.tensor(cfg.fan_out_list_miss)
+    # ---- custom masks ----
+    ctx_lens = torch.tensor([40, 57])
+    for step in range(2):
+        ctx = ctx_lens + step * sum(cfg.fan_out_list)
+        m = get_custom_mask(cfg, ctx, step, Kf, F, 2, torch.device("cpu"), hits)
+        out[f"m_ctx{step}"], out[f"m_mask{step}"] = ctx, m.to(torch.uint8)
+    save_npz(os.path.join(HERE, "logic_golden.npz"), out)
+    print("logic_golden.npz written")
+
+
+class RefDriver:
+    """Drives one reference model for ONE sequence the way ModelRunner.prepare_* does
+    (ssd/engine/model_runner.py:506-550) with a non-contiguous page table."""
+
+    def __init__(self, model, cfg, block_size=16, num_blocks=24, table=None, tree=None):
+        self.m, self.cfg, self.bs = model, cfg, block_size
+        L = cfg.num_hidden_layers
+        nkv = cfg.num_key_value_heads
+        hd = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
+        self.kv = torch.zeros(2, L, num_blocks, block_size, nkv, hd, dtype=BF)
+        i = 0
+        for mod in self.m.modules():
+            if hasattr(mod, "k_cache") and hasattr(mod, "v_cache"):
+                mod.k_cache, mod.v_cache = self.kv[0, i], self.kv[1, i]
+                if tree is not None:
+                    mod.only_prefill_wrapper = tree
+                i += 1
+        self.table = table if table is not None else [5, 2, 9, 1, 7, 3, 11, 13, 17, 19, 23, 0]
+        self.bt = torch.tensor([self.table], dtype=torch.int32)
+
+    def slots(self, positions):
+        return torch.tensor([self.table[p // self.bs] * self.bs + p % self.bs for p in positions], dtype=torch.int32)
+
+    @torch.inference_mode()
+    def prefill(self, tokens, all_logits=True):
+        n = len(tokens)
+        cu = torch.tensor([0, n], dtype=torch.int32)
+        set_context(True, cu_seqlens_q=cu, cu_seqlens_k=cu, max_seqlen_q=n, max_seqlen_k=n, slot_mapping=self.slots(range(n)))
+        h = self.m(torch.tensor(tokens, dtype=torch.int64), torch.arange(n, dtype=torch.int64))
+        lg = self.m.compute_logits(h, last_only=not all_logits)
+        reset_context()
+        return lg
+
+    @torch.inference_mode()
+    def decode(self, token, pos, is_jit=True):
+        set_context(False, slot_mapping=self.slots([pos]), context_lens=torch.tensor([pos + 1], dtype=torch.int32),
+                    block_tables=self.bt, is_jit=is_jit)
+        h = self.m(torch.tensor([token], dtype=torch.int64), torch.tensor([pos], dtype=torch.int64))
+        lg = self.m.compute_logits(h)
+        reset_context()
+        return lg
+
+    @torch.inference_mode()
+    def verify(self, tokens, pos0):
+        n = len(tokens)
+        cu = torch.tensor([0, n], dtype=torch.int32)
+        set_context(False, cu_seqlens_q=cu, max_seqlen_q=n, slot_mapping=self.slots(range(pos0, pos0 + n)),
+                    context_lens=torch.tensor([pos0 + n], dtype=torch.int32), block_tables=self.bt)
+        h = self.m(torch.tensor(tokens, dtype=torch.int64), torch.arange(pos0, pos0 + n, dtype=torch.int64))
+        lg = self.m.compute_logits(h, last_only=False)
+        reset_context()
+        return lg.view(n, -1)
+
+    @torch.inference_mode()
+    def tree_step(self, tokens, rope_pos, cache_pos, ctx_len):
+        set_context(False, slot_mapping=self.slots(cache_pos), context_lens=torch.tensor([ctx_len], dtype=torch.int32),
+                    block_tables=self.bt, is_jit=False)
+        h = self.m(torch.tensor(tokens, dtype=torch.int64), torch.tensor(rope_pos, dtype=torch.int64))
+        ctx = get_context()
+        lg = torch.nn.functional.linear(h, self.m.lm_head.weight)
+        reset_context()
+        return lg
+
+
+def tiny_llama_cfg(h=128, L=2, nh=2, nkv=1, I=256, V=512):
+    from transformers import LlamaConfig
+    return LlamaConfig(hidden_size=h, num_hidden_layers=L, num_attention_heads=nh, num_key_value_heads=nkv,
+                       intermediate_size=I, vocab_size=V, max_position_embeddings=512, rms_norm_eps=1e-5,
+                       tie_word_embeddings=False, hidden_act="silu", head_dim=h // nh)
+
+
+def build(cls, cfg, seed, std, **kw):
+    torch.manual_seed(seed)
+    torch.set_default_dtype(BF)
+    rope_mod.get_rope.cache_clear()
+    m = cls(cfg, **kw)
+    for n_, p in m.named_parameters():
+        if "norm" in n_:
+            p.data = (1.0 + 0.1 * torch.randn(p.shape, dtype=torch.float32)).to(BF)
+        else:
+            p.data = (std * torch.randn(p.shape, dtype=torch.float32)).to(BF)
+    torch.set_default_dtype(torch.float32)
+    m.eval()
+    return m
+
+
+def cfg_fields(cfg, family):
+    hd = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
+    theta = 1000000.0 if family == "qwen3" else 500000.0   # what the reference's getattr default resolves to
+    return torch.tensor([cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.num_key_value_heads, hd,
+                         cfg.intermediate_size, cfg.vocab_size, cfg.max_position_embeddings]), torch.tensor([cfg.rms_norm_eps, theta])
+
+
+def gen_tiny_llama():
+    cfg = tiny_llama_cfg()
+    K, F = 2, 2
+    MQ = F * (K + 1)
+    m = build(LlamaForCausalLM, cfg, 7, 0.08, draft=True, speculate=True, spec_k=K, async_fan_out=F, draft_async=True)
+    mcfg = types.SimpleNamespace(speculate_k=K, fan_out_list=[F] * (K + 1), fan_out_list_miss=[F] * (K + 1), max_model_len=512,
+                                 async_fan_out=F)
+    tree = TreeShim(mcfg, K, F, get_context, get_custom_mask)
+    tree.cache_hits = torch.tensor([1])
+    d = RefDriver(m, cfg, tree=tree)
+    out = {"w." + k: v.data.clone() for k, v in m.state_dict().items()}
+    out["cfg_i"], out["cfg_f"] = cfg_fields(cfg, "llama")
+    out["block_table"] = d.bt.clone()
+    g = torch.Generator().manual_seed(5)
+    prompt = torch.randint(0, cfg.vocab_size, (21,), generator=g).tolist()
+    out["prompt"] = torch.tensor(prompt)
+    out["prefill_logits"] = d.prefill(prompt).clone()                       # [21, V]
+    P = len(prompt)
+    # single-token decode x2 ("JIT" path) -- positions P, P+1
+    t0 = int(out["prefill_logits"][-1].float().argmax())
+    lg0 = d.decode(t0, P)
+    t1 = int(lg0[0].float().argmax())
+    lg1 = d.decode(t1, P + 1)
+    out["decode_tokens"], out["decode_logits"] = torch.tensor([t0, t1]), torch.cat([lg0, lg1]).clone()
+    # verify / glue: K+1 tokens at positions P .. P+K (overwrites the decode KV with the same values + one more)
+    t2 = int(lg1[0].float().argmax())
+    glue_tokens = [t0, t1, t2]
+    glue = d.verify(glue_tokens, P)
+    out["verify_tokens"], out["verify_logits"] = torch.tensor(glue_tokens), glue.clone()
+    # tree decode: fork top-F per glue position excluding the trunk's own next token, then K steps
+    returned = torch.tensor([glue_tokens])
+    forks = get_forked_recovery_tokens_from_logits(mcfg, glue.view(1, K + 1, -1), torch.tensor([1]), returned, None)
+    out["tree_forks"] = forks.clone()
+    toks = forks[0].tolist()
+    jidx = [i // F for i in range(MQ)]
+    base = P  # = num_tokens - 1 in the reference's terms (trunk ends at P-1, rec token at P)
+    tree_logits = []
+    for step in range(K):
+        tree.step = step
+        rope_pos = [base + j + 1 + step for j in jidx]
+        cache_pos = [base + K + 1 + step * MQ + i for i in range(MQ)]
+        ctx_len = cache_pos[-1] + 1
+        lg = d.tree_step(toks, rope_pos, cache_pos, ctx_len)
+        tree_logits.append(lg.clone())
+        toks = lg.float().argmax(-1).tolist()
+    out["tree_logits"] = torch.stack(tree_logits)                                # [K, MQ, V]
+    out["tree_K_F"] = torch.tensor([K, F])
+    save_npz(os.path.join(HERE, "tiny_llama.npz"), out)
+    print("tiny_llama.npz written")
+    return m, cfg
+
+
+def gen_tiny_qwen():
+    # transformers >= 5 exposes rope_scaling as a dict alias of rope_parameters, which the reference's
+    # lru_cache'd get_rope cannot hash (and asserts None); in the reference's pinned environment it is None
+    # for Qwen3, so hand the model a plain namespace with exactly the fields qwen3.py reads.
+    cfg = types.SimpleNamespace(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                                head_dim=64, intermediate_size=256, vocab_size=512, max_position_embeddings=512,
+                                rms_norm_eps=1e-6, tie_word_embeddings=True, hidden_act="silu", attention_bias=False,
+                                rope_theta=1000000.0, rope_scaling=None)
+    m = build(Qwen3ForCausalLM, cfg, 11, 0.08, speculate=True, spec_k=3)
+    if cfg.tie_word_embeddings:
+        m.lm_head.weight.data = m.model.embed_tokens.weight.data
+    d = RefDriver(m, cfg)
+    out = {"w." + k: v.data.clone() for k, v in m.state_dict().items()}
+    out["cfg_i"], out["cfg_f"] = cfg_fields(cfg, "qwen3")
+    out["block_table"] = d.bt.clone()
+    g = torch.Generator().manual_seed(6)
+    prompt = torch.randint(0, cfg.vocab_size, (19,), generator=g).tolist()
+    out["prompt"] = torch.tensor(prompt)
+    out["prefill_logits"] = d.prefill(prompt).clone()
+    P = len(prompt)
+    vt = torch.randint(0, cfg.vocab_size, (4,), generator=g).tolist()
+    out["verify_tokens"], out["verify_logits"] = torch.tensor(vt), d.verify(vt, P).clone()
+    save_npz(os.path.join(HERE, "tiny_qwen3.npz"), out)
+    print("tiny_qwen3.npz written")
+
+
+def _top2_margin(row):
+    t = row.float().topk(2).values
+    return float(t[0] - t[1])
+
+
+def _engine_trace(seed_t, seed_d):
+    tcfg = tiny_llama_cfg(h=128, L=2, nh=2, nkv=1, I=256, V=512)
+    dcfg = tiny_llama_cfg(h=64, L=1, nh=1, nkv=1, I=128, V=512)
+    K = 3
+    target = build(LlamaForCausalLM, tcfg, seed_t, 0.08, speculate=True, spec_k=K)
+    out = {"t." + k: v.data.clone() for k, v in target.state_dict().items()}
+    out["t_cfg_i"], out["t_cfg_f"] = cfg_fields(tcfg, "llama")
+    g = torch.Generator().manual_seed(3)
+    prompt = torch.randint(0, 512, (13,), generator=g).tolist()
+    out["prompt"] = torch.tensor(prompt)
+    margins = []
+    # ---- AR greedy, 24 tokens ----
+    td = RefDriver(target, tcfg)
+    lg = td.prefill(prompt, all_logits=False)
+    toks = []
+    ar_m = []
+    for i in range(24):
+        margins.append(_top2_margin(lg[-1]))
+        ar_m.append(margins[-1])
+        t = int(Sampler()(lg[-1:].clone(), torch.zeros(1))[0])
+        toks.append(t)
+        lg = td.decode(t, len(prompt) + i, is_jit=False)
+    out["ar_tokens"] = torch.tensor(toks)
+    out["ar_margins"] = torch.tensor(ar_m)
+    # ---- sync SD, K=3: (a) draft == target (all accepted)  (b) independent draft ----
+    for tag in ("same", "diff"):
+        if tag == "same":
+            draft, dc = build(LlamaForCausalLM, tcfg, seed_t, 0.08, speculate=True, spec_k=K), tcfg  # same weights
+        else:
+            draft, dc = build(LlamaForCausalLM, dcfg, seed_d, 0.08, speculate=True, spec_k=K), dcfg
+            for k_, v_ in draft.state_dict().items():
+                out["d." + k_] = v_.data.clone()
+            out["d_cfg_i"], out["d_cfg_f"] = cfg_fields(dc, "llama")
+        td, dd = RefDriver(target, tcfg), RefDriver(draft, dc)
+        lg = td.prefill(prompt, all_logits=False)
+        dd.prefill(prompt, all_logits=False)
+        margins.append(_top2_margin(lg[-1]))
+        r0 = int(lg[-1].float().argmax())
+        tokens = list(prompt)
+        trace_spec, trace_sfx, trace_rec, trace_m = [], [], [], []
+        for step in range(10):
+            m0 = len(margins) - (1 if step == 0 else 0)   # step 0 also owns the prefill decision
+            N = len(tokens)
+            spec = [r0]
+            cur = r0
+            for k in range(K + 1):
+                dlg = dd.decode(cur, N + k, is_jit=False)
+                if k == K:
+                    break
+                margins.append(_top2_margin(dlg[0]))
+                cur = int(Sampler()(dlg.clone(), torch.zeros(1))[0])
+                spec.append(cur)
+            logits_p = td.verify(spec, N).view(1, K + 1, -1)
+            for j in range(K + 1):
+                margins.append(_top2_margin(logits_p[0, j]))
+            sp = torch.tensor([spec])
+            sfx, rec = verify(logits_p, None, sp, torch.zeros(1), torch.zeros(1), cache_hits=None)
+            trace_spec.append(spec)
+            trace_sfx.append(sfx[0] + [-1] * (K + 1 - len(sfx[0])))
+            trace_rec.append(rec[0])
+            trace_m.append(min(margins[m0:]))
+            tokens.extend(sfx[0])
+            r0 = rec[0]
+        out[f"sd_{tag}_spec"] = torch.tensor(trace_spec)
+        out[f"sd_{tag}_suffix"] = torch.tensor(trace_sfx)
+        out[f"sd_{tag}_rec"] = torch.tensor(trace_rec)
+        out[f"sd_{tag}_margins"] = torch.tensor(trace_m)   # min top-2 margin of the decisions taken in each step
+        out[f"sd_{tag}_tokens"] = torch.tensor(tokens[len(prompt):])
+    out["sd_K"] = torch.tensor(K)
+    out["min_margin"] = torch.tensor(min(margins))
+    return out, min(margins)
+
+
+def gen_engine():
+    """Greedy AR stream and sync-SD trace.  Loop structure follows AutoRegressiveStep (ssd/engine/step.py:28-53)
+    and SpecDecodeStep + SpeculatorSync + Verifier (step.py:91-163, speculator_sync.py:25-69, verifier.py:54-153),
+    sequence-state invariants per SURVEY.md A.6; the model forwards and verify() are the reference's.
+    A few seeds are scanned for the largest minimum top-2 logit margin, and the margin of every greedy
+    decision is stored, so a comparison against an implementation with a different accumulation order can
+    stop at the first near-tie instead of calling it a mismatch."""
+    best = None
+    for seed in range(21, 61):
+        out, mm = _engine_trace(seed, seed + 1000)
+        if best is None or mm > best[1]:
+            best = (out, mm, seed)
+        if mm >= 0.0625:
+            break
+    out, mm, seed = best
+    out["seed"] = torch.tensor(seed)
+    save_npz(os.path.join(HERE, "engine_golden.npz"), out)
+    print("engine_golden.npz written; seed", seed, "min margin", mm)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["ops", "logic", "llama", "qwen", "engine"]
+    if "ops" in which:
+        gen_ops()
+    if "logic" in which:
+        gen_logic()
+    if "llama" in which:
+        gen_tiny_llama()
+    if "qwen" in which:
+        gen_tiny_qwen()
+    if "engine" in which:
+        gen_engine()
