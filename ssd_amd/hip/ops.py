@@ -1,0 +1,97 @@
+"""Thin torch-tensor front end over the C ABI (include/ssd_hip.h).
+
+PyTorch is used here only as a device-memory carrier: every function passes raw device pointers and the
+current HIP stream to libssdhip and returns nothing new (callers own all buffers, so the calls are
+hipGraph-capturable).  No function in this module computes anything in torch.
+"""
+from __future__ import annotations
+
+import torch
+
+from .lib import load_library, SsdHipError
+
+EPI_ROWS, EPI_SILU_FRAG, EPI_ROWS_F32 = 0, 1, 2
+MODE_CAUSAL, MODE_TREE = 0, 1
+
+
+def _p(t) -> int:
+    if t is None:
+        return 0
+    assert t.is_cuda and t.is_contiguous(), "libssdhip needs contiguous device tensors"
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check(rc: int, name: str):
+    if rc != 0:
+        raise SsdHipError(f"{name} failed with code {rc}")
+
+
+def frag_numel(M: int, K: int) -> int:
+    return ((M + 15) // 16) * 16 * K
+
+
+def rows_to_frag(src: torch.Tensor, dst: torch.Tensor, R: int, K: int, mode: int = 0):
+    _check(load_library().ssd_rows_to_frag(_p(src), _p(dst), R, K, mode, _stream()), "ssd_rows_to_frag")
+
+
+def frag_to_rows(src: torch.Tensor, dst: torch.Tensor, R: int, K: int):
+    _check(load_library().ssd_frag_to_rows(_p(src), _p(dst), R, K, _stream()), "ssd_frag_to_rows")
+
+
+def embedding(ids, table, out_rows, T: int, H: int, vocab_start: int = 0, vocab_count: int | None = None):
+    vc = table.shape[0] if vocab_count is None else vocab_count
+    _check(load_library().ssd_embedding(_p(ids), _p(table), _p(out_rows), T, H, vocab_start, vc, _stream()), "ssd_embedding")
+
+
+def rmsnorm(x_rows, weight, eps: float, T: int, H: int, res_in=None, res_out=None, out_rows=None, out_frag=None, gather=None):
+    _check(load_library().ssd_rmsnorm(_p(x_rows), _p(res_in), _p(res_out), _p(weight), eps, _p(out_rows), _p(out_frag),
+                                      _p(gather), T, H, _stream()), "ssd_rmsnorm")
+
+
+def gemm(x_frag, w_frag, y, M: int, N: int, K: int, ldy: int, epilogue: int = EPI_ROWS, bias=None, cfg=None):
+    lib = load_library()
+    if cfg is None:
+        rc = lib.ssd_gemm_wf(_p(x_frag), _p(w_frag), _p(bias), _p(y), M, N, K, ldy, epilogue, _stream())
+    else:
+        rc = lib.ssd_gemm_wf_cfg(_p(x_frag), _p(w_frag), _p(bias), _p(y), M, N, K, ldy, epilogue, cfg[0], cfg[1], _stream())
+    _check(rc, "ssd_gemm_wf")
+
+
+def rope_store_kv(qkv_rows, positions, cos_sin, slot_mapping, q_out, k_cache, v_cache, T, nh, nkv, hd, block_size,
+                  q_norm_w=None, k_norm_w=None, eps: float = 0.0):
+    _check(load_library().ssd_rope_store_kv(_p(qkv_rows), _p(positions), _p(cos_sin), _p(slot_mapping), _p(q_out),
+                                            _p(k_cache), _p(v_cache), _p(q_norm_w), _p(k_norm_w), eps, T, nh, nkv, hd,
+                                            block_size, _stream()), "ssd_rope_store_kv")
+
+
+def attn_paged(q_rows, k_cache, v_cache, block_tables, max_blocks, context_lens, B, T, max_q, nh, nkv, hd, block_size,
+               scale, cu_q=None, q_per_seq=0, mode=MODE_CAUSAL, tree_K=0, tree_mq=0, tree_step=0, tree_F=1, tree_jidx=None,
+               splits=1, flags=0, ws_o=None, ws_ml=None, out_rows=None, out_frag=None):
+    _check(load_library().ssd_attn_paged(_p(q_rows), _p(k_cache), _p(v_cache), _p(block_tables), max_blocks,
+                                         _p(context_lens), _p(cu_q), q_per_seq, B, T, max_q, nh, nkv, hd, block_size,
+                                         scale, mode, tree_K, tree_mq, tree_step, tree_F, _p(tree_jidx), splits, flags,
+                                         _p(ws_o), _p(ws_ml), _p(out_rows), _p(out_frag), _stream()), "ssd_attn_paged")
+
+
+def argmax_rows(logits, ld: int, T: int, V: int, out, out2=None):
+    _check(load_library().ssd_argmax_rows(_p(logits), ld, T, V, _p(out), _p(out2), _stream()), "ssd_argmax_rows")
+
+
+def verify_greedy(preds, speculations, B: int, K: int, accept_len, recovery):
+    _check(load_library().ssd_verify_greedy(_p(preds), _p(speculations), B, K, _p(accept_len), _p(recovery), _stream()),
+           "ssd_verify_greedy")
+
+
+def fork_topf(logits, ld: int, V: int, returned, counts, offsets, B: int, K: int, mq: int, out):
+    _check(load_library().ssd_fork_topf(_p(logits), ld, V, _p(returned), _p(counts), _p(offsets), B, K, mq, _p(out),
+                                        _stream()), "ssd_fork_topf")
+
+
+def draft_advance(next_ids, input_ids, positions, slots, context_lens, block_tables, max_blocks, block_size, spec, K, step, B):
+    _check(load_library().ssd_draft_advance(_p(next_ids), _p(input_ids), _p(positions), _p(slots), _p(context_lens),
+                                            _p(block_tables), max_blocks, block_size, _p(spec), K, _p(step), B, _stream()),
+           "ssd_draft_advance")

@@ -1,0 +1,388 @@
+"""GPU parity of every libssdhip kernel, called through the C ABI, against the CPU oracle and against the
+golden vectors produced by the reference's own code.  Bit-exact for integer results; for bf16 results the
+bar is "identical up to the accumulation order": at most 1 bf16 ulp on a small fraction of elements (2 ulp for
+attention, whose P operand is bf16 as in FlashAttention).  fp32 GEMM output is checked to 1e-3 absolute."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ops as O
+from oracle import layout as LY
+from tests.util import assert_close_bf16
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def H():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ssd_amd.hip import ops
+    from ssd_amd.hip.lib import load_library
+    load_library()
+    return ops
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def to_frag_dev(x):
+    return dev(LY.rows_to_frag_ref(x))
+
+
+# ------------------------------------------------------------------------------------------------
+def test_layout_kernels(H):
+    torch.manual_seed(0)
+    for R, K in [(7, 64), (16, 256), (40, 4096), (512, 128)]:
+        x = torch.randn(R, K).to(BF)
+        ref = LY.rows_to_frag_ref(x)
+        out = torch.zeros(H.frag_numel(R, K), dtype=BF, device="cuda")
+        H.rows_to_frag(dev(x), out, R, K)
+        assert torch.equal(out.cpu().view(torch.int16), ref.view(torch.int16))
+        back = torch.empty(R, K, dtype=BF, device="cuda")
+        H.frag_to_rows(out, back, R, K)
+        assert torch.equal(back.cpu().view(torch.int16), x.view(torch.int16))
+    w = torch.randn(128, 64).to(BF)   # gate/up interleave
+    out = torch.zeros(128 * 64, dtype=BF, device="cuda")
+    H.rows_to_frag(dev(w), out, 128, 64, mode=1)
+    assert torch.equal(out.cpu().view(torch.int16), LY.rows_to_frag_ref(LY.interleave_gate_up_rows(w)).view(torch.int16))
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 256, 256), (7, 6144, 4096), (8, 4096, 14336), (16, 512, 2048), (24, 2048, 2048),
+                                   (33, 256, 1024), (100, 1024, 512), (128, 512, 4096), (7, 128256 // 8, 1024), (5, 272, 96)])
+def test_gemm_vs_oracle(H, M, N, K):
+    torch.manual_seed(M * 1000 + N + K)
+    x = torch.randn(M, K).to(BF)
+    w = (torch.randn(N, K) * 0.05).to(BF)
+    # asymmetric structure so a transposed / permuted tile cannot pass
+    w[3, :] = 0.5
+    x[M - 1, : K // 2] = -1.0
+    ref = O.linear(x, w)
+    xf, wf = to_frag_dev(x), to_frag_dev(w)
+    y = torch.full((M, N), float("nan"), dtype=BF, device="cuda")
+    H.gemm(xf, wf, y, M, N, K, N)
+    assert_close_bf16(y, ref, max_ulp=1, max_frac=0.03, what="gemm rows")
+    # fp32 epilogue against an fp64 reference: <= 1e-3 abs (north_star logits tolerance)
+    y32 = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+    H.gemm(xf, wf, y32, M, N, K, N, epilogue=H.EPI_ROWS_F32)
+    ref64 = (x.double() @ w.double().t())
+    assert (y32.cpu().double() - ref64).abs().max().item() <= 1e-3
+
+
+def test_gemm_configs_and_bias(H):
+    torch.manual_seed(5)
+    M, N, K = 7, 1024, 2048
+    x = torch.randn(M, K).to(BF)
+    w = (torch.randn(N, K) * 0.05).to(BF)
+    b = torch.randn(N).to(BF)
+    ref = O.linear(x, w, b)
+    xf, wf = to_frag_dev(x), to_frag_dev(w)
+    outs = []
+    for nt in (1, 2, 4):
+        for waves in (1, 3, 4, 8, 16):
+            y = torch.zeros(M, N, dtype=BF, device="cuda")
+            H.gemm(xf, wf, y, M, N, K, N, bias=dev(b), cfg=(nt, waves))
+            assert_close_bf16(y, ref, max_ulp=1, max_frac=0.03, what=f"gemm cfg {nt},{waves}")
+            outs.append(y.clone())
+    # determinism: same config twice -> identical bits
+    y2 = torch.zeros(M, N, dtype=BF, device="cuda")
+    H.gemm(xf, wf, y2, M, N, K, N, bias=dev(b), cfg=(4, 16))
+    assert torch.equal(y2.view(torch.int16), outs[-1].view(torch.int16))
+
+
+@pytest.mark.parametrize("M", [1, 7, 24, 70])
+def test_gemm_silu_epilogue(H, M):
+    torch.manual_seed(M)
+    I, K = 512, 1024
+    x = torch.randn(M, K).to(BF)
+    w = (torch.randn(2 * I, K) * 0.06).to(BF)
+    ref = O.silu_mul(O.linear(x, w))
+    wf = torch.zeros(2 * I * K, dtype=BF, device="cuda")
+    H.rows_to_frag(dev(w), wf, 2 * I, K, mode=1)
+    act_f = torch.zeros(H.frag_numel(M, I), dtype=BF, device="cuda")
+    H.gemm(to_frag_dev(x), wf, act_f, M, 2 * I, K, 0, epilogue=H.EPI_SILU_FRAG)
+    act = LY.frag_to_rows_ref(act_f.cpu(), M, I)
+    assert_close_bf16(act, ref, max_ulp=1, max_frac=0.03, what="gemm+silu")
+
+
+def test_embedding(H, golden):
+    g = golden("ops_golden")
+    out = torch.zeros(7, 256, dtype=BF, device="cuda")
+    H.embedding(dev(g["emb_ids"]), dev(g["emb_w"]), out, 7, 256)
+    assert torch.equal(out.cpu().view(torch.int16), g["emb_y"].view(torch.int16))
+    # TP-style shard [500, 1000): rows outside give zeros
+    H.embedding(dev(g["emb_ids"]), dev(g["emb_w"][500:].contiguous()), out, 7, 256, vocab_start=500, vocab_count=500)
+    ref = O.embedding(g["emb_ids"], g["emb_w"][500:], 500)
+    assert torch.equal(out.cpu().view(torch.int16), ref.view(torch.int16))
+
+
+def test_rmsnorm_golden(H, golden):
+    g = golden("ops_golden")
+    T, Hd = g["norm_x"].shape
+    y = torch.zeros(T, Hd, dtype=BF, device="cuda")
+    yf = torch.zeros(H.frag_numel(T, Hd), dtype=BF, device="cuda")
+    H.rmsnorm(dev(g["norm_x"]), dev(g["norm_w"]), 1e-5, T, Hd, out_rows=y, out_frag=yf)
+    assert_close_bf16(y, g["norm_y"], max_ulp=1, max_frac=0.005, what="rmsnorm")
+    assert torch.equal(LY.frag_to_rows_ref(yf.cpu(), T, Hd).view(torch.int16), y.cpu().view(torch.int16))
+    res = torch.zeros(T, Hd, dtype=BF, device="cuda")
+    H.rmsnorm(dev(g["norm_x"]), dev(g["norm_w"]), 1e-5, T, Hd, res_in=dev(g["norm_res"]), res_out=res, out_rows=y)
+    assert torch.equal(res.cpu().view(torch.int16), g["addnorm_res"].view(torch.int16))
+    assert_close_bf16(y, g["addnorm_y"], max_ulp=1, max_frac=0.005, what="add+rmsnorm")
+
+
+@pytest.mark.parametrize("T,Hd", [(1, 2048), (7, 4096), (24, 8192), (3, 1024), (130, 5120)])
+def test_rmsnorm_shapes(H, T, Hd):
+    torch.manual_seed(T + Hd)
+    x, r = torch.randn(T, Hd).to(BF), torch.randn(T, Hd).to(BF)
+    w = (1 + 0.1 * torch.randn(Hd)).to(BF)
+    yr, rr = O.rmsnorm(x, w, 1e-6, r)
+    y = torch.zeros(T, Hd, dtype=BF, device="cuda")
+    res = torch.zeros(T, Hd, dtype=BF, device="cuda")
+    H.rmsnorm(dev(x), dev(w), 1e-6, T, Hd, res_in=dev(r), res_out=res, out_rows=y)
+    assert torch.equal(res.cpu().view(torch.int16), rr.view(torch.int16))
+    assert_close_bf16(y, yr, max_ulp=1, max_frac=0.005, what="add+rmsnorm")
+    # gather (prefill last-token rows)
+    idx = torch.tensor([T - 1, 0], dtype=torch.int32)
+    yg = torch.zeros(2, Hd, dtype=BF, device="cuda")
+    H.rmsnorm(dev(x), dev(w), 1e-6, 2, Hd, res_in=dev(r), out_rows=yg, gather=dev(idx))
+    assert torch.equal(yg.cpu().view(torch.int16), y.cpu()[idx.long()].view(torch.int16))
+
+
+def run_rope(H, qkv, pos, cache, slots, nh, nkv, hd, bs, nblocks, qn=None, kn=None, eps=0.0):
+    T = qkv.shape[0]
+    q_out = torch.zeros(T, nh * hd, dtype=BF, device="cuda")
+    kc = torch.zeros(nblocks, nkv, bs, hd, dtype=BF, device="cuda")
+    vc = torch.zeros_like(kc)
+    H.rope_store_kv(dev(qkv), dev(pos), dev(cache), dev(slots), q_out, kc, vc, T, nh, nkv, hd, bs,
+                    q_norm_w=None if qn is None else dev(qn), k_norm_w=None if kn is None else dev(kn), eps=eps)
+    return q_out.cpu(), kc.cpu(), vc.cpu()
+
+
+def test_rope_store_golden(H, golden):
+    g = golden("ops_golden")
+    T, nh, nkv, hd, bs, nb = 7, 4, 2, 64, 16, 6
+    v = torch.randn(T, nkv * hd).to(BF)
+    qkv = torch.cat([g["rope_q"], g["rope_k"], v], dim=1)
+    slots = torch.tensor([5, 17, -1, 40, 95, 0, 33], dtype=torch.int32)
+    q_out, kc, vc = run_rope(H, qkv, g["rope_pos"], g["rope_cache"], slots, nh, nkv, hd, bs, nb)
+    assert torch.equal(q_out.view(torch.int16), g["rope_qo"].view(torch.int16))          # bit-exact vs the reference
+    kref = torch.zeros(nb, bs, nkv, hd, dtype=BF)
+    vref = torch.zeros_like(kref)
+    O.store_kv(g["rope_ko"].view(T, nkv, hd), v.view(T, nkv, hd), kref, vref, slots)
+    assert torch.equal(LY.kv_hnd_to_nhd(kc).view(torch.int16), kref.view(torch.int16))
+    assert torch.equal(LY.kv_hnd_to_nhd(vc).view(torch.int16), vref.view(torch.int16))
+
+
+def test_rope_head_norm(H):
+    torch.manual_seed(3)
+    T, nh, nkv, hd, bs, nb = 5, 8, 2, 128, 16, 4
+    qkv = torch.randn(T, (nh + 2 * nkv) * hd).to(BF)
+    qn, kn = (1 + 0.1 * torch.randn(hd)).to(BF), (1 + 0.1 * torch.randn(hd)).to(BF)
+    pos = torch.tensor([0, 3, 9, 100, 101], dtype=torch.int64)
+    cache = O.make_cos_sin_cache(hd, 256, 1e6)
+    slots = torch.arange(T, dtype=torch.int32) + 7
+    q, k, v = qkv.split([nh * hd, nkv * hd, nkv * hd], dim=1)
+    qr = O.rmsnorm(q.reshape(-1, hd), qn, 1e-6).reshape(q.shape)
+    kr = O.rmsnorm(k.reshape(-1, hd), kn, 1e-6).reshape(k.shape)
+    qr, kr = O.rope(pos, qr, kr, cache, hd)
+    q_out, kc, vc = run_rope(H, qkv, pos, cache, slots, nh, nkv, hd, bs, nb, qn, kn, 1e-6)
+    assert_close_bf16(q_out, qr, max_ulp=1, max_frac=0.01, what="qk-norm+rope q")
+    kref = torch.zeros(nb, bs, nkv, hd, dtype=BF)
+    vref = torch.zeros_like(kref)
+    O.store_kv(kr.view(T, nkv, hd), v.contiguous().view(T, nkv, hd), kref, vref, slots)
+    assert_close_bf16(LY.kv_hnd_to_nhd(kc), kref, max_ulp=1, max_frac=0.01, what="qk-norm+rope k")
+    assert torch.equal(LY.kv_hnd_to_nhd(vc).view(torch.int16), vref.view(torch.int16))
+
+
+# ------------------------------------------------------------------------------------------------
+def make_paged(B, ctx_lens, nkv, hd, bs, seed):
+    """Random paged K/V in the reference layout with a shuffled page table."""
+    g = torch.Generator().manual_seed(seed)
+    max_blocks = max((L + bs - 1) // bs for L in ctx_lens) + 1
+    nblocks = B * max_blocks + 3
+    perm = torch.randperm(nblocks, generator=g)
+    bt = torch.full((B, max_blocks), -1, dtype=torch.int32)
+    p = 0
+    for b, L in enumerate(ctx_lens):
+        n = (L + bs - 1) // bs
+        bt[b, :n] = perm[p:p + n].to(torch.int32)
+        p += n
+    kc = torch.randn(nblocks, bs, nkv, hd, generator=g).to(BF)
+    vc = torch.randn(nblocks, bs, nkv, hd, generator=g).to(BF)
+    return kc, vc, bt, max_blocks
+
+
+def run_attn(H, q, kc, vc, bt, max_blocks, ctx, nh, nkv, hd, bs, cu_q=None, q_per_seq=0, splits=1, flags=0, **tree):
+    T = q.shape[0]
+    B = ctx.numel()
+    max_q = q_per_seq if cu_q is None else int((cu_q[1:] - cu_q[:-1]).max())
+    out = torch.full((T, nh * hd), float("nan"), dtype=BF, device="cuda")
+    outf = torch.zeros(H.frag_numel(T, nh * hd), dtype=BF, device="cuda")
+    ws_o = torch.zeros(T * nh * splits * hd, dtype=torch.float32, device="cuda")
+    ws_ml = torch.zeros(T * nh * splits * 2, dtype=torch.float32, device="cuda")
+    H.attn_paged(dev(q), dev(LY.kv_nhd_to_hnd(kc)), dev(LY.kv_nhd_to_hnd(vc)), dev(bt), max_blocks, dev(ctx), B, T, max_q,
+                 nh, nkv, hd, bs, hd ** -0.5, cu_q=None if cu_q is None else dev(cu_q), q_per_seq=q_per_seq, splits=splits,
+                 flags=flags, ws_o=ws_o, ws_ml=ws_ml, out_rows=out, out_frag=outf, **tree)
+    torch.cuda.synchronize()
+    rows = out.cpu()
+    assert torch.equal(LY.frag_to_rows_ref(outf.cpu(), T, nh * hd).view(torch.int16), rows.view(torch.int16))
+    return rows
+
+
+ATTN_TOL = dict(max_ulp=2, max_frac=0.25, abs_floor=2e-3)
+
+
+@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("nh,nkv,hd", [(32, 8, 128), (32, 8, 64), (16, 8, 128), (8, 1, 128)])
+def test_attn_decode_and_verify(H, nh, nkv, hd, flags):
+    bs = 16
+    for (B, qps, ctx_lens, splits) in [(1, 1, [37], 1), (3, 1, [1, 64, 333], 4), (1, 7, [135], 1), (2, 8, [640, 77], 5),
+                                       (1, 24, [200], 3)]:
+        kc, vc, bt, mb = make_paged(B, ctx_lens, nkv, hd, bs, seed=B * 100 + qps)
+        torch.manual_seed(qps)
+        q = torch.randn(B * qps, nh, hd).to(BF)
+        ctx = torch.tensor(ctx_lens, dtype=torch.int32)
+        cu = torch.arange(B + 1, dtype=torch.int32) * qps
+        ref = O.attn_paged(q, kc, vc, ctx, bt, hd ** -0.5, cu_q=cu).reshape(B * qps, nh * hd)
+        got = run_attn(H, q.view(B * qps, -1), kc, vc, bt, mb, ctx, nh, nkv, hd, bs, q_per_seq=qps, splits=splits, flags=flags)
+        assert_close_bf16(got, ref, what=f"attn B{B} q{qps} splits{splits}", **ATTN_TOL)
+
+
+def test_attn_prefill_varlen(H):
+    nh, nkv, hd, bs = 8, 2, 128, 16
+    lens = [5, 128, 33]
+    kc, vc, bt, mb = make_paged(3, lens, nkv, hd, bs, seed=9)
+    torch.manual_seed(1)
+    T = sum(lens)
+    q = torch.randn(T, nh, hd).to(BF)
+    cu = torch.tensor([0, 5, 133, 166], dtype=torch.int32)
+    ctx = torch.tensor(lens, dtype=torch.int32)
+    ref = O.attn_paged(q, kc, vc, ctx, bt, hd ** -0.5, cu_q=cu).reshape(T, nh * hd)
+    got = run_attn(H, q.view(T, -1), kc, vc, bt, mb, ctx, nh, nkv, hd, bs, cu_q=cu, splits=2)
+    assert_close_bf16(got, ref, what="prefill varlen", **ATTN_TOL)
+    # prefix-cache style: fewer queries than keys (bottom-right alignment)
+    cu2 = torch.tensor([0, 2, 66, 70], dtype=torch.int32)
+    q2 = q[:70]
+    ref2 = O.attn_paged(q2, kc, vc, ctx, bt, hd ** -0.5, cu_q=cu2).reshape(70, nh * hd)
+    got2 = run_attn(H, q2.reshape(70, -1), kc, vc, bt, mb, ctx, nh, nkv, hd, bs, cu_q=cu2, splits=1)
+    assert_close_bf16(got2, ref2, what="prefill suffix", **ATTN_TOL)
+
+
+@pytest.mark.parametrize("splits", [1, 3])
+def test_attn_tree(H, splits):
+    nh, nkv, hd, bs = 32, 8, 64, 16
+    K, F = 7, 3
+    MQ = F * (K + 1)
+    for step in (0, 3, 6):
+        prefix = [150, 41]
+        ctx_lens = [p + K + 1 + (step + 1) * MQ for p in prefix]
+        kc, vc, bt, mb = make_paged(2, ctx_lens, nkv, hd, bs, seed=step)
+        torch.manual_seed(step)
+        q = torch.randn(2 * MQ, nh, hd).to(BF)
+        ctx = torch.tensor(ctx_lens, dtype=torch.int32)
+        jidx = [i // F for i in range(MQ)]
+        ref = O.attn_tree(q, kc, vc, ctx, bt, hd ** -0.5, step, K, [jidx, jidx]).reshape(2 * MQ, nh * hd)
+        got = run_attn(H, q.view(2 * MQ, -1), kc, vc, bt, mb, ctx, nh, nkv, hd, bs, q_per_seq=MQ, splits=splits,
+                       mode=H.MODE_TREE, tree_K=K, tree_mq=MQ, tree_step=step, tree_F=F)
+        assert_close_bf16(got, ref, what=f"tree step {step}", **ATTN_TOL)
+    # non-uniform fan-out through the explicit branch->glue-position table
+    fl = [[2, 2, 3, 1], [3, 2, 2, 1]]
+    K2, MQ2 = 3, 8
+    jl = [[j for j, f in enumerate(l) for _ in range(f)] for l in fl]
+    ctx_lens = [30 + K2 + 1 + MQ2, 55 + K2 + 1 + MQ2]
+    kc, vc, bt, mb = make_paged(2, ctx_lens, nkv, hd, bs, seed=77)
+    q = torch.randn(2 * MQ2, nh, hd).to(BF)
+    ctx = torch.tensor(ctx_lens, dtype=torch.int32)
+    ref = O.attn_tree(q, kc, vc, ctx, bt, hd ** -0.5, 0, K2, jl).reshape(2 * MQ2, nh * hd)
+    got = run_attn(H, q.view(2 * MQ2, -1), kc, vc, bt, mb, ctx, nh, nkv, hd, bs, q_per_seq=MQ2, splits=splits, mode=H.MODE_TREE,
+                   tree_K=K2, tree_mq=MQ2, tree_step=0, tree_F=1, tree_jidx=dev(torch.tensor(jl, dtype=torch.int32)))
+    assert_close_bf16(got, ref, what="tree non-uniform", **ATTN_TOL)
+
+
+def test_attn_softmax_spike(H):
+    """A key that dominates one query row late in the scan forces the online-softmax rescale branch."""
+    nh, nkv, hd, bs = 4, 1, 128, 16
+    kc, vc, bt, mb = make_paged(1, [300], nkv, hd, bs, seed=4)
+    q = torch.randn(1, nh, hd).to(BF)
+    blk, off = int(bt[0, 250 // bs]), 250 % bs
+    kc[blk, off, 0] = (q[0, 2].float() * 4).to(BF)
+    ctx = torch.tensor([300], dtype=torch.int32)
+    ref = O.attn_paged(q, kc, vc, ctx, bt, hd ** -0.5).reshape(1, nh * hd)
+    for splits in (1, 4):
+        got = run_attn(H, q.view(1, -1), kc, vc, bt, mb, ctx, nh, nkv, hd, bs, q_per_seq=1, splits=splits)
+        assert_close_bf16(got, ref, what="spike", **ATTN_TOL)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_argmax_ties_and_golden(H, golden):
+    g = golden("ops_golden")
+    lg = g["head_logits"]
+    out = torch.zeros(7, dtype=torch.int64, device="cuda")
+    H.argmax_rows(dev(lg), lg.shape[1], 7, lg.shape[1], out)
+    assert out.cpu().tolist() == g["sample_tokens"].tolist()
+    V = 128256
+    x = torch.randn(3, V).to(BF)
+    x[0, 77] = 9.0
+    x[0, 100000] = 9.0          # tie -> lowest index
+    x[1, V - 1] = 11.0          # last element
+    x[2, 0] = 12.0
+    H.argmax_rows(dev(x), V, 3, V, out)
+    assert out.cpu()[:3].tolist() == [77, V - 1, 0] == O.argmax_rows(x).tolist()
+    y = torch.randn(5, 151936).to(BF)
+    o2 = torch.zeros(5, dtype=torch.int64, device="cuda")
+    H.argmax_rows(dev(y), 151936, 5, 151936, out, o2)
+    assert out.cpu()[:5].tolist() == O.argmax_rows(y).tolist() == o2.cpu().tolist()
+
+
+def test_verify_greedy_golden(H, golden):
+    g = golden("logic_golden")
+    lp, spec = g["v_logits_p"], g["v_spec"]
+    B, Kp1, V = lp.shape
+    preds = torch.zeros(B * Kp1, dtype=torch.int64, device="cuda")
+    H.argmax_rows(dev(lp.view(B * Kp1, V)), V, B * Kp1, V, preds)
+    acc = torch.zeros(B, dtype=torch.int32, device="cuda")
+    rec = torch.zeros(B, dtype=torch.int64, device="cuda")
+    H.verify_greedy(preds, dev(spec), B, Kp1 - 1, acc, rec)
+    assert (acc.cpu() + 1).tolist() == g["v_suffix_len"].tolist()
+    assert rec.cpu().tolist() == g["v_rec"].tolist()
+
+
+def test_fork_golden(H, golden):
+    g = golden("logic_golden")
+    lg = g["f_logits"]                      # [2, 4, 500]
+    B, Kp1, V = lg.shape
+    lists = [g["f_list_hit"].tolist() if h else g["f_list_miss"].tolist() for h in g["f_hits"].tolist()]
+    counts = torch.tensor(lists, dtype=torch.int32)
+    offsets = torch.cumsum(counts, 1).to(torch.int32) - counts
+    mq = int(counts[0].sum())
+    out = torch.zeros(B, mq, dtype=torch.int64, device="cuda")
+    # V=500 is not a multiple of 8: pad the row stride
+    ld = 504
+    padded = torch.full((B * Kp1, ld), float("-inf"), dtype=BF)
+    padded[:, :V] = lg.view(B * Kp1, V)
+    H.fork_topf(dev(padded), ld, V, dev(g["f_returned"]), dev(counts), dev(offsets), B, Kp1 - 1, mq, out)
+    assert torch.equal(out.cpu(), g["f_idx"])
+
+
+def test_draft_advance(H):
+    B, K, bs, mb = 3, 4, 16, 8
+    bt = torch.arange(B * mb, dtype=torch.int32).view(B, mb)
+    nxt = torch.tensor([11, 22, 33], dtype=torch.int64)
+    ids = torch.zeros(B, dtype=torch.int64)
+    pos = torch.tensor([15, 16, 40], dtype=torch.int64)
+    slots = torch.zeros(B, dtype=torch.int32)
+    ctx = (pos + 1).to(torch.int32)
+    spec = torch.zeros(B, K + 1, dtype=torch.int64)
+    step = torch.tensor([1], dtype=torch.int32)
+    d = [dev(t) for t in (nxt, ids, pos, slots, ctx, bt, spec, step)]
+    H.draft_advance(d[0], d[1], d[2], d[3], d[4], d[5], mb, bs, d[6], K, d[7], B)
+    assert d[1].cpu().tolist() == [11, 22, 33]
+    assert d[2].cpu().tolist() == [16, 17, 41]
+    assert d[4].cpu().tolist() == [17, 18, 42]
+    assert d[3].cpu().tolist() == [int(bt[0, 1]) * bs + 0, int(bt[1, 1]) * bs + 1, int(bt[2, 2]) * bs + 9]
+    assert d[6].cpu()[:, 2].tolist() == [11, 22, 33]
+    assert d[7].cpu().item() == 2
