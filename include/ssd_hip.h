@@ -83,7 +83,8 @@ int ssd_rope_store_kv(const void* qkv_rows, const int64_t* positions, const floa
  *           gives each branch's glue position (NULL -> branch / tree_F).
  * splits = key-range splits per (sequence, kv head) (static per launch; ranges derive from context_lens on
  * device).  ws_o fp32[T*nh*splits*hd], ws_ml fp32[T*nh*splits*2] needed when splits > 1.
- * flags bit0: use scalar LDS gathers instead of ds_read_b64_tr_b16 (diagnostic). */
+ * flags bit0: use scalar LDS gathers instead of ds_read_b64_tr_b16 (diagnostic).
+ * flags bit1: single-bf16 probabilities in P.V (FlashAttention's rounding) instead of the default hi+lo split. */
 int ssd_attn_paged(const void* q_rows, const void* k_cache, const void* v_cache, const int32_t* block_tables,
                    int max_blocks, const int32_t* context_lens, const int32_t* cu_q, int q_per_seq, int B, int T,
                    int max_q, int nh, int nkv, int hd, int block_size, float scale, int mode, int tree_K,
@@ -92,10 +93,19 @@ int ssd_attn_paged(const void* q_rows, const void* k_cache, const void* v_cache,
 
 /* Sampler.forward at temperature 0 -- ssd/layers/sampler.py:15-20; verify.py:34.  out2 optional copy. */
 int ssd_argmax_rows(const void* logits_rows, long ld, int T, int V, int64_t* out, int64_t* out2, void* stream);
+/* Vocab-parallel form of the same argmax (ParallelLMHead gather + cat, ssd/layers/embed_head.py:88-92, followed by
+ * argmax): each rank reduces its shard to (max value, global index = local + idx_offset); the [tp][stride] pairs are
+ * all-gathered (16 bytes per row instead of the logits) and merged: larger value, then lower index. */
+int ssd_argmax_rows_val(const void* logits_rows, long ld, int T, int V, long idx_offset, int64_t* out_idx,
+                        float* out_val, void* stream);
+int ssd_argmax_merge(const float* vals, const int64_t* idxs, int tp, int T, long stride, int64_t* out, int64_t* out2,
+                     void* stream);
 
-/* verify(), greedy branch -- ssd/utils/verify.py:28-48.  preds/speculations int64 [B][K+1]. */
+/* verify(), greedy branch -- ssd/utils/verify.py:28-48.  preds/speculations int64 [B][K+1].
+ * packed (optional) int64 [B][K+3] = (accept_len, recovery, spec_0..spec_K): the step's whole result in one D2H
+ * copy instead of the reference's four .tolist() syncs (verify.py:173-181). */
 int ssd_verify_greedy(const int64_t* preds, const int64_t* speculations, int B, int K, int32_t* accept_len,
-                      int64_t* recovery, void* stream);
+                      int64_t* recovery, int64_t* packed, void* stream);
 
 /* get_forked_recovery_tokens_from_logits -- ssd/utils/async_helpers/async_spec_helpers.py:26-78.
  * counts/offsets int32 [B][K+1]: fan-out and output offset of each glue position. */

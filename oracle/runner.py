@@ -1,0 +1,146 @@
+"""CPU stand-in for ssd_amd.engine.model_runner.ModelRunner built on the oracle model (TEST INFRASTRUCTURE ONLY).
+
+Same public surface (run / speculate_chain / verify_chain / num_kvcache_blocks) so the REAL engine code --
+scheduler, block managers, SpecDecodeStep, speculators, verifier -- can be exercised on CPU in the ``not gpu``
+tests, under ``gloo`` for the multi-rank paths, and timed as the CPU baseline in bench.py.  Input preparation
+restates ssd/engine/helpers/runner_helpers.py:50-180; sampling is Sampler at temperature 0 and verification is
+the greedy branch of ssd/utils/verify.py.  It is injected explicitly (``LLMEngine(..., runner_factory=...)``);
+the product never selects it.
+"""
+from __future__ import annotations
+
+import torch
+
+from oracle import ops as O
+from oracle.model import OracleModel, Ctx, shard_weights
+from ssd_amd import weights as W
+
+
+class OracleRunner:
+    def __init__(self, config, model_cfg, *, is_draft: bool, topo=None, weights: dict | None = None,
+                 num_kvcache_blocks: int = -1, **_):
+        self.config, self.cfg, self.is_draft = config, model_cfg, is_draft
+        self.block_size = config.kvcache_block_size
+        self.K = config.speculate_k if config.speculate else 0
+        tp_rank = topo.tp_rank if topo is not None else 0
+        tp_size = topo.tp_size if topo is not None else 1
+        tp_group = topo.tp_group if topo is not None else None
+        if weights is None:
+            seed = config.draft_weights_seed if is_draft else config.weights_seed
+            weights = W.synthetic_state_dict(model_cfg, seed, config.weights_std)
+        self.num_kvcache_blocks = num_kvcache_blocks if num_kvcache_blocks > 0 else 64
+        self.model = OracleModel(model_cfg, shard_weights(model_cfg, weights, tp_rank, tp_size), self.num_kvcache_blocks,
+                                 self.block_size, tp_rank, tp_size, tp_group)
+        self.tp_rank, self.tp_size, self.tp_group = tp_rank, tp_size, tp_group
+
+    # ---- helpers ----
+    def _table(self, s):
+        return s.draft_block_table if self.is_draft else s.block_table
+
+    def _slot(self, table, p):
+        return table[p // self.block_size] * self.block_size + p % self.block_size
+
+    def _bt(self, seqs):
+        n = max(len(self._table(s)) for s in seqs)
+        return torch.tensor([self._table(s) + [-1] * (n - len(self._table(s))) for s in seqs], dtype=torch.int32)
+
+    def _logits(self, hidden):
+        """Full-vocab logits on every rank (the engine is SPMD)."""
+        lg = O.linear(hidden, self.model.w["model.embed_tokens.weight" if self.cfg.tie_word_embeddings else "lm_head.weight"])
+        if self.tp_size > 1:
+            import torch.distributed as dist
+            parts = [torch.empty_like(lg) for _ in range(self.tp_size)]
+            dist.all_gather(parts, lg.contiguous(), group=self.tp_group)
+            lg = torch.cat(parts, dim=-1)
+        return lg
+
+    def call(self, method, *args):
+        return getattr(self, method)(*args)
+
+    @torch.inference_mode()
+    def run(self, seqs, is_prefill: bool, last_only: bool = True, draft_return_logits: bool = False):
+        if is_prefill:
+            ids, pos, slots, cu_q, cu_k = [], [], [], [0], [0]
+            for s in seqs:
+                cached = s.num_draft_cached_tokens if self.is_draft else s.num_cached_tokens
+                n = len(s)
+                ids.extend(s[cached:])
+                pos.extend(range(cached, n))
+                slots.extend(self._slot(self._table(s), p) for p in range(cached, n))
+                cu_q.append(cu_q[-1] + n - cached)
+                cu_k.append(cu_k[-1] + n)
+            cu_q_t, cu_k_t = torch.tensor(cu_q, dtype=torch.int32), torch.tensor(cu_k, dtype=torch.int32)
+            paged = cu_k[-1] > cu_q[-1]
+            ctx = Ctx("prefill", slot_mapping=torch.tensor(slots, dtype=torch.int32), cu_q=cu_q_t, cu_k=cu_k_t,
+                      block_tables=self._bt(seqs) if paged else None)
+            h = self.model.forward(torch.tensor(ids), torch.tensor(pos), ctx)
+            lg = self._logits(h[(cu_q_t[1:] - 1).long()])
+            toks = O.argmax_rows(lg).tolist()
+            return (toks, lg) if draft_return_logits else toks
+        if not last_only:
+            lg = self._verify_logits(seqs, None)
+            return lg
+        ids, pos, slots, ctx_lens = [], [], [], []
+        for s in seqs:
+            ids.append(s.last_token)
+            pos.append(len(s) - 1)
+            slots.append(self._slot(self._table(s), len(s) - 1))
+            ctx_lens.append(len(s))
+        lg = self._decode(ids, pos, slots, ctx_lens, self._bt(seqs))
+        toks = O.argmax_rows(lg).tolist()
+        return (toks, lg) if draft_return_logits else toks
+
+    def _decode(self, ids, pos, slots, ctx_lens, bt):
+        ctx = Ctx("decode", slot_mapping=torch.tensor(slots, dtype=torch.int32),
+                  context_lens=torch.tensor(ctx_lens, dtype=torch.int32), block_tables=bt)
+        return self._logits(self.model.forward(torch.tensor(ids), torch.tensor(pos), ctx))
+
+    def _verify_logits(self, seqs, speculations):
+        K = self.K
+        ids, pos, slots, ctx_lens = [], [], [], []
+        for b, s in enumerate(seqs):
+            pos0 = s.num_tokens - (K + 1)
+            ids.extend(s[pos0:] if speculations is None else speculations[b].tolist())
+            pos.extend(range(pos0, pos0 + K + 1))
+            slots.extend(self._slot(self._table(s), p) for p in range(pos0, pos0 + K + 1))
+            ctx_lens.append(len(s))
+        B = len(seqs)
+        ctx = Ctx("verify", slot_mapping=torch.tensor(slots, dtype=torch.int32),
+                  context_lens=torch.tensor(ctx_lens, dtype=torch.int32), block_tables=self._bt(seqs),
+                  cu_q=torch.arange(B + 1, dtype=torch.int32) * (K + 1))
+        return self._logits(self.model.forward(torch.tensor(ids), torch.tensor(pos), ctx))
+
+    @torch.inference_mode()
+    def speculate_chain(self, seqs, recovery_tokens):
+        """K+1 sequential draft decodes from the recovery token (speculator_sync.py:47-66)."""
+        B, K = len(seqs), self.K
+        spec = torch.zeros(B, K + 1, dtype=torch.int64)
+        spec[:, 0] = torch.tensor(recovery_tokens)
+        cur = list(recovery_tokens)
+        bt = self._bt(seqs)
+        for k in range(K + 1):
+            pos = [len(s) - 1 + k for s in seqs]
+            slots = [self._slot(self._table(s), p) for s, p in zip(seqs, pos)]
+            lg = self._decode(cur, pos, slots, [p + 1 for p in pos], bt)
+            if k == K:
+                break
+            cur = O.argmax_rows(lg).tolist()
+            spec[:, k + 1] = torch.tensor(cur)
+        return spec
+
+    @torch.inference_mode()
+    def verify_chain(self, seqs, speculations):
+        B, K = len(seqs), self.K
+        lg = self._verify_logits(seqs, speculations).view(B, K + 1, -1)
+        return O.verify_suffixes(lg, speculations)
+
+    def exit(self, *a):
+        pass
+
+
+def oracle_runner_factory(weights_target: dict | None = None, weights_draft: dict | None = None):
+    def factory(config, model_cfg, *, is_draft: bool, topo, **kw):
+        return OracleRunner(config, model_cfg, is_draft=is_draft, topo=topo,
+                            weights=weights_draft if is_draft else weights_target,
+                            num_kvcache_blocks=kw.get("num_kvcache_blocks", -1))
+    return factory

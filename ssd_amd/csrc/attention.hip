@@ -32,7 +32,7 @@ struct AttnParams {
   int max_blocks, q_per_seq, nh, nkv, bs;
   int mode;                  // 0 = causal (bottom-right aligned), 1 = tree
   int tree_K, tree_mq, tree_step, tree_F;
-  int splits, use_tr;
+  int splits, use_tr, p_split;
   float scale_log2e;
 };
 
@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(64) attn_kernel(const AttnParams p) {
       }
     }
     // -- mask + online softmax; P^T stays in the accumulator layout --
-    u32x4_t pf[RT];
+    u32x4_t pf[RT], pl[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       float s[8];
@@ -170,6 +170,12 @@ __global__ void __launch_bounds__(64) attn_kernel(const AttnParams p) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) o[rt][dt] *= alpha;
       pf[rt] = u32x4_t{pack_bf2(pv[0], pv[1]), pack_bf2(pv[2], pv[3]), pack_bf2(pv[4], pv[5]), pack_bf2(pv[6], pv[7])};
+      // P = P_hi + P_lo (two bf16 terms, ~2^-17 relative): P.V then tracks an fp32-softmax reference instead of
+      // carrying FlashAttention's 2^-9 probability rounding; costs one extra MFMA per output tile.
+      float pr[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) pr[i] = pv[i] - round_bf(pv[i]);
+      pl[rt] = u32x4_t{pack_bf2(pr[0], pr[1]), pack_bf2(pr[2], pr[3]), pack_bf2(pr[4], pr[5]), pack_bf2(pr[6], pr[7])};
     }
     __syncthreads();
     // -- O^T += V^T . P^T ; V^T fragments by transpose-read from the staged tile --
@@ -195,7 +201,10 @@ __global__ void __launch_bounds__(64) attn_kernel(const AttnParams p) {
         vf = u32x4_t{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
       }
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) o[rt][dt] = mfma16(vf, pf[rt], o[rt][dt]);
+      for (int rt = 0; rt < RT; ++rt) {
+        o[rt][dt] = mfma16(vf, pf[rt], o[rt][dt]);
+        if (p.p_split) o[rt][dt] = mfma16(vf, pl[rt], o[rt][dt]);
+      }
     }
     __syncthreads();
   }
@@ -293,7 +302,7 @@ extern "C" int ssd_attn_paged(const void* q_rows, const void* k_cache, const voi
   p.ws_o = (float*)ws_o; p.ws_ml = (float*)ws_ml; p.out_rows = (bf16_t*)out_rows; p.out_frag = (u32x2_t*)out_frag;
   p.max_blocks = max_blocks; p.q_per_seq = q_per_seq; p.nh = nh; p.nkv = nkv; p.bs = block_size;
   p.mode = mode; p.tree_K = tree_K; p.tree_mq = tree_mq; p.tree_step = tree_step; p.tree_F = tree_F;
-  p.splits = splits; p.use_tr = (flags & 1) ? 0 : 1;
+  p.splits = splits; p.use_tr = (flags & 1) ? 0 : 1; p.p_split = (flags & 2) ? 0 : 1;
   p.scale_log2e = scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;
   return hd == 128 ? attn_launch<128>(p, B, T, max_q, st) : attn_launch<64>(p, B, T, max_q, st);

@@ -56,19 +56,54 @@ __device__ ArgBest block_row_argmax(const bf16_t* __restrict__ row, int V, const
 constexpr int ARG_THREADS = 1024;
 
 __global__ void __launch_bounds__(ARG_THREADS)
-argmax_rows_kernel(const bf16_t* __restrict__ logits, long ld, int V, int64_t* __restrict__ out, int64_t* __restrict__ out2) {
+argmax_rows_kernel(const bf16_t* __restrict__ logits, long ld, int V, int64_t* __restrict__ out, int64_t* __restrict__ out2,
+                   float* __restrict__ out_val, long idx_offset) {
   __shared__ ArgBest sm[ARG_THREADS / 64];
   const ArgBest r = block_row_argmax<ARG_THREADS>(logits + (size_t)blockIdx.x * ld, V, nullptr, 0, sm);
   if (threadIdx.x == 0) {
-    out[blockIdx.x] = r.i;
-    if (out2) out2[blockIdx.x] = r.i;
+    out[blockIdx.x] = r.i + idx_offset;
+    if (out2) out2[blockIdx.x] = r.i + idx_offset;
+    if (out_val) out_val[blockIdx.x] = r.v;
   }
+}
+
+// Vocab-parallel argmax merge: vals/idxs [tp][stride >= T] (per-rank local maxima with GLOBAL indices) -> out[T].
+// Equivalent to argmax over the concatenated logits (ParallelLMHead gather + cat, reference
+// ssd/layers/embed_head.py:88-92): larger value wins, lowest global index on ties.
+__global__ void argmax_merge_kernel(const float* __restrict__ vals, const int64_t* __restrict__ idxs, int tp, int T,
+                                    long stride, int64_t* __restrict__ out, int64_t* __restrict__ out2) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  float bv = vals[t];
+  int64_t bi = idxs[t];
+  for (int r = 1; r < tp; ++r) {
+    const float v = vals[(size_t)r * stride + t];
+    const int64_t i = idxs[(size_t)r * stride + t];
+    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+  }
+  out[t] = bi;
+  if (out2) out2[t] = bi;
+}
+
+extern "C" int ssd_argmax_merge(const float* vals, const int64_t* idxs, int tp, int T, long stride, int64_t* out,
+                                int64_t* out2, void* stream) {
+  if (tp <= 0 || T <= 0 || stride < T) return SSD_ERR_SHAPE;
+  hipLaunchKernelGGL(argmax_merge_kernel, dim3((T + 63) / 64), dim3(64), 0, (hipStream_t)stream, vals, idxs, tp, T, stride, out, out2);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
 extern "C" int ssd_argmax_rows(const void* logits, long ld, int T, int V, int64_t* out, int64_t* out2, void* stream) {
   if (T <= 0 || V <= 0 || (ld & 7)) return SSD_ERR_SHAPE;
   hipLaunchKernelGGL(argmax_rows_kernel, dim3(T), dim3(ARG_THREADS), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, V,
-                     out, out2);
+                     out, out2, (float*)nullptr, 0L);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
+extern "C" int ssd_argmax_rows_val(const void* logits, long ld, int T, int V, long idx_offset, int64_t* out_idx,
+                                   float* out_val, void* stream) {
+  if (T <= 0 || V <= 0 || (ld & 7)) return SSD_ERR_SHAPE;
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(T), dim3(ARG_THREADS), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, V,
+                     out_idx, (int64_t*)nullptr, out_val, idx_offset);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
@@ -76,7 +111,8 @@ extern "C" int ssd_argmax_rows(const void* logits, long ld, int T, int V, int64_
 // accept_len[b] = number of accepted draft tokens n (0..K); recovery[b] = preds[b][n];
 // out_suffix[b] (optional, [K+2] per seq) = [n+1, recovery_prev, x_1..x_n ...] packed for one D2H copy.
 __global__ void verify_greedy_kernel(const int64_t* __restrict__ preds, const int64_t* __restrict__ spec, int K,
-                                     int32_t* __restrict__ accept_len, int64_t* __restrict__ recovery) {
+                                     int32_t* __restrict__ accept_len, int64_t* __restrict__ recovery,
+                                     int64_t* __restrict__ packed) {
   const int b = blockIdx.x, lane = threadIdx.x;
   bool mismatch = false;
   if (lane < K) mismatch = spec[(size_t)b * (K + 1) + lane + 1] != preds[(size_t)b * (K + 1) + lane];
@@ -86,13 +122,18 @@ __global__ void verify_greedy_kernel(const int64_t* __restrict__ preds, const in
     accept_len[b] = n;
     recovery[b] = preds[(size_t)b * (K + 1) + n];
   }
+  if (packed) {  // one row per sequence for a single D2H copy: [n, recovery, spec_0 .. spec_K]
+    int64_t* row = packed + (size_t)b * (K + 3);
+    if (lane == 0) { row[0] = n; row[1] = preds[(size_t)b * (K + 1) + n]; }
+    if (lane <= K) row[2 + lane] = spec[(size_t)b * (K + 1) + lane];
+  }
 }
 
 extern "C" int ssd_verify_greedy(const int64_t* preds, const int64_t* speculations, int B, int K, int32_t* accept_len,
-                                 int64_t* recovery, void* stream) {
-  if (B <= 0 || K < 0 || K > 63) return SSD_ERR_SHAPE;
+                                 int64_t* recovery, int64_t* packed, void* stream) {
+  if (B <= 0 || K < 0 || K > 62) return SSD_ERR_SHAPE;
   hipLaunchKernelGGL(verify_greedy_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, preds, speculations, K, accept_len,
-                     recovery);
+                     recovery, packed);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 

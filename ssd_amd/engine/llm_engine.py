@@ -1,0 +1,198 @@
+"""LLMEngine: request loop, metrics, step wiring (reference ssd/engine/llm_engine.py:39-381).
+
+Public behaviour kept: ``LLM(model, **Config fields)``; ``generate(prompts, sampling_params, use_tqdm=True,
+stream_callback=None) -> (outputs, METRICS)`` with ``outputs[i] = {"text", "token_ids"}``; the METRICS keys.
+
+Process model (differs by design): one process per GPU, SPMD.  Under ``torchrun`` every rank constructs the same
+engine and calls ``generate`` with the same requests; tensor-parallel ranks stay in lock step through the RCCL
+collectives inside the forward and never exchange control messages (the reference pickles every call into a
+shared-memory RPC, model_runner.py:404-428).
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import fields
+from time import perf_counter
+
+import torch
+
+from ssd_amd.config import Config
+from ssd_amd.sampling_params import SamplingParams
+from ssd_amd.engine.sequence import Sequence
+from ssd_amd.engine.scheduler import Scheduler
+from ssd_amd.engine.step import AutoRegressiveStep, SpecDecodeStep, InferenceStep
+from ssd_amd.engine.speculator_sync import SpeculatorSync
+from ssd_amd.engine.verifier import Verifier
+
+
+def _fresh_metrics() -> dict:
+    return {
+        "cache_hits": [],
+        "accepted_suffix_lens_with_recovery": [],
+        "accepted_suffix_lens_on_hit": [],
+        "accepted_suffix_lens_on_miss": [],
+        "prefill_total_time": 0,
+        "decode_total_time": 0,
+        "prefill_total_tokens": 0,
+        "decode_total_tokens": 0,
+        "target_step_times": [],
+        "target_verify_times": [],
+    }
+
+
+METRICS = _fresh_metrics()
+
+
+def _load_tokenizer(path: str):
+    if not os.path.isdir(path):
+        return None
+    if not any(os.path.exists(os.path.join(path, f)) for f in ("tokenizer.json", "tokenizer_config.json", "tokenizer.model")):
+        return None
+    from transformers import AutoTokenizer
+    return AutoTokenizer.from_pretrained(path, use_fast=True)
+
+
+def hip_runner_factory(config, model_cfg, *, is_draft: bool, topo, **kw):
+    from ssd_amd.engine.model_runner import ModelRunner
+    path = config.draft if is_draft else config.model
+    return ModelRunner(config, model_cfg, is_draft=is_draft, device=topo.device, tp_rank=topo.tp_rank,
+                       tp_size=topo.tp_size, tp_group=topo.tp_group, model_path=path if os.path.isdir(path or "") else None,
+                       weights_seed=config.draft_weights_seed if is_draft else config.weights_seed, **kw)
+
+
+class LLMEngine:
+    def __init__(self, model: str, runner_factory=None, topology=None, **kwargs):
+        names = {f.name for f in fields(Config)}
+        config = Config(model, **{k: v for k, v in kwargs.items() if k in names})
+        self.config = config
+        Sequence.block_size = config.kvcache_block_size
+        assert config.num_gpus > 1 or not config.draft_async, "draft_async requires at least 2 gpus"
+
+        from ssd_amd.utils.topology import resolve_topology
+        self.topo = topology or resolve_topology(config)
+        factory = runner_factory or hip_runner_factory
+
+        self.draft_runner = None
+        self.async_link = None
+        if self.topo.role == "draft":               # dedicated draft GPU of async speculation
+            from ssd_amd.engine.draft_runner import DraftServer
+            self.draft_server = DraftServer(config, self.topo, factory)
+            return
+        self.model_runner = factory(config, config.hf_config, is_draft=False, topo=self.topo,
+                                    num_kvcache_blocks=config.num_kvcache_blocks)
+        config.num_kvcache_blocks = self.model_runner.num_kvcache_blocks
+        draft_blocks = None
+        if config.speculate and not config.draft_async:
+            self.draft_runner = factory(config, config.draft_hf_config, is_draft=True, topo=self.topo.single(),
+                                        memory_utilization=0.75, num_kvcache_blocks=config.num_draft_kvcache_blocks)
+            draft_blocks = self.draft_runner.num_kvcache_blocks
+        elif config.speculate:
+            from ssd_amd.engine.speculator_async import AsyncLink
+            self.async_link = AsyncLink(config, self.topo)
+            draft_blocks = self.async_link.draft_num_blocks()
+
+        self.tokenizer = _load_tokenizer(config.tokenizer_path or config.model)
+        if self.tokenizer is not None and self.tokenizer.eos_token_id is not None:
+            config.eos = self.tokenizer.eos_token_id
+        self.scheduler = Scheduler(config, draft_num_blocks=draft_blocks)
+
+    # ---------------------------------------------------------------------------------------------
+    def add_request(self, prompt, sampling_params: SamplingParams) -> None:
+        if isinstance(prompt, str):
+            if self.tokenizer is None:
+                raise ValueError("string prompts need a tokenizer in the model directory; pass token-id lists")
+            prompt = self.tokenizer.encode(prompt)
+        self.scheduler.add(Sequence(prompt, sampling_params))
+
+    def step(self, step: InferenceStep):
+        t = perf_counter()
+        seqs, is_prefill = self.scheduler.schedule()
+        n = step.prefill(seqs) if is_prefill else step.decode(seqs)
+        dt = perf_counter() - t
+        if is_prefill:
+            METRICS["prefill_total_time"] += dt
+            METRICS["prefill_total_tokens"] += n
+        else:
+            METRICS["decode_total_time"] += dt
+            METRICS["decode_total_tokens"] += n
+        return [(s.seq_id, s.completion_token_ids) for s in seqs if s.is_finished]
+
+    def is_finished(self) -> bool:
+        return self.scheduler.is_finished()
+
+    def create_inference_step(self, config: Config) -> InferenceStep:
+        if not config.speculate:
+            return AutoRegressiveStep(self.scheduler, self.model_runner, self.tokenizer)
+        if config.draft_async:
+            from ssd_amd.engine.speculator_async import SpeculatorAsync
+            speculator = SpeculatorAsync(config.speculate_k, self.topo.device, self.async_link, config)
+        else:
+            speculator = SpeculatorSync(config.speculate_k, self.topo.device, self.draft_runner)
+        verifier = Verifier(config.speculate_k, self.topo.device, self.model_runner, sampler_x=config.sampler_x,
+                            async_fan_out=config.async_fan_out, jit_speculate=config.jit_speculate,
+                            tokenizer=self.tokenizer, metrics=METRICS)
+        return SpecDecodeStep(self.scheduler, speculator, verifier, eagle=False, tokenizer=self.tokenizer,
+                              async_spec=config.draft_async)
+
+    def log_metrics(self) -> None:
+        if METRICS["prefill_total_time"]:
+            print(f"Final Prefill Throughput: {int(METRICS['prefill_total_tokens'] / METRICS['prefill_total_time'])}tok/s", flush=True)
+        if METRICS["decode_total_time"]:
+            print(f"Final Decode Throughput: {int(METRICS['decode_total_tokens'] / METRICS['decode_total_time'])}tok/s", flush=True)
+        lens = METRICS["accepted_suffix_lens_with_recovery"]
+        if self.config.speculate and lens:
+            print(f"[metrics] Avg Tokens per step (incl recovery): {sum(lens) / len(lens):.2f}", flush=True)
+            print(f"[metrics] Avg Fraction of Speculated Tokens Accepted: "
+                  f"{((sum(lens) - len(lens)) / len(lens)) / self.config.speculate_k:.2f}", flush=True)
+            if METRICS["cache_hits"]:
+                print(f"[metrics] Avg Cache Hits: {sum(METRICS['cache_hits']) / len(METRICS['cache_hits']):.2f}", flush=True)
+
+    def generate(self, prompts, sampling_params, use_tqdm: bool = True, stream_callback=None):
+        for k, v in _fresh_metrics().items():
+            METRICS[k] = v
+        if not isinstance(sampling_params, list):
+            sampling_params = [sampling_params] * len(prompts)
+        for prompt, sp in zip(prompts, sampling_params):
+            self.add_request(prompt, sp)
+        pbar = None
+        if use_tqdm:
+            from tqdm.auto import tqdm
+            pbar = tqdm(total=len(prompts), desc="Generating", dynamic_ncols=True)
+        outputs: dict[int, list[int]] = {}
+        step = self.create_inference_step(self.config)
+        max_steps = self.config.max_steps if self.config.max_steps is not None else float("inf")
+        streamed: dict[int, int] = {}
+        i = 0
+        while not self.is_finished() and i < max_steps:
+            i += 1
+            t = perf_counter()
+            finished = self.step(step)
+            METRICS["target_step_times"].append(perf_counter() - t)
+            if stream_callback:
+                for seq in self.scheduler.running:
+                    cur, prev = seq.num_completion_tokens, streamed.get(seq.seq_id, 0)
+                    if cur > prev:
+                        stream_callback(seq.seq_id, seq.completion_token_ids[prev:cur])
+                        streamed[seq.seq_id] = cur
+            for seq_id, token_ids in finished:
+                if stream_callback:
+                    prev = streamed.get(seq_id, 0)
+                    if len(token_ids) > prev:
+                        stream_callback(seq_id, token_ids[prev:])
+                outputs[seq_id] = token_ids
+                if pbar:
+                    pbar.update(1)
+        if pbar:
+            pbar.close()
+        result = []
+        for seq_id in sorted(outputs):
+            toks = outputs[seq_id]
+            text = self.tokenizer.decode(toks) if self.tokenizer is not None else ""
+            result.append({"text": text, "token_ids": toks})
+        if not stream_callback and self.config.verbose:
+            self.log_metrics()
+        return result, METRICS
+
+    def exit(self, hard: bool = False) -> None:
+        if self.async_link is not None:
+            self.async_link.shutdown()

@@ -1,0 +1,331 @@
+"""One model on one MI355X: weights, paged KV cache, static input buffers, hipGraph capture / replay.
+
+Counterpart of the reference ModelRunner (ssd/engine/model_runner.py:37-680) and of the tensor preparation in
+ssd/engine/helpers/runner_helpers.py:50-180 and the graph helpers in ssd/engine/helpers/cudagraph_helpers.py.
+Re-designed for this hardware rather than translated:
+  * SPMD tensor parallelism: every rank runs the same Python step on identical small metadata, so there is no
+    shared-memory RPC (reference model_runner.py:404-428); ranks only meet in RCCL collectives.
+  * the K+1 single-token draft forwards of synchronous speculation are chained ON THE DEVICE (argmax ->
+    ssd_draft_advance -> next replay), and verification ends in ssd_verify_greedy writing one packed row per
+    sequence: one host sync per speculation step instead of K+5.
+  * decode / verify / tree forwards are captured once per batch size as hipGraphs over static buffers
+    (torch.cuda.CUDAGraph == hipGraph); prefill is eager, like the reference (model_runner.py:602).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from ssd_amd.hip import ops as H
+from ssd_amd.hip.lib import load_library
+from ssd_amd.model import HipDecoder, AttnMeta
+from ssd_amd.model_config import ModelConfig
+from ssd_amd import weights as W
+
+
+class ModelRunner:
+    def __init__(self, config, model_cfg: ModelConfig, *, is_draft: bool, device: torch.device, tp_rank: int = 0,
+                 tp_size: int = 1, tp_group=None, model_path: str | None = None, weights_seed: int = 0,
+                 gen_device: str | None = None, num_kvcache_blocks: int = -1, memory_utilization: float | None = None,
+                 max_decode_tokens: int | None = None, weight_source=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("ssd_amd.ModelRunner needs an MI355X; there is no CPU fallback on the product path")
+        load_library()  # fail loudly before allocating anything
+        self.config, self.cfg = config, model_cfg
+        self.is_draft, self.device = is_draft, device
+        self.tp_rank, self.tp_size, self.tp_group = tp_rank, tp_size, tp_group
+        self.block_size = config.kvcache_block_size
+        self.max_blocks = config.max_blocks
+        self.K = config.speculate_k if config.speculate else 0
+        self.max_bs = config.max_num_seqs
+        torch.cuda.set_device(device)
+
+        mq = config.MQ_LEN if (config.speculate and config.draft_async) else 0
+        dec_tokens = self.max_bs * max(1, self.K + 1, mq)
+        self.max_decode_tokens = max_decode_tokens or dec_tokens
+        max_tokens = max(config.max_num_batched_tokens, self.max_decode_tokens)
+        self.model = HipDecoder(model_cfg, max_tokens=max_tokens, max_seqs=self.max_bs, max_blocks=self.max_blocks,
+                                block_size=self.block_size, max_model_len=config.max_model_len, device=device,
+                                tp_rank=tp_rank, tp_size=tp_size, tp_group=tp_group,
+                                max_logit_rows=max(self.max_decode_tokens, self.max_bs),
+                                max_split_tokens=max(256, self.max_decode_tokens))
+        if weight_source is not None:
+            src = weight_source
+        elif model_path is not None and W.has_safetensors(model_path):
+            src = W.load_safetensors(model_cfg, model_path, tp_rank, tp_size, out_device=str(device))
+        else:
+            gd = gen_device or ("cuda" if model_cfg.hidden_size >= 1024 else "cpu")
+            src = W.synthetic_weights(model_cfg, weights_seed, config.weights_std, tp_rank, tp_size, gen_device=gd,
+                                      out_device=str(device))
+        self.model.load_weights(src)
+
+        # ---- KV cache: free * utilisation // block_bytes (reference model_runner.py:446-492) ----
+        if num_kvcache_blocks <= 0:
+            free, _ = torch.cuda.mem_get_info(device)
+            util = memory_utilization if memory_utilization is not None else config.gpu_memory_utilization
+            num_kvcache_blocks = int(free * util) // self.model.kv_block_bytes()
+            if tp_size > 1:   # all ranks must agree (SPMD schedulers)
+                t = torch.tensor([num_kvcache_blocks], dtype=torch.int64, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=tp_group)
+                num_kvcache_blocks = int(t.item())
+        assert num_kvcache_blocks > 0, "KV cache does not fit"
+        self.num_kvcache_blocks = num_kvcache_blocks
+        self.model.alloc_kv(num_kvcache_blocks)
+
+        # ---- static inputs (device) + pinned host staging ----
+        T, B = max_tokens, self.max_bs
+        dev = dict(device=device)
+        self.d_ids = torch.zeros(T, dtype=torch.int64, **dev)
+        self.d_pos = torch.zeros(T, dtype=torch.int64, **dev)
+        self.d_slots = torch.zeros(T, dtype=torch.int32, **dev)
+        self.d_ctx = torch.zeros(B, dtype=torch.int32, **dev)
+        self.d_cu_q = torch.zeros(B + 1, dtype=torch.int32, **dev)
+        self.d_gather = torch.zeros(B, dtype=torch.int32, **dev)
+        self.d_bt = torch.zeros(B, self.max_blocks, dtype=torch.int32, **dev)
+        self.d_next = torch.zeros(max(self.max_decode_tokens, B), dtype=torch.int64, **dev)
+        self.d_spec = torch.zeros(B, self.K + 1, dtype=torch.int64, **dev)
+        self.d_step = torch.zeros(1, dtype=torch.int32, **dev)
+        self.d_accept = torch.zeros(B, dtype=torch.int32, **dev)
+        self.d_recovery = torch.zeros(B, dtype=torch.int64, **dev)
+        self.d_packed = torch.zeros(B, self.K + 3, dtype=torch.int64, **dev)
+        self.h_packed = torch.zeros(B, self.K + 3, dtype=torch.int64).pin_memory()
+        self.h_next = torch.zeros(max(self.max_decode_tokens, B), dtype=torch.int64).pin_memory()
+        self._stage: dict = {}
+        self.graphs: dict = {}
+        self.graph_pool = None
+        self.stream = torch.cuda.Stream(device)
+
+    # ---------------------------------------------------------------------------------------------
+    # host -> device input staging
+    # ---------------------------------------------------------------------------------------------
+    def _table(self, seq):
+        return seq.draft_block_table if self.is_draft else seq.block_table
+
+    def _slot(self, table, pos: int) -> int:
+        return table[pos // self.block_size] * self.block_size + pos % self.block_size
+
+    def _upload(self, dst: torch.Tensor, values, dtype) -> None:
+        """Host list -> persistent pinned staging -> async H2D.  Every step ends in a stream sync before the
+        next one stages, so a staging buffer is never rewritten while its copy is in flight."""
+        n = len(values)
+        if n:
+            stage = self._stage.get(id(dst))
+            if stage is None:
+                stage = self._stage[id(dst)] = torch.zeros(dst.shape, dtype=dst.dtype).pin_memory()
+            stage[:n] = torch.tensor(values, dtype=dtype)
+            dst[:n].copy_(stage[:n], non_blocking=True)
+
+    def _upload_block_tables(self, seqs) -> None:
+        rows = []
+        for s in seqs:
+            t = self._table(s)
+            assert len(t) <= self.max_blocks
+            rows.append(t + [-1] * (self.max_blocks - len(t)))
+        self._upload(self.d_bt, rows, torch.int32)
+
+    def _prepare_prefill(self, seqs) -> tuple[int, int]:
+        """prepare_prefill_tensors_from_seqs (runner_helpers.py:123-180): new tokens of each sequence, their
+        positions and slots; context length = whole sequence (keys already cached by a prefix hit included)."""
+        ids, pos, slots, ctx, cu, gather = [], [], [], [], [0], []
+        max_q = 0
+        for s in seqs:
+            cached = s.num_draft_cached_tokens if self.is_draft else s.num_cached_tokens
+            n = len(s)
+            assert cached < n, "fully cached prompt: nothing to prefill"
+            table = self._table(s)
+            ids.extend(s[cached:])
+            pos.extend(range(cached, n))
+            slots.extend(self._slot(table, p) for p in range(cached, n))
+            ctx.append(n)
+            cu.append(cu[-1] + n - cached)
+            gather.append(cu[-1] - 1)
+            max_q = max(max_q, n - cached)
+        T = len(ids)
+        assert T <= self.d_ids.numel(), "prefill exceeds max_num_batched_tokens"
+        self._upload(self.d_ids, ids, torch.int64)
+        self._upload(self.d_pos, pos, torch.int64)
+        self._upload(self.d_slots, slots, torch.int32)
+        self._upload(self.d_ctx, ctx, torch.int32)
+        self._upload(self.d_cu_q, cu, torch.int32)
+        self._upload(self.d_gather, gather, torch.int32)
+        self._upload_block_tables(seqs)
+        return T, max_q
+
+    def _prepare_decode(self, seqs) -> int:
+        """Single-token decode inputs (runner_helpers.py:59-75)."""
+        ids, pos, slots, ctx = [], [], [], []
+        for s in seqs:
+            cached = s.num_draft_cached_tokens if self.is_draft else s.num_cached_tokens
+            assert cached == len(s) - 1, "decode expects exactly one uncached token"
+            ids.append(s.last_token)
+            pos.append(len(s) - 1)
+            ctx.append(len(s))
+            slots.append(self._slot(self._table(s), len(s) - 1))
+        self._upload(self.d_ids, ids, torch.int64)
+        self._upload(self.d_pos, pos, torch.int64)
+        self._upload(self.d_slots, slots, torch.int32)
+        self._upload(self.d_ctx, ctx, torch.int32)
+        self._upload_block_tables(seqs)
+        return len(seqs)
+
+    def _prepare_verify(self, seqs, ids_from_seq: bool) -> int:
+        """K+1 query tokens per sequence at positions pos0 .. pos0+K (runner_helpers.py:77-96)."""
+        K = self.K
+        ids, pos, slots, ctx = [], [], [], []
+        for s in seqs:
+            pos0 = s.num_tokens - (K + 1)
+            cached = s.num_draft_cached_tokens if self.is_draft else s.num_cached_tokens
+            assert cached == pos0, f"num_cached_tokens={cached} != pos0={pos0}"
+            table = self._table(s)
+            if ids_from_seq:
+                ids.extend(s[pos0:])
+            pos.extend(range(pos0, pos0 + K + 1))
+            slots.extend(self._slot(table, p) for p in range(pos0, pos0 + K + 1))
+            ctx.append(len(s))
+        if ids_from_seq:
+            self._upload(self.d_ids, ids, torch.int64)
+        self._upload(self.d_pos, pos, torch.int64)
+        self._upload(self.d_slots, slots, torch.int32)
+        self._upload(self.d_ctx, ctx, torch.int32)
+        self._upload_block_tables(seqs)
+        return len(seqs) * (K + 1)
+
+    # ---------------------------------------------------------------------------------------------
+    # graph bodies (all inputs already in the static buffers)
+    # ---------------------------------------------------------------------------------------------
+    def _meta(self, kind: str, B: int, max_q: int = 1, tree_step: int = 0) -> AttnMeta:
+        if kind == "prefill":
+            return AttnMeta(H.MODE_CAUSAL, B, max_q, self.d_slots, self.d_ctx, self.d_bt, cu_q=self.d_cu_q)
+        if kind == "decode":
+            return AttnMeta(H.MODE_CAUSAL, B, 1, self.d_slots, self.d_ctx, self.d_bt, q_per_seq=1)
+        if kind == "verify":
+            return AttnMeta(H.MODE_CAUSAL, B, self.K + 1, self.d_slots, self.d_ctx, self.d_bt, q_per_seq=self.K + 1)
+        raise ValueError(kind)
+
+    def _body_decode(self, B: int, chain: bool) -> None:
+        self.model.forward(self.d_ids, self.d_pos, B, self._meta("decode", B))
+        self.model.compute_logits(B)
+        self.model.argmax(B, self.d_next)
+        if chain:
+            H.draft_advance(self.d_next, self.d_ids, self.d_pos, self.d_slots, self.d_ctx, self.d_bt, self.max_blocks,
+                            self.block_size, self.d_spec, self.K, self.d_step, B)
+
+    def _body_verify(self, B: int, greedy_tail: bool) -> None:
+        T = B * (self.K + 1)
+        self.model.forward(self.d_ids, self.d_pos, T, self._meta("verify", B))
+        self.model.compute_logits(T)
+        if greedy_tail:
+            self.model.argmax(T, self.d_next)
+            H.verify_greedy(self.d_next, self.d_ids, B, self.K, self.d_accept, self.d_recovery, self.d_packed)
+
+    def _launch(self, key, body) -> None:
+        """Replay the captured hipGraph for `key`, capturing it on first use (after one eager warm-up run, which
+        also performs every lazy initialisation a capture must not contain)."""
+        if self.config.enforce_eager:
+            body()
+            return
+        g = self.graphs.get(key)
+        if g is None:
+            body()                                   # eager warm-up on the current stream
+            torch.cuda.current_stream().synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.graph_pool, stream=self.stream):
+                body()
+            if self.graph_pool is None:
+                self.graph_pool = g.pool()
+            self.graphs[key] = g
+            # the warm-up advanced device-side state (draft chain); callers re-upload inputs before replay
+            return "captured"
+        g.replay()
+        return None
+
+    # ---------------------------------------------------------------------------------------------
+    # public API
+    # ---------------------------------------------------------------------------------------------
+    def call(self, method: str, *args):
+        """Reference-compatible entry (ssd/engine/model_runner.py:422-428); no RPC is needed under SPMD."""
+        return getattr(self, method)(*args)
+
+    @torch.inference_mode()
+    def run(self, seqs, is_prefill: bool, last_only: bool = True, draft_return_logits: bool = False):
+        """ModelRunner.run (model_runner.py:634-680).  Greedy only on this path (temperature 0): returns token
+        ids (last_only) or the flat logits [B*(K+1), V] (verify with last_only=False)."""
+        B = len(seqs)
+        if is_prefill:
+            T, max_q = self._prepare_prefill(seqs)
+            self.model.forward(self.d_ids, self.d_pos, T, self._meta("prefill", B, max_q))
+            self.model.compute_logits(T, gather=self.d_gather, rows=B)
+            self.model.argmax(B, self.d_next)
+            toks = self._read_tokens(B)
+            return (toks, self.model.full_logits(B)) if draft_return_logits else toks
+        if not last_only:
+            T = self._prepare_verify(seqs, ids_from_seq=True)
+            if self._launch(("verify_logits", B), lambda: self._body_verify(B, False)) == "captured":
+                self._prepare_verify(seqs, ids_from_seq=True)
+                self.graphs[("verify_logits", B)].replay()
+            return self.model.full_logits(T)
+        self._prepare_decode(seqs)
+        if self._launch(("decode", B), lambda: self._body_decode(B, False)) == "captured":
+            self._prepare_decode(seqs)
+            self.graphs[("decode", B)].replay()
+        toks = self._read_tokens(B)
+        return (toks, self.model.full_logits(B)) if draft_return_logits else toks
+
+    def _read_tokens(self, n: int) -> list[int]:
+        self.h_next[:n].copy_(self.d_next[:n], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return self.h_next[:n].tolist()
+
+    # ---- fast path of synchronous speculation: no host sync until the verify result ----
+    @torch.inference_mode()
+    def speculate_chain(self, seqs, recovery_tokens: list[int]) -> torch.Tensor:
+        """K+1 chained single-token draft forwards (SpeculatorSync.speculate, speculator_sync.py:47-66) starting
+        from the recovery token at position N = len(seq) - 1 (the caller has appended it).  Returns the device
+        tensor speculations [B, K+1] = (recovery, x_1..x_K); nothing is read back."""
+        B, K = len(seqs), self.K
+        key = ("decode_chain", B)
+
+        def stage():
+            self._prepare_decode(seqs)
+            self.d_step.zero_()
+            self.d_spec[:B, 0].copy_(self.d_ids[:B])
+
+        stage()
+        first = 0
+        if self._launch(key, lambda: self._body_decode(B, True)) == "captured":
+            stage()                      # the warm-up + capture runs disturbed the chained state
+        else:
+            first = 1
+        g = self.graphs.get(key)
+        for _ in range(first, K + 1):
+            if g is not None:
+                g.replay()
+            else:
+                self._body_decode(B, True)
+        return self.d_spec[:B]
+
+    @torch.inference_mode()
+    def verify_chain(self, seqs, speculations: torch.Tensor):
+        """Target forward over the K+1 speculated tokens + greedy accept/reject on the device
+        (Verifier.verify + verify(), verifier.py:54-153, utils/verify.py:5-48).  One packed D2H copy.
+        Returns (new_suffixes, recovery_tokens)."""
+        B, K = len(seqs), self.K
+        key = ("verify", B)
+
+        def stage():
+            self._prepare_verify(seqs, ids_from_seq=False)
+            self.d_ids[:B * (K + 1)].copy_(speculations.reshape(-1))
+
+        stage()
+        if self._launch(key, lambda: self._body_verify(B, True)) == "captured":
+            stage()
+            self.graphs[key].replay()
+        self.h_packed[:B].copy_(self.d_packed[:B], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        rows = self.h_packed[:B].tolist()
+        suffixes = [r[2:3 + r[0]] for r in rows]
+        recovery = [r[1] for r in rows]
+        return suffixes, recovery
+
+    def exit(self, *a):
+        self.graphs.clear()

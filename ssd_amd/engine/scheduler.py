@@ -1,0 +1,186 @@
+"""Admission, lookahead reservation, preemption and post-step bookkeeping (host side of the hot loop).
+
+Behavioural restatement of the reference Scheduler (ssd/engine/scheduler.py:12-327): prefill has priority over
+decode; decode reserves K+1 target positions and K+1 (sync) or K+1+K*MQ_LEN (async) draft positions per
+sequence (scheduler.py:97-126, async_spec_helpers.py:6-7); KV pressure preempts the youngest running sequence
+and re-queues it as a fresh prompt; postprocess_speculate truncates the accepted suffix at EOS /
+max_new_tokens / max_model_len, returns over-reserved blocks, and hashes blocks that became full.
+"""
+from __future__ import annotations
+
+from collections import deque
+
+from ssd_amd.engine.block_manager import BlockManager
+from ssd_amd.engine.sequence import Sequence, SequenceStatus
+
+
+def megaspec_lookahead(mq_len: int, k: int) -> int:
+    """Draft positions beyond the sequence used by one async round: glue (K+1) + K tree steps of MQ_LEN
+    (reference ssd/utils/async_helpers/async_spec_helpers.py:6-7)."""
+    return k + 1 + k * mq_len
+
+
+class Scheduler:
+    def __init__(self, config, draft_num_blocks: int | None = None):
+        self.config = config
+        self.max_num_seqs = config.max_num_seqs
+        self.max_num_batched_tokens = config.max_num_batched_tokens
+        self.max_model_len = config.max_model_len
+        self.eos = config.eos
+        self.speculate = config.speculate
+        self.draft_async = config.draft_async
+        self.K = config.speculate_k
+        self.block_size = config.kvcache_block_size
+        self.MQ_LEN = sum(config.fan_out_list) if (config.speculate and config.draft_async) else 0
+        self.block_manager = BlockManager(config.num_kvcache_blocks, self.block_size, is_draft=False,
+                                          max_model_len=self.max_model_len)
+        self.draft_block_manager = None
+        if self.speculate:
+            assert draft_num_blocks is not None and draft_num_blocks > 0
+            self.draft_block_manager = BlockManager(draft_num_blocks, self.block_size, is_draft=True,
+                                                    speculate_k=self.K, max_model_len=self.max_model_len)
+        self.waiting: deque[Sequence] = deque()
+        self.running: deque[Sequence] = deque()
+
+    def is_finished(self) -> bool:
+        return not self.waiting and not self.running
+
+    def add(self, seq: Sequence) -> None:
+        self.waiting.append(seq)
+
+    # ---- lookahead lengths (reference scheduler.py:97-107) ----
+    def lookaheads(self) -> tuple[int, int | None]:
+        if not self.speculate:
+            return 1, None
+        if self.draft_async:
+            return self.K + 1, megaspec_lookahead(self.MQ_LEN, self.K)
+        return self.K + 1, self.K + 1
+
+    def _can_append(self, seq, tgt: int, dft: int | None) -> bool:
+        ok = self.block_manager.can_append(seq, tgt)
+        if self.speculate:
+            ok = ok and self.draft_block_manager.can_append(seq, dft)
+        return ok
+
+    def _can_allocate(self, seq) -> bool:
+        return self.block_manager.can_allocate(seq) and (not self.speculate or self.draft_block_manager.can_allocate(seq))
+
+    # ---- one scheduling decision ----
+    def schedule(self) -> tuple[list[Sequence], bool]:
+        picked: list[Sequence] = []
+        budget = 0
+        while self.waiting:
+            seq = self.waiting[0]
+            fresh = len(seq) - seq.num_cached_tokens
+            if budget + fresh > self.max_num_batched_tokens or not self._can_allocate(seq):
+                break
+            self.block_manager.allocate(seq)
+            if self.speculate:
+                self.draft_block_manager.allocate(seq)
+            budget += fresh
+            seq.status = SequenceStatus.RUNNING
+            self.waiting.popleft()
+            self.running.append(seq)
+            picked.append(seq)
+        if picked:
+            return picked, True
+
+        tgt, dft = self.lookaheads()
+        while self.running and len(picked) < self.max_num_seqs:
+            seq = self.running.popleft()
+            admitted = True
+            while not self._can_append(seq, tgt, dft):
+                if self.running:
+                    self.preempt(self.running.pop())
+                else:
+                    self.preempt(seq)
+                    admitted = False
+                    break
+            if admitted:
+                self.block_manager.may_append(seq, tgt)
+                if self.speculate:
+                    self.draft_block_manager.may_append(seq, dft)
+                picked.append(seq)
+        self.running.extendleft(reversed(picked))
+        return picked, False
+
+    def preempt(self, seq: Sequence) -> None:
+        seq.status = SequenceStatus.WAITING
+        seq.recovery_token_id = None
+        self.block_manager.deallocate(seq)
+        if self.speculate:
+            self.draft_block_manager.deallocate(seq)
+        self.waiting.appendleft(seq)
+        seq.num_prompt_tokens = seq.num_tokens      # completions so far are re-prefilled as prompt
+        seq.last_spec_step_accepted_len = -1
+
+    # ---- autoregressive post-step (reference scheduler.py:149-170) ----
+    def postprocess(self, seqs: list[Sequence], token_ids: list[int], is_prefill: bool) -> None:
+        bm = self.block_manager
+        for seq, tok in zip(seqs, token_ids):
+            seq.append_token(tok)
+            if is_prefill:
+                seq.num_cached_tokens = seq.num_prompt_tokens
+            else:
+                seq.num_cached_tokens += 1
+            done = (not seq.ignore_eos and tok == self.eos) or seq.num_completion_tokens == seq.max_new_tokens
+            if done:
+                seq.status = SequenceStatus.FINISHED
+                bm.deallocate(seq)
+                self.running.remove(seq)
+            elif seq.last_block_num_tokens == self.block_size:
+                bm.finalize_block(seq, seq.block_table, seq.num_blocks - 1)
+
+    # ---- speculative post-step (reference scheduler.py:172-327) ----
+    def _clip_suffix(self, seq: Sequence, suffix: list[int]) -> tuple[list[int], bool]:
+        if not seq.ignore_eos and self.eos in suffix:
+            suffix = suffix[:suffix.index(self.eos) + 1]
+        if seq.num_completion_tokens + len(suffix) >= seq.max_new_tokens:
+            suffix = suffix[:seq.max_new_tokens - seq.num_completion_tokens]
+        if seq.num_tokens + len(suffix) > self.max_model_len:
+            suffix = suffix[:max(0, self.max_model_len - seq.num_tokens)]
+        n = len(suffix)
+        finished = ((not seq.ignore_eos and self.eos in suffix)
+                    or seq.num_completion_tokens + n == seq.max_new_tokens
+                    or seq.num_tokens + n >= self.max_model_len)
+        return suffix, finished
+
+    def _return_excess_blocks(self, seq: Sequence, suffix_len: int) -> None:
+        needed = -(-(seq.num_tokens + suffix_len) // self.block_size)
+        for bm, table_name in ((self.block_manager, "block_table"), (self.draft_block_manager, "draft_block_table")):
+            table = getattr(seq, table_name)
+            extra = len(table) - needed
+            if extra > 0:
+                for block_id in table[-extra:]:
+                    bm.unref(block_id)
+                setattr(seq, table_name, table[:-extra])
+
+    def _commit_suffix(self, seq: Sequence, suffix: list[int], recovery: int) -> None:
+        n = len(suffix)
+        assert n >= 1
+        seq.token_ids.extend(suffix)
+        seq.num_tokens += n
+        seq.last_token = suffix[-1]
+        seq.num_cached_tokens += n
+        seq.num_draft_cached_tokens += n
+        seq.last_spec_step_accepted_len = n
+        seq.recovery_token_id = recovery
+        assert seq.block_table and seq.draft_block_table
+        for idx in range(len(seq.block_table)):
+            if (idx + 1) * self.block_size <= seq.num_tokens:
+                if self.block_manager.blocks[seq.block_table[idx]].hash == -1:
+                    self.block_manager.finalize_block(seq, seq.block_table, idx)
+                if self.draft_block_manager.blocks[seq.draft_block_table[idx]].hash == -1:
+                    self.draft_block_manager.finalize_block(seq, seq.draft_block_table, idx)
+
+    def postprocess_speculate(self, seqs: list[Sequence], new_suffixes: list[list[int]], next_recovery_tokens: list[int],
+                              eagle_acts=None) -> None:
+        for seq, suffix, rec in zip(seqs, new_suffixes, next_recovery_tokens):
+            suffix, finished = self._clip_suffix(seq, suffix)
+            self._return_excess_blocks(seq, len(suffix))
+            self._commit_suffix(seq, suffix, rec)
+            if finished:
+                seq.status = SequenceStatus.FINISHED
+                self.block_manager.deallocate(seq)
+                self.draft_block_manager.deallocate(seq)
+                self.running.remove(seq)

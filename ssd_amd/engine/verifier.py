@@ -1,0 +1,42 @@
+"""Target-side verification (reference Verifier, ssd/engine/verifier.py:12-153, and verify(),
+ssd/utils/verify.py:5-181, greedy branch): one K+1-query target forward per step; accept/reject runs on the
+device (wave ballot + prefix count) and the step's whole result comes back in one packed copy."""
+from __future__ import annotations
+
+from time import perf_counter
+
+from ssd_amd.engine.speculate_types import SpeculateResult, VerifierBase, VerifyResult
+
+
+class Verifier(VerifierBase):
+    def __init__(self, lookahead: int, device, target_model_runner, sampler_x=None, async_fan_out=None,
+                 jit_speculate: bool = False, tokenizer=None, metrics: dict | None = None):
+        super().__init__(lookahead, device)
+        self.target_model_runner = target_model_runner
+        self.sampler_x, self.async_fan_out, self.jit_speculate = sampler_x, async_fan_out, jit_speculate
+        self.tokenizer = tokenizer
+        self.metrics = metrics if metrics is not None else {}
+
+    def prefill(self, seqs, eagle: bool = False) -> VerifyResult:
+        token_ids = self.target_model_runner.call("run", seqs, True)
+        for seq, tok in zip(seqs, token_ids):
+            seq.recovery_token_id = tok
+        return VerifyResult([], [seq.recovery_token_id for seq in seqs], None)
+
+    def verify(self, seqs, speculate_result: SpeculateResult, eagle: bool = False) -> VerifyResult:
+        for seq in seqs:
+            if seq.temperature != 0 or (seq.draft_temperature or 0) != 0:
+                raise NotImplementedError("stochastic verification (temperature > 0) is a 'next' row (SURVEY.md 8f)")
+        t0 = perf_counter()
+        new_suffixes, recovery = self.target_model_runner.verify_chain(seqs, speculate_result.speculations)
+        for seq in seqs:
+            seq.num_cached_tokens += self.lookahead + 1
+        self.metrics.setdefault("target_verify_times", []).append(perf_counter() - t0)
+        self.metrics.setdefault("accepted_suffix_lens_with_recovery", []).extend(len(s) for s in new_suffixes)
+        hits = speculate_result.cache_hits
+        if hits is not None:
+            hl = hits if isinstance(hits, list) else hits.tolist()
+            self.metrics.setdefault("cache_hits", []).append(sum(hl) / max(1, len(hl)))
+            for h, s in zip(hl, new_suffixes):
+                self.metrics.setdefault("accepted_suffix_lens_on_hit" if h == 1 else "accepted_suffix_lens_on_miss", []).append(len(s))
+        return VerifyResult(new_suffixes, recovery, None)

@@ -31,7 +31,9 @@ SIGNATURES = {
                        c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int,
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "ssd_argmax_rows": [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p],
-    "ssd_verify_greedy": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "ssd_argmax_rows_val": [c_void_p, c_long, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p],
+    "ssd_argmax_merge": [c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p],
+    "ssd_verify_greedy": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "ssd_fork_topf": [c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "ssd_draft_advance": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
                           c_void_p, c_int, c_void_p],

@@ -81,9 +81,18 @@ def argmax_rows(logits, ld: int, T: int, V: int, out, out2=None):
     _check(load_library().ssd_argmax_rows(_p(logits), ld, T, V, _p(out), _p(out2), _stream()), "ssd_argmax_rows")
 
 
-def verify_greedy(preds, speculations, B: int, K: int, accept_len, recovery):
-    _check(load_library().ssd_verify_greedy(_p(preds), _p(speculations), B, K, _p(accept_len), _p(recovery), _stream()),
-           "ssd_verify_greedy")
+def argmax_rows_val(logits, ld: int, T: int, V: int, idx_offset: int, out_idx, out_val):
+    _check(load_library().ssd_argmax_rows_val(_p(logits), ld, T, V, idx_offset, _p(out_idx), _p(out_val), _stream()),
+           "ssd_argmax_rows_val")
+
+
+def argmax_merge(vals, idxs, tp: int, T: int, stride: int, out, out2=None):
+    _check(load_library().ssd_argmax_merge(_p(vals), _p(idxs), tp, T, stride, _p(out), _p(out2), _stream()), "ssd_argmax_merge")
+
+
+def verify_greedy(preds, speculations, B: int, K: int, accept_len, recovery, packed=None):
+    _check(load_library().ssd_verify_greedy(_p(preds), _p(speculations), B, K, _p(accept_len), _p(recovery), _p(packed),
+                                            _stream()), "ssd_verify_greedy")
 
 
 def fork_topf(logits, ld: int, V: int, returned, counts, offsets, B: int, K: int, mq: int, out):

@@ -1,0 +1,217 @@
+"""The decoder forward on MI355X: a fixed sequence of libssdhip launches over pre-allocated buffers.
+
+Functionally LlamaForCausalLM.forward / Qwen3ForCausalLM.forward + compute_logits of the reference
+(ssd/models/llama3.py:89-99,185-199,248-273; ssd/models/qwen3.py:90-108; ssd/layers/embed_head.py:78-116), with
+the process-global attention Context (ssd/utils/context.py) turned into explicit arguments.
+
+Per layer the launch list is: add+RMSNorm -> QKV GEMM -> (head-norm)+RoPE+KV-store -> paged attention
+(+split merge) -> O GEMM [+all-reduce] -> add+RMSNorm -> gate_up GEMM with fused SiLU*mul -> down GEMM
+[+all-reduce].  Activations that feed a GEMM are produced directly in the fragment-major layout; nothing is
+allocated during a forward, so the whole thing can be captured in a hipGraph (torch.cuda.CUDAGraph is
+hipGraph on ROCm) including the RCCL all-reduces.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as dist
+
+from ssd_amd.hip import ops as H
+from ssd_amd.model_config import ModelConfig
+
+BF16 = torch.bfloat16
+
+
+@dataclass
+class AttnMeta:
+    """What the reference keeps in its global Context, plus the tree geometry."""
+    mode: int                     # H.MODE_CAUSAL | H.MODE_TREE
+    B: int
+    max_q: int
+    slot_mapping: torch.Tensor    # int32 [T]
+    context_lens: torch.Tensor    # int32 [B]
+    block_tables: torch.Tensor    # int32 [B, max_blocks]
+    cu_q: torch.Tensor | None = None
+    q_per_seq: int = 0
+    tree_K: int = 0
+    tree_mq: int = 0
+    tree_step: int = 0
+    tree_F: int = 1
+    tree_jidx: torch.Tensor | None = None
+
+
+def make_cos_sin(head_dim: int, max_pos: int, theta: float, device) -> torch.Tensor:
+    """fp32 [max_pos, hd] = cos || sin, computed on the host exactly as RotaryEmbedding.__init__ does
+    (ssd/layers/rotary_embedding.py:28-36) -- never sinf/cosf on the device."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float) / head_dim))
+    t = torch.arange(max_pos, dtype=torch.float)
+    freqs = torch.einsum("i,j -> ij", t, inv_freq)
+    return torch.cat((freqs.cos(), freqs.sin()), dim=-1).contiguous().to(device)
+
+
+class HipDecoder:
+    def __init__(self, cfg: ModelConfig, *, max_tokens: int, max_seqs: int, max_blocks: int, block_size: int,
+                 max_model_len: int, device: torch.device, tp_rank: int = 0, tp_size: int = 1, tp_group=None,
+                 max_logit_rows: int | None = None, max_split_tokens: int = 256):
+        self.cfg, self.device = cfg, device
+        self.tp_rank, self.tp_size, self.tp_group = tp_rank, tp_size, tp_group
+        assert cfg.num_heads % tp_size == 0 and cfg.num_kv_heads % tp_size == 0
+        assert cfg.intermediate_size % (tp_size * 32) == 0 and cfg.vocab_size % (tp_size * 16) == 0
+        self.nh, self.nkv = cfg.num_heads // tp_size, cfg.num_kv_heads // tp_size
+        self.hd, self.h = cfg.head_dim, cfg.hidden_size
+        self.I = cfg.intermediate_size // tp_size
+        self.V = cfg.vocab_size // tp_size
+        self.qkv_n = (self.nh + 2 * self.nkv) * self.hd
+        self.qn = self.nh * self.hd
+        self.block_size, self.max_blocks = block_size, max_blocks
+        self.max_tokens = max_tokens
+        self.max_logit_rows = max_logit_rows or max_tokens
+        self.max_split_tokens = max_split_tokens
+        self.w: dict[str, torch.Tensor] = {}
+        self.kv_cache: torch.Tensor | None = None
+        self.cos_sin = make_cos_sin(self.hd, max_model_len, cfg.rope_theta, device)
+
+        def z(*shape, dtype=BF16):
+            return torch.zeros(*shape, dtype=dtype, device=device)
+
+        T = max_tokens
+        self.buf_h = z(T, self.h)
+        self.buf_res = z(T, self.h)
+        self.buf_xf = z(H.frag_numel(T, self.h))
+        self.buf_qkv = z(T, self.qkv_n)
+        self.buf_q = z(T, self.qn)
+        self.buf_af = z(H.frag_numel(T, self.qn))
+        self.buf_actf = z(H.frag_numel(T, self.I))
+        self.buf_lastf = z(H.frag_numel(self.max_logit_rows, self.h))
+        self.logits = z(self.max_logit_rows, self.V)
+        self.max_splits = 16
+        st = min(T, max_split_tokens)
+        self.ws_o = z(st * self.nh * self.max_splits * self.hd, dtype=torch.float32)
+        self.ws_ml = z(st * self.nh * self.max_splits * 2, dtype=torch.float32)
+        # vocab-parallel argmax scratch
+        self.am_val = z(tp_size, self.max_logit_rows, dtype=torch.float32)
+        self.am_idx = z(tp_size, self.max_logit_rows, dtype=torch.int64)
+        self.am_val_l = z(self.max_logit_rows, dtype=torch.float32)
+        self.am_idx_l = z(self.max_logit_rows, dtype=torch.int64)
+
+    # ---------------------------------------------------------------------------------------------
+    def load_weights(self, weight_iter) -> None:
+        """Consumes (name, row-major bf16 shard) pairs; matrices are re-tiled once into the fragment-major
+        layout (gate_up with gate/up row groups interleaved for the fused SiLU epilogue)."""
+        for name, w in weight_iter:
+            w = w.to(self.device).contiguous()
+            if w.dim() == 2 and not name.endswith("embed_tokens.weight"):
+                R, K = w.shape
+                out = torch.empty(H.frag_numel(R, K), dtype=BF16, device=self.device)
+                H.rows_to_frag(w, out, R, K, mode=1 if name.endswith("gate_up_proj.weight") else 0)
+                self.w[name] = out
+            elif name.endswith("embed_tokens.weight"):
+                self.w[name] = w                                   # row-major for the gather
+                if self.cfg.tie_word_embeddings:                   # tied LM head: same values, GEMM layout
+                    out = torch.empty(H.frag_numel(w.shape[0], w.shape[1]), dtype=BF16, device=self.device)
+                    H.rows_to_frag(w, out, w.shape[0], w.shape[1])
+                    self.w["lm_head.weight"] = out
+            else:
+                self.w[name] = w
+        torch.cuda.synchronize(self.device)
+
+    def weight_bytes(self) -> int:
+        """HBM bytes one forward must stream (every matrix once; the embedding table is only gathered)."""
+        return sum(t.numel() * t.element_size() for n, t in self.w.items() if n != "model.embed_tokens.weight")
+
+    def kv_block_bytes(self) -> int:
+        return 2 * self.cfg.num_layers * self.block_size * self.nkv * self.hd * 2
+
+    def alloc_kv(self, num_blocks: int) -> None:
+        # [L][2][blocks][nkv][block_size][hd]: one (page, kv head) is a contiguous run for the attention kernel
+        self.num_blocks = num_blocks
+        self.kv_cache = torch.zeros(self.cfg.num_layers, 2, num_blocks, self.nkv, self.block_size, self.hd,
+                                    dtype=BF16, device=self.device)
+
+    # ---------------------------------------------------------------------------------------------
+    def _gemm(self, xf, K, w, N, y, T, ldy, epi=H.EPI_ROWS, bias=None):
+        if T <= 128:
+            H.gemm(xf, w, y, T, N, K, ldy, epi, bias)
+            return
+        yf = y.view(-1)
+        for m0 in range(0, T, 128):
+            m = min(128, T - m0)
+            x_off = (m0 // 16) * (K // 32) * 512
+            y_off = (m0 // 16) * ((N // 2) // 32) * 512 if epi == H.EPI_SILU_FRAG else m0 * ldy
+            H.gemm(xf[x_off:], w, yf[y_off:], m, N, K, ldy, epi, bias)
+
+    def _allreduce(self, t):
+        if self.tp_size > 1:
+            dist.all_reduce(t, group=self.tp_group)
+
+    def _splits(self, T: int, meta: AttnMeta) -> int:
+        G = self.nh // self.nkv
+        groups = (-(-(meta.max_q * G) // 16) + 1) // 2
+        base = max(1, groups * meta.B * self.nkv)
+        s = max(1, min(self.max_splits, 256 // base))
+        if s > 1 and T > self.max_split_tokens:
+            s = 1
+        return s
+
+    def forward(self, input_ids: torch.Tensor, positions: torch.Tensor, T: int, meta: AttnMeta) -> None:
+        """Runs all layers; leaves the final (pre-norm) hidden state in buf_h and the residual in buf_res."""
+        cfg, w = self.cfg, self.w
+        h, res, xf = self.buf_h, self.buf_res, self.buf_xf
+        H.embedding(input_ids, w["model.embed_tokens.weight"], h, T, self.h,
+                    vocab_start=self.tp_rank * self.V if self.tp_size > 1 else 0, vocab_count=self.V if self.tp_size > 1 else cfg.vocab_size)
+        self._allreduce(h[:T])
+        splits = self._splits(T, meta)
+        scale = self.hd ** -0.5
+        for li in range(cfg.num_layers):
+            p = f"model.layers.{li}."
+            # residual is None on layer 0 (llama3.py:187-190): residual := embeddings, x := norm(embeddings)
+            H.rmsnorm(h, w[p + "input_layernorm.weight"], cfg.rms_norm_eps, T, self.h,
+                      res_in=None if li == 0 else res, res_out=res, out_frag=xf)
+            self._gemm(xf, self.h, w[p + "self_attn.qkv_proj.weight"], self.qkv_n, self.buf_qkv, T, self.qkv_n,
+                       bias=w.get(p + "self_attn.qkv_proj.bias"))
+            kc, vc = self.kv_cache[li, 0], self.kv_cache[li, 1]
+            H.rope_store_kv(self.buf_qkv, positions, self.cos_sin, meta.slot_mapping, self.buf_q, kc, vc, T, self.nh,
+                            self.nkv, self.hd, self.block_size, q_norm_w=w.get(p + "self_attn.q_norm.weight"),
+                            k_norm_w=w.get(p + "self_attn.k_norm.weight"), eps=cfg.rms_norm_eps)
+            H.attn_paged(self.buf_q, kc, vc, meta.block_tables, self.max_blocks, meta.context_lens, meta.B, T, meta.max_q,
+                         self.nh, self.nkv, self.hd, self.block_size, scale, cu_q=meta.cu_q, q_per_seq=meta.q_per_seq,
+                         mode=meta.mode, tree_K=meta.tree_K, tree_mq=meta.tree_mq, tree_step=meta.tree_step,
+                         tree_F=meta.tree_F, tree_jidx=meta.tree_jidx, splits=splits, ws_o=self.ws_o, ws_ml=self.ws_ml,
+                         out_frag=self.buf_af)
+            self._gemm(self.buf_af, self.qn, w[p + "self_attn.o_proj.weight"], self.h, h, T, self.h)
+            self._allreduce(h[:T])
+            H.rmsnorm(h, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps, T, self.h, res_in=res, res_out=res, out_frag=xf)
+            self._gemm(xf, self.h, w[p + "mlp.gate_up_proj.weight"], 2 * self.I, self.buf_actf, T, 0, epi=H.EPI_SILU_FRAG)
+            self._gemm(self.buf_actf, self.I, w[p + "mlp.down_proj.weight"], self.h, h, T, self.h)
+            self._allreduce(h[:T])
+
+    def compute_logits(self, T: int, gather: torch.Tensor | None = None, rows: int | None = None) -> int:
+        """Final add+RMSNorm (optionally only the `gather` rows: prefill last-token, embed_head.py:81-84) and the
+        LM-head GEMM into self.logits[:rows] (this rank's vocab shard).  Returns the number of logit rows."""
+        n = T if gather is None else rows
+        assert n <= self.max_logit_rows
+        H.rmsnorm(self.buf_h, self.w["model.norm.weight"], self.cfg.rms_norm_eps, n, self.h, res_in=self.buf_res,
+                  out_frag=self.buf_lastf, gather=gather)
+        self._gemm(self.buf_lastf, self.h, self.w["lm_head.weight"], self.V, self.logits, n, self.V)
+        return n
+
+    def argmax(self, n: int, out: torch.Tensor, out2: torch.Tensor | None = None) -> None:
+        """Greedy tokens of logits[:n] over the FULL vocabulary (identical on every TP rank)."""
+        if self.tp_size == 1:
+            H.argmax_rows(self.logits, self.V, n, self.V, out, out2)
+            return
+        H.argmax_rows_val(self.logits, self.V, n, self.V, self.tp_rank * self.V, self.am_idx_l, self.am_val_l)
+        R = self.max_logit_rows
+        dist.all_gather_into_tensor(self.am_val.view(-1), self.am_val_l, group=self.tp_group)
+        dist.all_gather_into_tensor(self.am_idx.view(-1), self.am_idx_l, group=self.tp_group)
+        # gathered layout is [tp][R]; rows beyond n are ignored by the merge (T = n, stride R)
+        H.argmax_merge(self.am_val, self.am_idx, self.tp_size, n, R, out, out2)
+
+    def full_logits(self, n: int) -> torch.Tensor:
+        """[n, V_full] logits on every rank (only needed off the greedy path)."""
+        if self.tp_size == 1:
+            return self.logits[:n]
+        parts = [torch.empty(n, self.V, dtype=BF16, device=self.device) for _ in range(self.tp_size)]
+        dist.all_gather(parts, self.logits[:n].contiguous(), group=self.tp_group)
+        return torch.cat(parts, dim=-1)

@@ -1,0 +1,66 @@
+"""Which GPU / rank / role this process has.
+
+One process per GPU.  Roles as in the reference (ssd/engine/llm_engine.py:61-93): ranks 0..TP-1 hold the
+tensor-parallel target; with draft_async the LAST rank is the dedicated draft GPU.  The group layout mirrors
+ssd/engine/model_runner.py:98-107 (tp group + a 2-rank async group), but the processes are launched SPMD
+(``torchrun`` / ``python -m torch.distributed.run``) and rendezvous over 127.0.0.1.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, replace
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass
+class Topology:
+    rank: int
+    world_size: int
+    device: torch.device
+    role: str                    # "target" | "draft"
+    tp_rank: int
+    tp_size: int
+    tp_group: object = None
+    async_group: object = None   # [rank 0, draft rank]
+    draft_rank: int = -1
+
+    def single(self) -> "Topology":
+        """Same device, no tensor parallelism (a sync-speculation draft is replicated on every rank)."""
+        return replace(self, tp_rank=0, tp_size=1, tp_group=None)
+
+
+def init_process_group_if_needed(backend: str | None = None) -> tuple[int, int]:
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", str(rank))))
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world
+
+
+def resolve_topology(config) -> Topology:
+    rank, world = init_process_group_if_needed()
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    device = torch.device("cuda", local) if torch.cuda.is_available() else torch.device("cpu")
+    if world == 1:
+        assert config.num_gpus == 1, (f"num_gpus={config.num_gpus} needs one process per GPU: launch with "
+                                      f"`python -m torch.distributed.run --nproc-per-node {config.num_gpus} ...`")
+        return Topology(0, 1, device, "target", 0, 1)
+    assert world == config.num_gpus, f"WORLD_SIZE={world} but num_gpus={config.num_gpus}"
+    if config.speculate and config.draft_async:
+        tp = world - 1
+        tp_group = dist.new_group(list(range(tp)))
+        async_group = dist.new_group([0, tp])
+        if rank == tp:
+            return Topology(rank, world, device, "draft", 0, 1, None, async_group, tp)
+        return Topology(rank, world, device, "target", rank, tp, tp_group, async_group if rank == 0 else None, tp)
+    tp_group = dist.new_group(list(range(world)))
+    return Topology(rank, world, device, "target", rank, world, tp_group)

@@ -1,0 +1,136 @@
+"""Weights: reference parameter names, TP sharding, synthetic generation and safetensors loading.
+
+Parameter names are the reference's packed names (ssd/models/llama3.py:277-283, ssd/utils/loader.py:186-218):
+  model.embed_tokens.weight [V,h]; model.layers.{i}.input_layernorm.weight; .self_attn.qkv_proj.weight
+  [(nh+2nkv)hd, h] (+ .bias, + q_norm/k_norm for Qwen3); .self_attn.o_proj.weight [h, nh*hd];
+  .post_attention_layernorm.weight; .mlp.gate_up_proj.weight [2I, h]; .mlp.down_proj.weight [h, I];
+  model.norm.weight; lm_head.weight [V,h] (absent when tied).
+Sharding follows the reference weight loaders (ssd/layers/linear.py:90-95,116-122,148-162,188-193;
+ssd/layers/embed_head.py:41-47).
+
+No weights exist offline, so the default source is synthetic: every FULL tensor is a deterministic function
+of (seed, name) -- independent of rank -- and is sharded afterwards, so TP=N computes the same function as TP=1.
+"""
+from __future__ import annotations
+
+import glob
+import hashlib
+import os
+from typing import Iterator
+
+import torch
+
+from ssd_amd.model_config import ModelConfig
+
+BF16 = torch.bfloat16
+
+
+def param_shapes(cfg: ModelConfig) -> list[tuple[str, tuple[int, ...]]]:
+    h, hd, nh, nkv, I, V = cfg.hidden_size, cfg.head_dim, cfg.num_heads, cfg.num_kv_heads, cfg.intermediate_size, cfg.vocab_size
+    out = [("model.embed_tokens.weight", (V, h))]
+    for i in range(cfg.num_layers):
+        p = f"model.layers.{i}."
+        out.append((p + "input_layernorm.weight", (h,)))
+        out.append((p + "self_attn.qkv_proj.weight", ((nh + 2 * nkv) * hd, h)))
+        if cfg.attention_bias:
+            out.append((p + "self_attn.qkv_proj.bias", ((nh + 2 * nkv) * hd,)))
+        if cfg.qk_norm:
+            out.append((p + "self_attn.q_norm.weight", (hd,)))
+            out.append((p + "self_attn.k_norm.weight", (hd,)))
+        out.append((p + "self_attn.o_proj.weight", (h, nh * hd)))
+        out.append((p + "post_attention_layernorm.weight", (h,)))
+        out.append((p + "mlp.gate_up_proj.weight", (2 * I, h)))
+        out.append((p + "mlp.down_proj.weight", (h, I)))
+    out.append(("model.norm.weight", (h,)))
+    if not cfg.tie_word_embeddings:
+        out.append(("lm_head.weight", (V, h)))
+    return out
+
+
+def _name_seed(seed: int, name: str) -> int:
+    return int.from_bytes(hashlib.blake2b(f"{seed}:{name}".encode(), digest_size=7).digest(), "little")
+
+
+def synthetic_tensor(name: str, shape, seed: int, std: float, gen_device: str, norm_jitter: float = 0.0) -> torch.Tensor:
+    """Full (unsharded) synthetic parameter.  gen_device="cpu" gives values reproducible on any machine (tests,
+    oracle comparisons); "cuda" is for the multi-GB benchmark models."""
+    g = torch.Generator(device=gen_device)
+    g.manual_seed(_name_seed(seed, name))
+    if "norm" in name:
+        if norm_jitter == 0.0:
+            return torch.ones(shape, dtype=BF16, device=gen_device)
+        return (1.0 + norm_jitter * torch.randn(shape, generator=g, device=gen_device, dtype=torch.float32)).to(BF16)
+    return (std * torch.randn(shape, generator=g, device=gen_device, dtype=torch.float32)).to(BF16)
+
+
+def shard_param(cfg: ModelConfig, name: str, w: torch.Tensor, rank: int, tp: int) -> torch.Tensor:
+    if tp == 1:
+        return w
+    hd, nh, nkv, I = cfg.head_dim, cfg.num_heads, cfg.num_kv_heads, cfg.intermediate_size
+    if name.endswith("qkv_proj.weight") or name.endswith("qkv_proj.bias"):
+        q, k, v = w.split([nh * hd, nkv * hd, nkv * hd], dim=0)
+        return torch.cat([q.chunk(tp, 0)[rank], k.chunk(tp, 0)[rank], v.chunk(tp, 0)[rank]], 0).contiguous()
+    if name.endswith("gate_up_proj.weight"):
+        g, u = w.split([I, I], dim=0)
+        return torch.cat([g.chunk(tp, 0)[rank], u.chunk(tp, 0)[rank]], 0).contiguous()
+    if name.endswith("o_proj.weight") or name.endswith("down_proj.weight"):
+        return w.chunk(tp, 1)[rank].contiguous()
+    if name.endswith("embed_tokens.weight") or name.endswith("lm_head.weight"):
+        return w.chunk(tp, 0)[rank].contiguous()
+    return w
+
+
+def synthetic_weights(cfg: ModelConfig, seed: int, std: float, rank: int = 0, tp: int = 1, gen_device: str = "cpu",
+                      out_device: str | None = None, norm_jitter: float = 0.0) -> Iterator[tuple[str, torch.Tensor]]:
+    """Yields (name, this rank's shard) one tensor at a time (bounded transient memory for 70B)."""
+    for name, shape in param_shapes(cfg):
+        w = shard_param(cfg, name, synthetic_tensor(name, shape, seed, std, gen_device, norm_jitter), rank, tp)
+        yield name, (w.to(out_device) if out_device is not None else w)
+
+
+def synthetic_state_dict(cfg: ModelConfig, seed: int, std: float, norm_jitter: float = 0.0) -> dict:
+    return dict(synthetic_weights(cfg, seed, std, gen_device="cpu", norm_jitter=norm_jitter))
+
+
+# --------------------------------------------------------------------------------------------------
+# HF safetensors (reference ssd/utils/loader.py:186-218): q/k/v and gate/up are packed by concatenation
+# --------------------------------------------------------------------------------------------------
+_PACK = {"q_proj": ("qkv_proj", 0), "k_proj": ("qkv_proj", 1), "v_proj": ("qkv_proj", 2),
+         "gate_proj": ("gate_up_proj", 0), "up_proj": ("gate_up_proj", 1)}
+
+
+def has_safetensors(model_dir: str) -> bool:
+    return os.path.isdir(model_dir) and bool(glob.glob(os.path.join(model_dir, "*.safetensors")))
+
+
+def load_safetensors(cfg: ModelConfig, model_dir: str, rank: int = 0, tp: int = 1,
+                     out_device: str | None = None) -> Iterator[tuple[str, torch.Tensor]]:
+    from safetensors import safe_open
+    index: dict[str, str] = {}
+    for f in sorted(glob.glob(os.path.join(model_dir, "*.safetensors"))):
+        with safe_open(f, "pt", "cpu") as sf:
+            for k in sf.keys():
+                index[k] = f
+
+    def get(name: str) -> torch.Tensor:
+        with safe_open(index[name], "pt", "cpu") as sf:
+            return sf.get_tensor(name).to(BF16)
+
+    def packed_sources(name: str) -> list[str] | None:
+        for src, (dst, _) in _PACK.items():
+            pass
+        if "qkv_proj" in name:
+            return [name.replace("qkv_proj", s) for s in ("q_proj", "k_proj", "v_proj")]
+        if "gate_up_proj" in name:
+            return [name.replace("gate_up_proj", s) for s in ("gate_proj", "up_proj")]
+        return None
+
+    for name, shape in param_shapes(cfg):
+        srcs = packed_sources(name)
+        if srcs is not None and name not in index:
+            w = torch.cat([get(s) for s in srcs], dim=0)
+        else:
+            w = get(name)
+        assert tuple(w.shape) == tuple(shape), f"{name}: {tuple(w.shape)} != {shape}"
+        w = shard_param(cfg, name, w, rank, tp)
+        yield name, (w.to(out_device) if out_device is not None else w)

@@ -1,0 +1,94 @@
+"""The real engine (scheduler, block managers, SpecDecodeStep, SpeculatorSync, Verifier) driven on CPU through
+the oracle runner, pinned against traces produced by the reference's own modules (tests/golden/make_golden.py:
+gen_engine).  Same machine + same torch calls => token streams must be identical."""
+import torch
+
+from oracle.runner import oracle_runner_factory
+from ssd_amd.engine.llm_engine import LLMEngine
+from ssd_amd.model_config import ModelConfig
+from ssd_amd.sampling_params import SamplingParams
+
+
+def mcfg(g, prefix):
+    ci, cf = g[prefix + "cfg_i"].tolist(), g[prefix + "cfg_f"].tolist()
+    return ModelConfig("llama", ci[0], ci[1], ci[2], ci[3], ci[4], ci[5], ci[6], cf[0], cf[1], ci[7], False)
+
+
+def weights(g, prefix):
+    return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix) and "cfg" not in k}
+
+
+COMMON = dict(max_model_len=512, max_num_batched_tokens=512, kvcache_block_size=16, num_kvcache_blocks=64)
+
+
+def test_autoregressive_matches_reference(golden):
+    g = golden("engine_golden")
+    eng = LLMEngine("tiny", hf_config=mcfg(g, "t_"), runner_factory=oracle_runner_factory(weights(g, "t.")), **COMMON)
+    n = g["ar_tokens"].numel()
+    out, metrics = eng.generate([g["prompt"].tolist()], SamplingParams(temperature=0, max_new_tokens=n, ignore_eos=True), use_tqdm=False)
+    assert out[0]["token_ids"] == g["ar_tokens"].tolist()
+    # the prefill count includes the token appended by postprocess, exactly like the reference (step.py:47-48)
+    assert metrics["decode_total_tokens"] == n - 1 and metrics["prefill_total_tokens"] == g["prompt"].numel() + 1
+
+
+def _sd(g, tag):
+    K = int(g["sd_K"])
+    wt = weights(g, "t.")
+    if tag == "same":
+        cfg_d, wd = mcfg(g, "t_"), wt
+    else:
+        cfg_d, wd = mcfg(g, "d_"), weights(g, "d.")
+    eng = LLMEngine("tiny", hf_config=mcfg(g, "t_"), draft="tiny-draft", draft_hf_config=cfg_d, speculate=True, speculate_k=K,
+                    runner_factory=oracle_runner_factory(wt, wd), **COMMON)
+    want = g[f"sd_{tag}_tokens"].tolist()
+    streamed = []
+    out, metrics = eng.generate([g["prompt"].tolist()], SamplingParams(temperature=0, max_new_tokens=len(want), ignore_eos=True),
+                                use_tqdm=False, stream_callback=lambda sid, toks: streamed.extend(toks))
+    assert out[0]["token_ids"] == want
+    assert streamed == want
+    lens = metrics["accepted_suffix_lens_with_recovery"]
+    ref_lens = [(row >= 0).sum().item() for row in g[f"sd_{tag}_suffix"]]
+    assert lens == ref_lens
+    return lens, K
+
+
+def test_sync_sd_matches_reference_independent_draft(golden):
+    lens, K = _sd(golden("engine_golden"), "diff")
+    assert min(lens) >= 1
+
+
+def test_sync_sd_draft_equals_target_accepts_everything(golden):
+    g = golden("engine_golden")
+    lens, K = _sd(g, "same")
+    assert all(n == K + 1 for n in lens)
+    # speculative decoding is exact: the stream equals plain autoregressive decoding
+    n = min(g["ar_tokens"].numel(), g["sd_same_tokens"].numel())
+    assert g["sd_same_tokens"][:n].tolist() == g["ar_tokens"][:n].tolist()
+
+
+def test_batch_of_sequences_and_eos():
+    """b > 1 scheduling, EOS truncation and block recycling on synthetic tiny models."""
+    cfg = ModelConfig("llama", 64, 2, 2, 1, 32, 128, 256, 1e-5, 5e5, 512, False)
+    dcfg = ModelConfig("llama", 64, 1, 2, 1, 32, 128, 256, 1e-5, 5e5, 512, False)
+    kw = dict(max_model_len=256, max_num_batched_tokens=256, kvcache_block_size=16, num_kvcache_blocks=40, weights_std=0.1)
+    prompts = [[(7 * i + j) % 256 for j in range(5 + 3 * i)] for i in range(4)]
+    sp = SamplingParams(temperature=0, max_new_tokens=20, ignore_eos=True)
+    ar = LLMEngine("t", hf_config=cfg, max_num_seqs=4, runner_factory=oracle_runner_factory(), **kw)
+    ref, _ = ar.generate(prompts, sp, use_tqdm=False)
+    sd = LLMEngine("t", hf_config=cfg, draft="d", draft_hf_config=dcfg, speculate=True, speculate_k=3, max_num_seqs=4,
+                   runner_factory=oracle_runner_factory(), **kw)
+    got, m = sd.generate(prompts, sp, use_tqdm=False)
+    assert [o["token_ids"] for o in got] == [o["token_ids"] for o in ref]
+    # every block went back to the pool
+    assert len(sd.scheduler.block_manager.free_block_ids) == 40
+    assert len(sd.scheduler.draft_block_manager.free_block_ids) == sd.draft_runner.num_kvcache_blocks
+    # EOS: declare the 3rd generated token of sequence 0 to be EOS
+    eos = ref[0]["token_ids"][2]
+    ar2 = LLMEngine("t", hf_config=cfg, eos=eos, max_num_seqs=4, runner_factory=oracle_runner_factory(), **kw)
+    sd2 = LLMEngine("t", hf_config=cfg, eos=eos, draft="d", draft_hf_config=dcfg, speculate=True, speculate_k=3,
+                    max_num_seqs=4, runner_factory=oracle_runner_factory(), **kw)
+    sp2 = SamplingParams(temperature=0, max_new_tokens=20, ignore_eos=False)
+    a, _ = ar2.generate(prompts, sp2, use_tqdm=False)
+    b, _ = sd2.generate(prompts, sp2, use_tqdm=False)
+    assert [o["token_ids"] for o in a] == [o["token_ids"] for o in b]
+    assert a[0]["token_ids"][-1] == eos and len(a[0]["token_ids"]) <= 3

@@ -65,7 +65,7 @@ def test_gemm_vs_oracle(H, M, N, K):
     xf, wf = to_frag_dev(x), to_frag_dev(w)
     y = torch.full((M, N), float("nan"), dtype=BF, device="cuda")
     H.gemm(xf, wf, y, M, N, K, N)
-    assert_close_bf16(y, ref, max_ulp=1, max_frac=0.03, what="gemm rows")
+    assert_close_bf16(y, ref, max_ulp=1, max_frac=0.03, rel_floor=2 ** -7, what="gemm rows")
     # fp32 epilogue against an fp64 reference: <= 1e-3 abs (north_star logits tolerance)
     y32 = torch.zeros(M, N, dtype=torch.float32, device="cuda")
     H.gemm(xf, wf, y32, M, N, K, N, epilogue=H.EPI_ROWS_F32)
@@ -86,7 +86,7 @@ def test_gemm_configs_and_bias(H):
         for waves in (1, 3, 4, 8, 16):
             y = torch.zeros(M, N, dtype=BF, device="cuda")
             H.gemm(xf, wf, y, M, N, K, N, bias=dev(b), cfg=(nt, waves))
-            assert_close_bf16(y, ref, max_ulp=1, max_frac=0.03, what=f"gemm cfg {nt},{waves}")
+            assert_close_bf16(y, ref, max_ulp=1, max_frac=0.03, rel_floor=2 ** -7, what=f"gemm cfg {nt},{waves}")
             outs.append(y.clone())
     # determinism: same config twice -> identical bits
     y2 = torch.zeros(M, N, dtype=BF, device="cuda")
@@ -106,7 +106,7 @@ def test_gemm_silu_epilogue(H, M):
     act_f = torch.zeros(H.frag_numel(M, I), dtype=BF, device="cuda")
     H.gemm(to_frag_dev(x), wf, act_f, M, 2 * I, K, 0, epilogue=H.EPI_SILU_FRAG)
     act = LY.frag_to_rows_ref(act_f.cpu(), M, I)
-    assert_close_bf16(act, ref, max_ulp=1, max_frac=0.03, what="gemm+silu")
+    assert_close_bf16(act, ref, max_ulp=1, max_frac=0.03, rel_floor=2 ** -7, what="gemm+silu")
 
 
 def test_embedding(H, golden):
@@ -117,7 +117,9 @@ def test_embedding(H, golden):
     # TP-style shard [500, 1000): rows outside give zeros
     H.embedding(dev(g["emb_ids"]), dev(g["emb_w"][500:].contiguous()), out, 7, 256, vocab_start=500, vocab_count=500)
     ref = O.embedding(g["emb_ids"], g["emb_w"][500:], 500)
-    assert torch.equal(out.cpu().view(torch.int16), ref.view(torch.int16))
+    # masked rows: the reference's `mask * y` leaves -0.0 where y < 0; the sign of zero vanishes in the TP
+    # all-reduce that always follows, so compare values, not bits
+    assert torch.equal(out.cpu().float(), ref.float())
 
 
 def test_rmsnorm_golden(H, golden):
@@ -233,7 +235,10 @@ def run_attn(H, q, kc, vc, bt, max_blocks, ctx, nh, nkv, hd, bs, cu_q=None, q_pe
     return rows
 
 
-ATTN_TOL = dict(max_ulp=2, max_frac=0.25, abs_floor=2e-3)
+# P is rounded to bf16 before P.V (as FlashAttention-3 does in the reference): |delta o| <= 2^-9 * sum_i p_i |v_i|,
+# i.e. up to ~4e-3 absolute for N(0,1) values on short contexts, whatever the magnitude of o itself.
+ATTN_TOL = dict(max_ulp=1, max_frac=0.05, abs_floor=2e-4)
+ATTN_TOL_FA = dict(max_ulp=2, max_frac=0.25, abs_floor=4e-3)   # flags bit1: single-bf16 P
 
 
 @pytest.mark.parametrize("flags", [0, 1])
@@ -343,12 +348,39 @@ def test_verify_greedy_golden(H, golden):
     lp, spec = g["v_logits_p"], g["v_spec"]
     B, Kp1, V = lp.shape
     preds = torch.zeros(B * Kp1, dtype=torch.int64, device="cuda")
-    H.argmax_rows(dev(lp.view(B * Kp1, V)), V, B * Kp1, V, preds)
+    ld = (V + 7) // 8 * 8            # rows must be 16-byte aligned (real vocab sizes are)
+    padded = torch.full((B * Kp1, ld), float("-inf"), dtype=BF)
+    padded[:, :V] = lp.view(B * Kp1, V)
+    H.argmax_rows(dev(padded), ld, B * Kp1, V, preds)
     acc = torch.zeros(B, dtype=torch.int32, device="cuda")
     rec = torch.zeros(B, dtype=torch.int64, device="cuda")
-    H.verify_greedy(preds, dev(spec), B, Kp1 - 1, acc, rec)
+    packed = torch.zeros(B, Kp1 + 2, dtype=torch.int64, device="cuda")
+    H.verify_greedy(preds, dev(spec), B, Kp1 - 1, acc, rec, packed)
     assert (acc.cpu() + 1).tolist() == g["v_suffix_len"].tolist()
     assert rec.cpu().tolist() == g["v_rec"].tolist()
+    pk = packed.cpu()
+    assert pk[:, 0].tolist() == acc.cpu().tolist() and pk[:, 1].tolist() == rec.cpu().tolist()
+    assert torch.equal(pk[:, 2:], spec)
+    for b in range(B):   # suffix = [spec_0] + accepted draft tokens, exactly what verify() returns
+        n = int(pk[b, 0])
+        assert pk[b, 2:3 + n].tolist() == g["v_suffix"][b, :n + 1].tolist()
+
+
+def test_argmax_vocab_parallel_merge(H):
+    torch.manual_seed(8)
+    T, V, tp = 6, 4096, 4
+    x = torch.randn(T, V).to(BF)
+    x[1, 100] = 7.0
+    x[1, 3000] = 7.0          # tie across shards -> lowest global index
+    Vs = V // tp
+    vals = torch.zeros(tp, T, dtype=torch.float32, device="cuda")
+    idxs = torch.zeros(tp, T, dtype=torch.int64, device="cuda")
+    for r in range(tp):
+        shard = dev(x[:, r * Vs:(r + 1) * Vs].contiguous())
+        H.argmax_rows_val(shard, Vs, T, Vs, r * Vs, idxs[r], vals[r])
+    out = torch.zeros(T, dtype=torch.int64, device="cuda")
+    H.argmax_merge(vals, idxs, tp, T, T, out)
+    assert out.cpu().tolist() == O.argmax_rows(x).tolist()
 
 
 def test_fork_golden(H, golden):
