@@ -69,6 +69,7 @@ def workload_models(name):
     return "tiny-target", t, "tiny-draft", d
 
 
+@torch.inference_mode()
 def gemm_roofline(engine, steps_k):
     """Time every skinny-GEMM launch shape of one speculation step with HIP events on the launch stream.
     For each (matrix kind, M) all L layers' matrices are launched back to back (L x tens of MB >> the 256 MiB

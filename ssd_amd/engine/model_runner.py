@@ -27,7 +27,7 @@ class ModelRunner:
     def __init__(self, config, model_cfg: ModelConfig, *, is_draft: bool, device: torch.device, tp_rank: int = 0,
                  tp_size: int = 1, tp_group=None, model_path: str | None = None, weights_seed: int = 0,
                  gen_device: str | None = None, num_kvcache_blocks: int = -1, memory_utilization: float | None = None,
-                 max_decode_tokens: int | None = None, weight_source=None):
+                 max_decode_tokens: int | None = None, weight_source=None, force_collectives: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("ssd_amd.ModelRunner needs an MI355X; there is no CPU fallback on the product path")
         load_library()  # fail loudly before allocating anything
@@ -48,7 +48,7 @@ class ModelRunner:
                                 block_size=self.block_size, max_model_len=config.max_model_len, device=device,
                                 tp_rank=tp_rank, tp_size=tp_size, tp_group=tp_group,
                                 max_logit_rows=max(self.max_decode_tokens, self.max_bs),
-                                max_split_tokens=max(256, self.max_decode_tokens))
+                                max_split_tokens=max(256, self.max_decode_tokens), force_collectives=force_collectives)
         if weight_source is not None:
             src = weight_source
         elif model_path is not None and W.has_safetensors(model_path):

@@ -53,9 +53,12 @@ def make_cos_sin(head_dim: int, max_pos: int, theta: float, device) -> torch.Ten
 class HipDecoder:
     def __init__(self, cfg: ModelConfig, *, max_tokens: int, max_seqs: int, max_blocks: int, block_size: int,
                  max_model_len: int, device: torch.device, tp_rank: int = 0, tp_size: int = 1, tp_group=None,
-                 max_logit_rows: int | None = None, max_split_tokens: int = 256):
+                 max_logit_rows: int | None = None, max_split_tokens: int = 256, force_collectives: bool = False):
         self.cfg, self.device = cfg, device
         self.tp_rank, self.tp_size, self.tp_group = tp_rank, tp_size, tp_group
+        # force_collectives: issue the RCCL calls even at tp_size == 1 (lets a single-GPU box exercise the
+        # collective + hipGraph-capture path that the multi-GPU runs depend on)
+        self.use_coll = tp_size > 1 or (force_collectives and tp_group is not None)
         assert cfg.num_heads % tp_size == 0 and cfg.num_kv_heads % tp_size == 0
         assert cfg.intermediate_size % (tp_size * 32) == 0 and cfg.vocab_size % (tp_size * 16) == 0
         self.nh, self.nkv = cfg.num_heads // tp_size, cfg.num_kv_heads // tp_size
@@ -142,7 +145,7 @@ class HipDecoder:
             H.gemm(xf[x_off:], w, yf[y_off:], m, N, K, ldy, epi, bias)
 
     def _allreduce(self, t):
-        if self.tp_size > 1:
+        if self.use_coll:
             dist.all_reduce(t, group=self.tp_group)
 
     def _splits(self, T: int, meta: AttnMeta) -> int:
@@ -198,7 +201,7 @@ class HipDecoder:
 
     def argmax(self, n: int, out: torch.Tensor, out2: torch.Tensor | None = None) -> None:
         """Greedy tokens of logits[:n] over the FULL vocabulary (identical on every TP rank)."""
-        if self.tp_size == 1:
+        if not self.use_coll:
             H.argmax_rows(self.logits, self.V, n, self.V, out, out2)
             return
         H.argmax_rows_val(self.logits, self.V, n, self.V, self.tp_rank * self.V, self.am_idx_l, self.am_val_l)
@@ -210,7 +213,7 @@ class HipDecoder:
 
     def full_logits(self, n: int) -> torch.Tensor:
         """[n, V_full] logits on every rank (only needed off the greedy path)."""
-        if self.tp_size == 1:
+        if not self.use_coll:
             return self.logits[:n]
         parts = [torch.empty(n, self.V, dtype=BF16, device=self.device) for _ in range(self.tp_size)]
         dist.all_gather(parts, self.logits[:n].contiguous(), group=self.tp_group)

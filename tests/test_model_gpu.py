@@ -219,3 +219,34 @@ def test_engine_sync_sd(gpu, golden, tag):
         # draft == target: everything is accepted while no near-tie has been hit
         lens = metrics["accepted_suffix_lens_with_recovery"]
         assert lens[0] == K + 1
+
+
+def test_collective_path_single_rank_nccl(gpu, golden):
+    """The RCCL calls of the tensor-parallel forward (all-reduce after o_proj / down_proj / embedding, the
+    vocab-parallel argmax all-gather) captured inside the hipGraphs and replayed, on a 1-rank NCCL group:
+    the same code the N-GPU runs execute, minus the peers.  Tokens must equal the collective-free run."""
+    import os
+    import torch.distributed as dist
+    from ssd_amd.engine.llm_engine import LLMEngine, hip_runner_factory
+    from ssd_amd.sampling_params import SamplingParams
+    from ssd_amd.utils.topology import Topology
+    g = golden("engine_golden")
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    grp = dist.new_group([0])
+    topo = Topology(0, 1, gpu, "target", 0, 1, grp)
+    K = int(g["sd_K"])
+    wt, wd = weights(g, "t."), weights(g, "d.")
+
+    def factory(config, model_cfg, *, is_draft, topo, **kw):
+        return hip_runner_factory(config, model_cfg, is_draft=is_draft, topo=topo, force_collectives=not is_draft,
+                                  weight_source=iter((wd if is_draft else wt).items()), **kw)
+
+    eng = LLMEngine("tiny", hf_config=mk_cfg(g, "llama", "t_"), draft="d", draft_hf_config=mk_cfg(g, "llama", "d_"),
+                    speculate=True, speculate_k=K, runner_factory=factory, topology=topo, **COMMON)
+    assert eng.model_runner.model.use_coll
+    want = g["sd_diff_tokens"].tolist()
+    out, _ = eng.generate([g["prompt"].tolist()], SamplingParams(temperature=0, max_new_tokens=len(want), ignore_eos=True), use_tqdm=False)
+    assert out[0]["token_ids"] == want
