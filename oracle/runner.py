@@ -134,6 +134,80 @@ class OracleRunner:
         lg = self._verify_logits(seqs, speculations).view(B, K + 1, -1)
         return O.verify_suffixes(lg, speculations)
 
+    # ---- draft-server operations of asynchronous speculation (explicit arrays, no Sequence objects) ----
+    def zeros_tokens(self, B, K):
+        return torch.zeros(B, K, dtype=torch.int64)
+
+    def _bt_from(self, tables):
+        return torch.tensor(tables, dtype=torch.int32)
+
+    @torch.inference_mode()
+    def draft_prefill(self, token_lists, tables):
+        """draft_async_prefill (draft_runner.py:51-101): trunk KV for the whole prompt."""
+        ids, pos, slots, cu = [], [], [], [0]
+        for toks, tb in zip(token_lists, tables):
+            n = len(toks)
+            ids.extend(toks)
+            pos.extend(range(n))
+            slots.extend(self._slot(tb, p) for p in range(n))
+            cu.append(cu[-1] + n)
+        cu_t = torch.tensor(cu, dtype=torch.int32)
+        self.model.forward(torch.tensor(ids), torch.tensor(pos), Ctx("prefill", slot_mapping=torch.tensor(slots, dtype=torch.int32),
+                                                                    cu_q=cu_t, cu_k=cu_t))
+
+    @torch.inference_mode()
+    def draft_jit(self, rec, num_tokens, tables):
+        """jit_speculate (draft_runner.py:124-184): K single-token decodes from the recovery token at P = n - 1."""
+        B, K = len(rec), self.K
+        bt = self._bt_from(tables)
+        out = torch.zeros(B, K, dtype=torch.int64)
+        cur = list(rec)
+        for i in range(K):
+            pos = [n - 1 + i for n in num_tokens]
+            slots = [self._slot(tb, p) for tb, p in zip(tables, pos)]
+            lg = self._decode(cur, pos, slots, [p + 1 for p in pos], bt)
+            cur = O.argmax_rows(lg).tolist()
+            out[:, i] = torch.tensor(cur)
+        return out
+
+    @torch.inference_mode()
+    def draft_glue_fork(self, glue_ids, num_tokens, tables, fan_lists):
+        """Glue decode + fork (draft_runner.py:620-700; async_spec_helpers.py:26-78)."""
+        B, K = glue_ids.shape[0], self.K
+        pos, slots = [], []
+        for n, tb in zip(num_tokens, tables):
+            for p in range(n - 1, n + K):
+                pos.append(p)
+                slots.append(self._slot(tb, p))
+        ctx = Ctx("verify", slot_mapping=torch.tensor(slots, dtype=torch.int32),
+                  context_lens=torch.tensor([n + K for n in num_tokens], dtype=torch.int32), block_tables=self._bt_from(tables),
+                  cu_q=torch.arange(B + 1, dtype=torch.int32) * (K + 1))
+        lg = self._logits(self.model.forward(glue_ids.reshape(-1), torch.tensor(pos), ctx)).view(B, K + 1, -1)
+        return O.fork_topf(lg, glue_ids, fan_lists)
+
+    @torch.inference_mode()
+    def draft_tree(self, forks, num_tokens, tables, jlists):
+        """K tree-decode steps (draft_runner.py:713-812): returns tokens [B*MQ, K]."""
+        B, K = forks.shape[0], self.K
+        mq = forks.shape[1]
+        bt = self._bt_from(tables)
+        toks = forks.reshape(-1)
+        out = torch.zeros(B * mq, K, dtype=torch.int64)
+        for d in range(K):
+            pos, slots, ctx_lens = [], [], []
+            for b, (n, tb) in enumerate(zip(num_tokens, tables)):
+                Pb = n - 1
+                for i in range(mq):
+                    pos.append(Pb + jlists[b][i] + 1 + d)
+                    slots.append(self._slot(tb, Pb + K + 1 + d * mq + i))
+                ctx_lens.append(Pb + K + 1 + (d + 1) * mq)
+            ctx = Ctx("tree", slot_mapping=torch.tensor(slots, dtype=torch.int32), context_lens=torch.tensor(ctx_lens, dtype=torch.int32),
+                      block_tables=bt, tree_step=d, tree_K=K, tree_jidx=jlists)
+            lg = self._logits(self.model.forward(toks, torch.tensor(pos), ctx))
+            toks = O.argmax_rows(lg)
+            out[:, d] = toks
+        return out
+
     def exit(self, *a):
         pass
 

@@ -1,0 +1,113 @@
+"""The draft side of asynchronous speculation ("SSD"): a server that answers speculation requests from a
+speculation cache and, while the target verifies, pre-computes the next cache by decoding a TREE of
+continuations -- one branch per (accepted-length j, recovery token) outcome the verifier could return.
+
+Restates the reference DraftRunner loop (ssd/engine/draft_runner.py:186-286 hit_cache_and_respond, :288-378
+_service_spec_request, :530-711 _build_tree_batch, :713-812 _decode_tree, :814-830 _populate_tree_cache,
+:859-928 draft_loop) over a backend-neutral draft runner (HIP on the GPU, the oracle in CPU tests) with four
+operations: draft_prefill, draft_jit, draft_glue_fork, draft_tree.
+
+Geometry, with P = num_tokens - 1 = position of the recovery token:
+  JIT (cache miss)  K single-token decodes at positions P .. P+K-1
+  glue              K+1 tokens [rec, x_1..x_K] at P .. P+K (re-deposits the trunk KV, yields the fork logits)
+  fork              top-F_j tokens per glue position j, excluding x_{j+1} for j < K  -> MQ_LEN branches
+  tree step d       branch i feeds its token at RoPE position P+j_i+1+d, KV slot P+K+1+d*MQ_LEN+i
+  cache             key (seq_id, j_i, fork token_i) -> K continuation tokens of branch i
+The speculation cache lives on the draft device (tokens) with its keys mirrored on the host; a request is
+answered before the glue/tree work of the new round starts, so that work overlaps the target's verify.
+"""
+from __future__ import annotations
+
+import torch
+
+from ssd_amd.engine import async_proto as P
+
+
+def branch_positions(fan_out: list[int]) -> list[int]:
+    """Glue position j of each branch: [0]*F_0 + [1]*F_1 + ... (repeat_interleave, draft_runner.py:118-119)."""
+    return [j for j, f in enumerate(fan_out) for _ in range(f)]
+
+
+class DraftServer:
+    def __init__(self, config, runner, transport):
+        self.config, self.runner, self.tx = config, runner, transport
+        self.K = config.speculate_k
+        self.mq = config.MQ_LEN
+        self.max_blocks = config.max_blocks
+        self.j_hit = branch_positions(config.fan_out_list)
+        self.j_miss = branch_positions(config.fan_out_list_miss)
+        self.cache_keys: dict[tuple[int, int, int], int] = {}
+        self.cache_tokens = None            # device tensor [N, K]
+        self.pending_forks = None           # device tensor [B, MQ] of the round whose keys are not mirrored yet
+        self.pending_meta = None
+        self.stats = {"requests": 0, "hits": 0, "rounds": 0}
+
+    # ---- one command ----
+    def handle_one(self) -> bool:
+        cmd, B, n, flags = self.tx.recv_ints(P.HEADER_LEN)
+        if cmd == P.CMD_EXIT:
+            return False
+        if cmd == P.CMD_HELLO:
+            self.tx.send_ints([self.runner.num_kvcache_blocks])
+            return True
+        payload = self.tx.recv_ints(n) if n else []
+        if cmd == P.CMD_PREFILL:
+            toks, tables = P.unpack_prefill(payload, B, self.max_blocks)
+            self.runner.draft_prefill(toks, tables)
+            return True
+        if cmd == P.CMD_SPECULATE:
+            self._speculate(B, payload, flags)
+            return True
+        raise RuntimeError(f"draft server: unknown command {cmd}")
+
+    def serve_forever(self) -> None:
+        while self.handle_one():
+            pass
+
+    # ---- speculation round ----
+    def _mirror_keys(self) -> None:
+        """Bring the fork tokens of the finished round to the host and index the cache by them."""
+        if self.pending_forks is None:
+            return
+        forks = self.pending_forks.tolist()         # the only device read of a round, after all its work is queued
+        seq_ids, jlists = self.pending_meta
+        self.cache_keys = {}
+        for b, row in enumerate(forks):
+            for i, tok in enumerate(row):
+                self.cache_keys.setdefault((seq_ids[b], jlists[b][i], tok), b * self.mq + i)
+        self.pending_forks = None
+
+    def _speculate(self, B: int, payload: list[int], flags: int) -> None:
+        K = self.K
+        keys, num_tokens, tables, temps = P.unpack_speculate(payload, B, self.max_blocks)
+        if any(t != 0 for t in temps) or (flags & P.FLAG_WANT_LOGITS):
+            raise NotImplementedError("stochastic drafting (temperature > 0) is a 'next' row (SURVEY.md 8f)")
+        self._mirror_keys()
+        idx = [self.cache_keys.get(tuple(k), -1) for k in keys]
+        hits = [1 if i >= 0 else 0 for i in idx]
+        self.stats["requests"] += B
+        self.stats["hits"] += sum(hits)
+        rec = [k[2] for k in keys]
+        jit = self.config.jit_speculate
+        serve_from_cache = (any(hits) and not jit) or (all(hits) and jit)
+        if serve_from_cache:
+            rows = torch.tensor([i if i >= 0 else 0 for i in idx], dtype=torch.int64, device=self.cache_tokens.device)
+            tokens = self.cache_tokens[rows]
+            if not all(hits):       # "fast" backup: miss rows carry filler tokens (the reference uses random ones)
+                tokens = tokens * torch.tensor(hits, dtype=torch.int64, device=tokens.device).unsqueeze(1)
+        elif jit:
+            tokens = self.runner.draft_jit(rec, num_tokens, tables)         # [B, K] on the draft device
+        else:
+            tokens = self.runner.zeros_tokens(B, K)
+        resp = torch.cat([torch.tensor(hits, dtype=torch.int64, device=tokens.device), tokens.reshape(-1)])
+        self.tx.send_tensor(resp)
+        # ---- from here on the target is verifying; pre-compute the next round's cache ----
+        fan = [self.config.fan_out_list if h else self.config.fan_out_list_miss for h in hits]
+        jl = [self.j_hit if h else self.j_miss for h in hits]
+        glue_ids = torch.cat([torch.tensor(rec, dtype=torch.int64, device=tokens.device).unsqueeze(1), tokens], dim=1)
+        forks = self.runner.draft_glue_fork(glue_ids, num_tokens, tables, fan)          # [B, MQ]
+        self.cache_tokens = self.runner.draft_tree(forks, num_tokens, tables, jl)        # [B*MQ, K]
+        self.pending_forks = forks
+        self.pending_meta = ([k[0] for k in keys], jl)
+        self.cache_keys = {}
+        self.stats["rounds"] += 1

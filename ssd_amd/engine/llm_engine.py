@@ -61,22 +61,31 @@ def hip_runner_factory(config, model_cfg, *, is_draft: bool, topo, **kw):
 
 
 class LLMEngine:
-    def __init__(self, model: str, runner_factory=None, topology=None, **kwargs):
+    def __init__(self, model: str, runner_factory=None, topology=None, inprocess_draft: bool = False, **kwargs):
+        """inprocess_draft: run the async draft server inside this process over a loopback transport (same
+        protocol and server code, no second GPU) -- for single-GPU functional tests, not a deployment mode."""
         names = {f.name for f in fields(Config)}
         config = Config(model, **{k: v for k, v in kwargs.items() if k in names})
         self.config = config
         Sequence.block_size = config.kvcache_block_size
-        assert config.num_gpus > 1 or not config.draft_async, "draft_async requires at least 2 gpus"
+        assert config.num_gpus > 1 or not config.draft_async or inprocess_draft, "draft_async requires at least 2 gpus"
 
-        from ssd_amd.utils.topology import resolve_topology
+        from ssd_amd.utils.topology import resolve_topology, Topology
+        if topology is None and inprocess_draft:
+            dev = torch.device("cuda", 0) if torch.cuda.is_available() else torch.device("cpu")
+            topology = Topology(0, 1, dev, "target", 0, 1)
         self.topo = topology or resolve_topology(config)
         factory = runner_factory or hip_runner_factory
 
         self.draft_runner = None
         self.async_link = None
+        self.draft_server = None
         if self.topo.role == "draft":               # dedicated draft GPU of async speculation
             from ssd_amd.engine.draft_runner import DraftServer
-            self.draft_server = DraftServer(config, self.topo, factory)
+            from ssd_amd.engine.async_proto import DistTransport
+            runner = factory(config, config.draft_hf_config, is_draft=True, topo=self.topo, memory_utilization=0.8,
+                             num_kvcache_blocks=config.num_draft_kvcache_blocks)
+            self.draft_server = DraftServer(config, runner, DistTransport(self.topo.async_group, 0, self.topo.device))
             return
         self.model_runner = factory(config, config.hf_config, is_draft=False, topo=self.topo,
                                     num_kvcache_blocks=config.num_kvcache_blocks)
@@ -88,7 +97,20 @@ class LLMEngine:
             draft_blocks = self.draft_runner.num_kvcache_blocks
         elif config.speculate:
             from ssd_amd.engine.speculator_async import AsyncLink
-            self.async_link = AsyncLink(config, self.topo)
+            transport = None
+            if inprocess_draft:
+                from ssd_amd.engine.draft_runner import DraftServer
+                from ssd_amd.engine.async_proto import LoopbackTransport
+                transport, server_end = LoopbackTransport.pair()
+                self.draft_runner = factory(config, config.draft_hf_config, is_draft=True, topo=self.topo,
+                                            memory_utilization=0.75, num_kvcache_blocks=config.num_draft_kvcache_blocks)
+                self.draft_server = DraftServer(config, self.draft_runner, server_end)
+
+                def pump(server=self.draft_server, end=server_end):
+                    while end.from_peer:
+                        server.handle_one()
+                transport.pump = pump
+            self.async_link = AsyncLink(config, self.topo, transport=transport)
             draft_blocks = self.async_link.draft_num_blocks()
 
         self.tokenizer = _load_tokenizer(config.tokenizer_path or config.model)
@@ -147,7 +169,19 @@ class LLMEngine:
             if METRICS["cache_hits"]:
                 print(f"[metrics] Avg Cache Hits: {sum(METRICS['cache_hits']) / len(METRICS['cache_hits']):.2f}", flush=True)
 
+    @property
+    def is_draft_process(self) -> bool:
+        return self.topo.role == "draft"
+
+    def serve(self) -> None:
+        """Draft rank: answer speculation requests until the target sends EXIT."""
+        assert self.is_draft_process
+        self.draft_server.serve_forever()
+
     def generate(self, prompts, sampling_params, use_tqdm: bool = True, stream_callback=None):
+        if self.is_draft_process:           # SPMD launch: the draft rank serves instead of generating
+            self.serve()
+            return [], METRICS
         for k, v in _fresh_metrics().items():
             METRICS[k] = v
         if not isinstance(sampling_params, list):

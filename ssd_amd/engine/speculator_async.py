@@ -1,0 +1,101 @@
+"""Target side of asynchronous speculation: ask the draft GPU for K tokens per sequence, keyed by the outcome of
+the previous verification (reference SpeculatorAsync, ssd/engine/speculator_async.py:12-187).
+
+Per step the head rank sends ONE request (header + fused int64 payload) and receives ONE reply
+(cache_hits | tokens); the other tensor-parallel ranks get the reply by an RCCL broadcast inside the TP group
+(the reference ships the updated sequences to its TP workers through shared-memory pickles instead,
+model_runner.py:404-428).  The request is built from Python ints in one go -- the reference writes every field
+with its own device scalar store (speculator_async.py:136-146).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from ssd_amd.engine import async_proto as P
+from ssd_amd.engine.speculate_types import SpeculateResult, SpeculatorBase, VerifyResult
+
+
+class AsyncLink:
+    """The head rank's connection to the draft server (+ fan-out of replies to the other TP ranks)."""
+
+    def __init__(self, config, topo, transport=None):
+        self.config, self.topo = config, topo
+        self.K = config.speculate_k
+        self.max_blocks = config.max_blocks
+        self.is_head = topo.tp_rank == 0
+        if transport is None and self.is_head:
+            transport = P.DistTransport(topo.async_group, topo.draft_rank, topo.device)
+        self.tx = transport
+        self._closed = False
+
+    def _bcast_ints(self, values: list[int] | None, n: int) -> list[int]:
+        if self.topo.tp_size == 1:
+            return values
+        t = torch.tensor(values if self.is_head else [0] * n, dtype=torch.int64, device=self.topo.device)
+        dist.broadcast(t, src=dist.get_global_rank(self.topo.tp_group, 0), group=self.topo.tp_group)
+        return t.tolist()
+
+    def draft_num_blocks(self) -> int:
+        v = None
+        if self.is_head:
+            self.tx.send_ints([P.CMD_HELLO, 0, 0, 0])
+            v = self.tx.recv_ints(1)
+        return self._bcast_ints(v, 1)[0]
+
+    def prefill(self, token_lists, block_tables) -> None:
+        if not self.is_head:
+            return
+        payload = P.pack_prefill(token_lists, block_tables, self.max_blocks)
+        self.tx.send_ints([P.CMD_PREFILL, len(token_lists), len(payload), 0])
+        self.tx.send_ints(payload)
+
+    def speculate(self, keys, num_tokens, block_tables, temps):
+        B, K = len(keys), self.K
+        resp = None
+        if self.is_head:
+            payload = P.pack_speculate(keys, num_tokens, block_tables, temps, self.max_blocks)
+            self.tx.send_ints([P.CMD_SPECULATE, B, len(payload), 0])
+            self.tx.send_ints(payload)
+            resp = self.tx.recv_tensor((B + B * K,), torch.int64).tolist()
+        resp = self._bcast_ints(resp, B + B * K)
+        hits = resp[:B]
+        tokens = [resp[B + b * K: B + (b + 1) * K] for b in range(B)]
+        return hits, tokens
+
+    def shutdown(self) -> None:
+        if self.is_head and not self._closed:
+            self._closed = True
+            self.tx.send_ints([P.CMD_EXIT, 0, 0, 0])
+
+
+class SpeculatorAsync(SpeculatorBase):
+    def __init__(self, lookahead: int, device, link: AsyncLink, config):
+        super().__init__(lookahead, device)
+        self.link, self.config = link, config
+
+    def prefill(self, seqs, verify_result: VerifyResult) -> SpeculateResult:
+        self.link.prefill([list(s.token_ids) for s in seqs], [list(s.draft_block_table) for s in seqs])
+        return SpeculateResult([], [])
+
+    def speculate(self, seqs, verify_result: VerifyResult) -> SpeculateResult:
+        K = self.lookahead
+        keys, nts, tables, temps = [], [], [], []
+        for seq in seqs:
+            assert seq.recovery_token_id is not None
+            seq.append_token(seq.recovery_token_id)
+            # (seq_id, accepted draft tokens of the previous step, recovery token); -2 on the first step => miss
+            keys.append((seq.seq_id, seq.last_spec_step_accepted_len - 1, seq.recovery_token_id))
+            nts.append(seq.num_tokens)
+            tables.append(list(seq.draft_block_table))
+            temps.append(seq.draft_temperature if seq.draft_temperature is not None else seq.temperature)
+        hits, tokens = self.link.speculate(keys, nts, tables, temps)
+        rows = []
+        for seq, toks in zip(seqs, tokens):
+            rows.append([seq.recovery_token_id] + toks)
+            seq.token_ids.extend(toks)
+            seq.num_tokens = len(seq.token_ids)
+            seq.last_token = seq.token_ids[-1]
+            seq.num_draft_cached_tokens += K + 1
+        speculations = torch.tensor(rows, dtype=torch.int64).to(self.device)
+        return SpeculateResult(speculations, None, hits)

@@ -1,0 +1,101 @@
+"""Asynchronous speculation (SSD) on CPU: the real engine + draft server + wire protocol, with oracle runners.
+(1) in-process loopback, (2) two gloo processes (target rank 0, draft rank 1) as deployed.
+Exactness: the async stream equals plain autoregressive decoding; with draft == target every verification is
+fully accepted and every request after the first is a speculation-cache hit."""
+import os
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def cfgs():
+    from ssd_amd.model_config import ModelConfig
+    t = ModelConfig("llama", 64, 2, 4, 2, 32, 128, 256, 1e-5, 5e5, 1024, False)
+    d = ModelConfig("llama", 64, 1, 2, 1, 32, 128, 256, 1e-5, 5e5, 1024, True)
+    return t, d
+
+
+KW = dict(max_model_len=512, max_num_batched_tokens=512, kvcache_block_size=32, num_kvcache_blocks=48, weights_std=0.1)
+PROMPTS = [[(5 * i + 3 * j) % 256 for j in range(6 + 2 * i)] for i in range(2)]
+
+
+def run(mode, same=False, bs=1, jit=True, fan=None, fan_miss=None, **extra):
+    from oracle.runner import oracle_runner_factory
+    from ssd_amd.engine.llm_engine import LLMEngine
+    from ssd_amd.sampling_params import SamplingParams
+    t, d = cfgs()
+    kw = dict(KW, max_num_seqs=bs)
+    kw.update(extra)
+    if mode != "ar":
+        kw.update(draft="d", draft_hf_config=t if same else d, speculate=True, speculate_k=3)
+        if same:
+            kw.update(draft_weights_seed=0)     # identical synthetic weights
+    if mode == "async":
+        kw.update(draft_async=True, async_fan_out=2, jit_speculate=jit, fan_out_list=fan, fan_out_list_miss=fan_miss)
+    eng = LLMEngine("t", hf_config=t, runner_factory=oracle_runner_factory(), inprocess_draft=(mode == "async" and "num_gpus" not in extra), **kw)
+    out, m = eng.generate(PROMPTS[:max(1, bs)], SamplingParams(temperature=0, max_new_tokens=14, ignore_eos=True), use_tqdm=False)
+    stats = eng.draft_server.stats if eng.draft_server is not None else None
+    eng.exit()
+    return [o["token_ids"] for o in out], m, stats
+
+
+def test_async_loopback_is_exact():
+    ar, _, _ = run("ar")
+    sync, _, _ = run("sync")
+    asy, m, stats = run("async")
+    assert ar == sync == asy
+    assert stats["requests"] == len(m["accepted_suffix_lens_with_recovery"])
+    assert len(m["cache_hits"]) == stats["rounds"]
+
+
+def test_async_same_model_hits_and_accepts_everything():
+    ar, _, _ = run("ar")
+    asy, m, stats = run("async", same=True)
+    assert asy == ar
+    lens = m["accepted_suffix_lens_with_recovery"]
+    assert all(n == 4 for n in lens[:-1])                 # K+1 tokens per step (last one may be clipped by max_new_tokens)
+    assert m["cache_hits"][0] == 0.0 and all(h == 1.0 for h in m["cache_hits"][1:])
+    assert stats["hits"] == stats["requests"] - 1
+
+
+def test_async_batch_nonuniform_fanout_and_fast_backup():
+    ar, _, _ = run("ar", bs=2)
+    a1, _, _ = run("async", bs=2, fan=[1, 2, 2, 3], fan_miss=[3, 2, 2, 1])
+    a2, _, _ = run("async", bs=2, jit=False)                # "fast" backup: misses carry filler tokens, still exact
+    a3, _, s3 = run("async", bs=2, same=True, fan=[1, 1, 1, 5], fan_miss=[2, 2, 2, 2])
+    assert ar == a1 == a2 == a3
+    assert s3["hits"] > 0
+
+
+def _worker(rank, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    toks, m, _ = run("async", same=True, num_gpus=2)
+    q.put((rank, toks, m["cache_hits"]))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_async_two_processes_gloo():
+    ar, _, _ = run("ar")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 90)
+    ps = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r, toks, hits = q.get(timeout=300)
+        got[r] = (toks, hits)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][0] == ar                 # target rank produced the exact stream
+    assert got[1][0] == []                 # draft rank only served
+    assert all(h == 1.0 for h in got[0][1][1:])
