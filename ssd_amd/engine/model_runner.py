@@ -327,5 +327,177 @@ class ModelRunner:
         recovery = [r[1] for r in rows]
         return suffixes, recovery
 
+    # ---------------------------------------------------------------------------------------------
+    # draft-server operations of asynchronous speculation (explicit arrays instead of Sequence objects;
+    # reference ssd/engine/draft_runner.py:51-101,124-184,380-450,620-812)
+    # ---------------------------------------------------------------------------------------------
+    def zeros_tokens(self, B: int, K: int) -> torch.Tensor:
+        return torch.zeros(B, K, dtype=torch.int64, device=self.device)
+
+    def _upload_tables(self, tables) -> None:
+        self._upload(self.d_bt, [list(t) + [-1] * (self.max_blocks - len(t)) for t in tables], torch.int32)
+
+    @torch.inference_mode()
+    def draft_prefill(self, token_lists, tables) -> None:
+        ids, pos, slots, ctx, cu, gather = [], [], [], [], [0], []
+        max_q = 0
+        for toks, tb in zip(token_lists, tables):
+            n = len(toks)
+            ids.extend(toks)
+            pos.extend(range(n))
+            slots.extend(self._slot(tb, p) for p in range(n))
+            ctx.append(n)
+            cu.append(cu[-1] + n)
+            gather.append(cu[-1] - 1)
+            max_q = max(max_q, n)
+        B, T = len(token_lists), len(ids)
+        assert T <= self.d_ids.numel()
+        self._upload(self.d_ids, ids, torch.int64)
+        self._upload(self.d_pos, pos, torch.int64)
+        self._upload(self.d_slots, slots, torch.int32)
+        self._upload(self.d_ctx, ctx, torch.int32)
+        self._upload(self.d_cu_q, cu, torch.int32)
+        self._upload_tables(tables)
+        self.model.forward(self.d_ids, self.d_pos, T, self._meta("prefill", B, max_q))
+
+    @torch.inference_mode()
+    def draft_jit(self, rec, num_tokens, tables) -> torch.Tensor:
+        """K chained single-token decodes from the recovery token at P = n - 1 (no host sync)."""
+        B, K = len(rec), self.K
+        key = ("decode_chain", B)
+
+        def stage():
+            pos = [n - 1 for n in num_tokens]
+            self._upload(self.d_ids, list(rec), torch.int64)
+            self._upload(self.d_pos, pos, torch.int64)
+            self._upload(self.d_slots, [self._slot(tb, p) for tb, p in zip(tables, pos)], torch.int32)
+            self._upload(self.d_ctx, list(num_tokens), torch.int32)
+            self._upload_tables(tables)
+            self.d_step.zero_()
+
+        stage()
+        first = 0
+        if self._launch(key, lambda: self._body_decode(B, True)) == "captured":
+            stage()
+        else:
+            first = 1
+        g = self.graphs.get(key)
+        for _ in range(first, K):
+            if g is not None:
+                g.replay()
+            else:
+                self._body_decode(B, True)
+        return self.d_spec[:B, 1:].clone()
+
+    def _body_glue_fork(self, B: int) -> None:
+        K, T = self.K, B * (self.K + 1)
+        self.model.forward(self.d_ids, self.d_pos, T, self._meta("verify", B))
+        self.model.compute_logits(T)
+        H.fork_topf(self.model.logits, self.model.V, self.model.V, self.d_ids, self.d_fan, self.d_fan_off, B, K, self.mq, self.d_forks)
+
+    def _ensure_tree_buffers(self) -> None:
+        if hasattr(self, "d_forks"):
+            return
+        B, K = self.max_bs, self.K
+        self.mq = self.config.MQ_LEN
+        T = B * self.mq
+        dev = dict(device=self.device)
+        self.d_fan = torch.zeros(B, K + 1, dtype=torch.int32, **dev)
+        self.d_fan_off = torch.zeros(B, K + 1, dtype=torch.int32, **dev)
+        self.d_forks = torch.zeros(B, self.mq, dtype=torch.int64, **dev)
+        self.d_jidx = torch.zeros(B, self.mq, dtype=torch.int32, **dev)
+        self.d_tree_pos = torch.zeros(K, T, dtype=torch.int64, **dev)
+        self.d_tree_slots = torch.zeros(K, T, dtype=torch.int32, **dev)
+        self.d_tree_ctx = torch.zeros(K, B, dtype=torch.int32, **dev)
+        self.d_tree_tokens = torch.zeros(T, K, dtype=torch.int64, **dev)
+        assert self.model.tp_size == 1, "the draft model is not tensor-parallel"
+
+    @torch.inference_mode()
+    def draft_glue_fork(self, glue_ids: torch.Tensor, num_tokens, tables, fan_lists) -> torch.Tensor:
+        """Glue decode over [rec, x_1..x_K] at P..P+K, then top-F fork per position on the device."""
+        self._ensure_tree_buffers()
+        B, K = glue_ids.shape[0], self.K
+        key = ("glue_fork", B)
+
+        def stage():
+            pos, slots = [], []
+            for n, tb in zip(num_tokens, tables):
+                for p in range(n - 1, n + K):
+                    pos.append(p)
+                    slots.append(self._slot(tb, p))
+            self.d_ids[:B * (K + 1)].copy_(glue_ids.reshape(-1))
+            self._upload(self.d_pos, pos, torch.int64)
+            self._upload(self.d_slots, slots, torch.int32)
+            self._upload(self.d_ctx, [n + K for n in num_tokens], torch.int32)
+            self._upload_tables(tables)
+            fl = [list(f) for f in fan_lists]
+            self._upload(self.d_fan, fl, torch.int32)
+            self._upload(self.d_fan_off, [[sum(f[:j]) for j in range(len(f))] for f in fl], torch.int32)
+
+        stage()
+        if self._launch(key, lambda: self._body_glue_fork(B)) == "captured":
+            stage()
+            self.graphs[key].replay()
+        return self.d_forks[:B].clone()
+
+    def _body_tree(self, B: int, d: int) -> None:
+        T = B * self.mq
+        meta = AttnMeta(H.MODE_TREE, B, self.mq, self.d_tree_slots[d], self.d_tree_ctx[d], self.d_bt, q_per_seq=self.mq,
+                        tree_K=self.K, tree_mq=self.mq, tree_step=d, tree_F=1, tree_jidx=self.d_jidx)
+        self.model.forward(self.d_ids, self.d_tree_pos[d], T, meta)
+        self.model.compute_logits(T)
+        self.model.argmax(T, self.d_next)
+        self.d_ids[:T].copy_(self.d_next[:T])
+        self.d_tree_tokens[:T, d].copy_(self.d_next[:T])
+
+    @torch.inference_mode()
+    def draft_tree(self, forks: torch.Tensor, num_tokens, tables, jlists) -> torch.Tensor:
+        """K tree-decode steps with the structural branch mask; greedy tokens are chained on the device.
+        Returns tokens [B*MQ, K]."""
+        self._ensure_tree_buffers()
+        B, K, mq = forks.shape[0], self.K, self.mq
+        T = B * mq
+
+        def stage():
+            pos = [[0] * T for _ in range(K)]
+            slots = [[0] * T for _ in range(K)]
+            ctx = [[0] * B for _ in range(K)]
+            for d in range(K):
+                for b, (n, tb) in enumerate(zip(num_tokens, tables)):
+                    Pb = n - 1
+                    for i in range(mq):
+                        pos[d][b * mq + i] = Pb + jlists[b][i] + 1 + d
+                        slots[d][b * mq + i] = self._slot(tb, Pb + K + 1 + d * mq + i)
+                    ctx[d][b] = Pb + K + 1 + (d + 1) * mq
+            # tables are [K][Tmax]-strided on the device: upload row by row into the leading T / B columns
+            for d in range(K):
+                self._stage_row(self.d_tree_pos, d, pos[d], torch.int64)
+                self._stage_row(self.d_tree_slots, d, slots[d], torch.int32)
+                self._stage_row(self.d_tree_ctx, d, ctx[d], torch.int32)
+            self._upload(self.d_jidx, [list(j) for j in jlists], torch.int32)
+            self._upload_tables(tables)
+            self.d_ids[:T].copy_(forks.reshape(-1))
+
+        stage()
+        for d in range(K):
+            key = ("tree", B, d)
+            if self._launch(key, lambda d=d: self._body_tree(B, d)) == "captured":
+                # the eager warm-up already advanced the chain by one step; restore this step's inputs and replay
+                if d == 0:
+                    self.d_ids[:T].copy_(forks.reshape(-1))
+                else:
+                    self.d_ids[:T].copy_(self.d_tree_tokens[:T, d - 1])
+                self.graphs[key].replay()
+        return self.d_tree_tokens[:T].clone()
+
+    def _stage_row(self, dst2d: torch.Tensor, row: int, values, dtype) -> None:
+        key = (id(dst2d), row)
+        stage = self._stage.get(key)
+        if stage is None:
+            stage = self._stage[key] = torch.zeros(dst2d.shape[1], dtype=dst2d.dtype).pin_memory()
+        n = len(values)
+        stage[:n] = torch.tensor(values, dtype=dtype)
+        dst2d[row, :n].copy_(stage[:n], non_blocking=True)
+
     def exit(self, *a):
         self.graphs.clear()

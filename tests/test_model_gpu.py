@@ -250,3 +250,32 @@ def test_collective_path_single_rank_nccl(gpu, golden):
     want = g["sd_diff_tokens"].tolist()
     out, _ = eng.generate([g["prompt"].tolist()], SamplingParams(temperature=0, max_new_tokens=len(want), ignore_eos=True), use_tqdm=False)
     assert out[0]["token_ids"] == want
+
+
+@pytest.mark.parametrize("tag", ["same", "diff"])
+def test_engine_async_ssd_loopback(gpu, golden, tag):
+    """Asynchronous speculation on one GPU: real draft server (speculation cache, glue + fork + tree decode on the
+    HIP kernels, hipGraph per tree step) behind the loopback transport.  SSD is exact, so the stream must equal
+    the reference-driven autoregressive trace; with draft == target every request after the first hits."""
+    from ssd_amd.engine.llm_engine import LLMEngine
+    from ssd_amd.sampling_params import SamplingParams
+    g = golden("engine_golden")
+    K = int(g["sd_K"])
+    wt = weights(g, "t.")
+    cfg_t = mk_cfg(g, "llama", "t_")
+    cfg_d, wd = (cfg_t, wt) if tag == "same" else (mk_cfg(g, "llama", "d_"), weights(g, "d."))
+    eng = LLMEngine("tiny", hf_config=cfg_t, draft="tiny-draft", draft_hf_config=cfg_d, speculate=True, speculate_k=K,
+                    draft_async=True, async_fan_out=2, jit_speculate=True, inprocess_draft=True,
+                    runner_factory=hip_factory(wt, wd), **COMMON)
+    want = g["ar_tokens"].tolist()
+    out, metrics = eng.generate([g["prompt"].tolist()], SamplingParams(temperature=0, max_new_tokens=len(want), ignore_eos=True),
+                                use_tqdm=False)
+    got = out[0]["token_ids"]
+    n = common_prefix(got, want)
+    margins = g["ar_margins"].tolist()
+    print(f"SSD[{tag}] identical tokens: {n} of {len(want)}; hits {metrics['cache_hits']}; lens {metrics['accepted_suffix_lens_with_recovery']}")
+    assert n == len(want) or margins[n] < 0.0625, f"diverged at token {n} (margin {margins[n]})"
+    assert n >= 8
+    if tag == "same":
+        assert metrics["cache_hits"][0] == 0.0 and metrics["cache_hits"][1] == 1.0
+        assert metrics["accepted_suffix_lens_with_recovery"][0] == K + 1
