@@ -7,7 +7,8 @@
 //                                    tensor, no plan(), graph-capturable.
 //   * varlen causal prefill         (reference ssd/layers/attention.py:90-93) -- reads the just-stored
 //                                    K/V through the page table, which also covers prefix-cache hits.
-// One wave per (16*RT query rows of one kv-head group, key split).  Query rows of a kv head are the
+// One wave per (16*RT query rows of one kv-head group, key range); a workgroup may hold up to 8 such waves that
+// split the key range and merge their partials through LDS (single launch, no workspace).  Query rows of a kv head are the
 // (token, q-head-in-group) pairs, token-major, so GQA shares every K/V byte across the group.
 // Math per 32-key tile (all MFMA 16x16x32 bf16, fp32 accumulate):
 //   S^T[key][row] = K . Q^T      (A = K rows straight from the paged cache, B = Q fragments in VGPRs)
@@ -42,19 +43,28 @@ __device__ __forceinline__ const bf16_t* kv_row(const bf16_t* base, const int32_
   return base + (((size_t)page * nkv + h) * bs + (key % bs)) * HD;
 }
 
+// LDS per wave: the V tile (32 keys x HD bf16) during the scan, then the wave's partial (O fp32 [RT*16][HD],
+// m/l [RT*16][2]) for the in-block merge.
 template <int HD, int RT>
-__global__ void __launch_bounds__(64) attn_kernel(const AttnParams p) {
-  __shared__ __attribute__((aligned(16))) bf16_t vlds[32 * HD];
+constexpr int attn_region_bytes() { return RT * 16 * HD * 4 + RT * 16 * 8; }
+
+template <int HD, int RT>
+__global__ void __launch_bounds__(512) attn_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int DS = HD / 32;  // k-steps of QK^T
   constexpr int DT = HD / 16;  // 16-wide output d tiles
-  const int lane = threadIdx.x, r16 = lane & 15, g4 = lane >> 4;
+  constexpr int REGION = attn_region_bytes<HD, RT>();
+  const int lane = threadIdx.x & 63, r16 = lane & 15, g4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int W = blockDim.x >> 6;
+  bf16_t* vlds = reinterpret_cast<bf16_t*>(smem + (size_t)wave * REGION);
   const int b = blockIdx.y / p.nkv, h = blockIdx.y % p.nkv;
   const int G = p.nh / p.nkv;
   const int q0 = p.cu_q ? p.cu_q[b] : b * p.q_per_seq;
   const int Tq = p.cu_q ? (p.cu_q[b + 1] - q0) : p.q_per_seq;
   const int rows = Tq * G;
   const int tile_base = blockIdx.x * RT;
-  if (tile_base * 16 >= rows) return;
+  if (tile_base * 16 >= rows) return;   // block-uniform
   const int ctx = p.context_lens[b];
   const int32_t* bt = p.block_tables + (size_t)b * p.max_blocks;
   const int z = blockIdx.z;
@@ -84,15 +94,17 @@ __global__ void __launch_bounds__(64) attn_kernel(const AttnParams p) {
     }
   }
 
-  // ---- key range of this split (derived on device so the grid is capture-static) ----
-  int chunk = (ctx + p.splits - 1) / p.splits;
-  chunk = ((chunk + 31) >> 5) << 5;
-  const int k_begin = z * chunk;
-  int k_end = min(ctx, k_begin + chunk);
+  // ---- key range of this (grid split z, wave) pair, derived on device so the launch is capture-static ----
+  int kmax = ctx;
   if (p.mode == 0) {  // rows of this tile never look past the last row's causal limit
     const int last_row = min(rows - 1, (tile_base + RT) * 16 - 1);
-    k_end = min(k_end, ctx - (Tq - 1 - last_row / G));
+    kmax = ctx - (Tq - 1 - last_row / G);
   }
+  const int parts = p.splits * W;
+  int chunk = (kmax + parts - 1) / parts;
+  chunk = ((chunk + 31) >> 5) << 5;
+  const int k_begin = (z * W + wave) * chunk;
+  const int k_end = min(kmax, k_begin + chunk);
 
   float m[RT], lsum[RT];
   f32x4_t o[RT][DT];
@@ -104,7 +116,7 @@ __global__ void __launch_bounds__(64) attn_kernel(const AttnParams p) {
   }
 
   for (int k0 = k_begin; k0 < k_end; k0 += 32) {
-    // -- stage the V tile [32 keys][HD] into LDS as DT sub-tiles of [32 keys][16 d] (tr-read image) --
+    // -- stage the V tile [32 keys][HD] into this wave's LDS region as DT sub-tiles of [32 keys][16 d] --
     constexpr int CH = HD / 8;  // 16-byte chunks per key row
 #pragma unroll
     for (int it = 0; it < (32 * CH) / 64; ++it) {
@@ -177,7 +189,10 @@ __global__ void __launch_bounds__(64) attn_kernel(const AttnParams p) {
       for (int i = 0; i < 8; ++i) pr[i] = pv[i] - round_bf(pv[i]);
       pl[rt] = u32x4_t{pack_bf2(pr[0], pr[1]), pack_bf2(pr[2], pr[3]), pack_bf2(pr[4], pr[5]), pack_bf2(pr[6], pr[7])};
     }
-    __syncthreads();
+    // the V tile is private to this wave: LDS ops of one wave execute in order, so a wave-level fence (no
+    // s_barrier -- waves have different trip counts) is all the write->transpose-read hand-off needs
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
     // -- O^T += V^T . P^T ; V^T fragments by transpose-read from the staged tile --
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
@@ -206,36 +221,89 @@ __global__ void __launch_bounds__(64) attn_kernel(const AttnParams p) {
         if (p.p_split) o[rt][dt] = mfma16(vf, pl[rt], o[rt][dt]);
       }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
   }
 
   // ---- epilogue ----
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
-    float l = lsum[rt];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    if (!rvalid[rt]) continue;
-    const size_t row = (size_t)(q0 + tl[rt]) * p.nh + hq[rt];
-    if (p.splits == 1) {
-      const float inv = l > 0.f ? 1.0f / l : 0.f;
+    lsum[rt] += __shfl_xor(lsum[rt], 16, 64);
+    lsum[rt] += __shfl_xor(lsum[rt], 32, 64);
+  }
+  if (W == 1) {
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        const int d = dt * 16 + g4 * 4;
-        const u32x2_t v = {pack_bf2(o[rt][dt][0] * inv, o[rt][dt][1] * inv), pack_bf2(o[rt][dt][2] * inv, o[rt][dt][3] * inv)};
-        if (p.out_rows) *reinterpret_cast<u32x2_t*>(p.out_rows + row * HD + d) = v;
-        if (p.out_frag) {
-          const int kcol = hq[rt] * HD + d;
-          p.out_frag[frag_chunk(q0 + tl[rt], kcol >> 3, (p.nh * HD) >> 5) * 2 + ((kcol >> 2) & 1)] = v;
+    for (int rt = 0; rt < RT; ++rt) {
+      if (!rvalid[rt]) continue;
+      const float l = lsum[rt];
+      const size_t row = (size_t)(q0 + tl[rt]) * p.nh + hq[rt];
+      if (p.splits == 1) {
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int d = dt * 16 + g4 * 4;
+          const u32x2_t v = {pack_bf2(o[rt][dt][0] * inv, o[rt][dt][1] * inv), pack_bf2(o[rt][dt][2] * inv, o[rt][dt][3] * inv)};
+          if (p.out_rows) *reinterpret_cast<u32x2_t*>(p.out_rows + row * HD + d) = v;
+          if (p.out_frag) {
+            const int kcol = hq[rt] * HD + d;
+            p.out_frag[frag_chunk(q0 + tl[rt], kcol >> 3, (p.nh * HD) >> 5) * 2 + ((kcol >> 2) & 1)] = v;
+          }
+        }
+      } else {
+        float* wo = p.ws_o + (row * p.splits + z) * HD;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4_t*>(wo + dt * 16 + g4 * 4) = o[rt][dt];
+        if (g4 == 0) {
+          p.ws_ml[(row * p.splits + z) * 2] = m[rt];
+          p.ws_ml[(row * p.splits + z) * 2 + 1] = l;
         }
       }
-    } else {
-      float* wo = p.ws_o + (row * p.splits + z) * HD;
+    }
+    return;
+  }
+  // ---- W > 1: merge the waves' partials through LDS in wave order (deterministic), one launch, no workspace ----
+  {
+    float* po = reinterpret_cast<float*>(smem + (size_t)wave * REGION);
+    float* pml = po + RT * 16 * HD;
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4_t*>(wo + dt * 16 + g4 * 4) = o[rt][dt];
-      if (g4 == 0) {
-        p.ws_ml[(row * p.splits + z) * 2] = m[rt];
-        p.ws_ml[(row * p.splits + z) * 2 + 1] = l;
+    for (int rt = 0; rt < RT; ++rt) {
+      const int lr = rt * 16 + r16;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4_t*>(po + lr * HD + dt * 16 + g4 * 4) = o[rt][dt];
+      if (g4 == 0) { pml[lr * 2] = m[rt]; pml[lr * 2 + 1] = lsum[rt]; }
+    }
+  }
+  __syncthreads();
+  for (int item = threadIdx.x; item < RT * 16 * (HD / 4); item += blockDim.x) {
+    const int lr = item / (HD / 4), d = (item % (HD / 4)) * 4;
+    const int rho = tile_base * 16 + lr;
+    if (rho >= rows) continue;
+    float M = -INFINITY;
+    for (int w = 0; w < W; ++w) M = fmaxf(M, reinterpret_cast<const float*>(smem + (size_t)w * REGION)[RT * 16 * HD + lr * 2]);
+    const float Ms = (M == -INFINITY) ? 0.f : M;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    float L = 0.f;
+    for (int w = 0; w < W; ++w) {
+      const float* base = reinterpret_cast<const float*>(smem + (size_t)w * REGION);
+      const float wt = exp2f(base[RT * 16 * HD + lr * 2] - Ms);
+      L += wt * base[RT * 16 * HD + lr * 2 + 1];
+      acc += wt * *reinterpret_cast<const f32x4_t*>(base + lr * HD + d);
+    }
+    const int tok = q0 + rho / G, head = h * G + rho % G;
+    const size_t row = (size_t)tok * p.nh + head;
+    if (p.splits == 1) {
+      const float inv = L > 0.f ? 1.0f / L : 0.f;
+      const u32x2_t v = {pack_bf2(acc[0] * inv, acc[1] * inv), pack_bf2(acc[2] * inv, acc[3] * inv)};
+      if (p.out_rows) *reinterpret_cast<u32x2_t*>(p.out_rows + row * HD + d) = v;
+      if (p.out_frag) {
+        const int kcol = head * HD + d;
+        p.out_frag[frag_chunk(tok, kcol >> 3, (p.nh * HD) >> 5) * 2 + ((kcol >> 2) & 1)] = v;
+      }
+    } else {
+      *reinterpret_cast<f32x4_t*>(p.ws_o + (row * p.splits + z) * HD + d) = acc;
+      if (d == 0) {
+        p.ws_ml[(row * p.splits + z) * 2] = M;
+        p.ws_ml[(row * p.splits + z) * 2 + 1] = L;
       }
     }
   }
@@ -267,15 +335,25 @@ __global__ void attn_combine_kernel(const float* __restrict__ ws_o, const float*
   }
 }
 
+template <int HD, int RT>
+static int attn_launch_rt(const AttnParams& p, dim3 grid, int waves, hipStream_t st) {
+  const int lds = waves * attn_region_bytes<HD, RT>();
+  auto kern = attn_kernel<HD, RT>;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    return SSD_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, grid, dim3(64 * waves), lds, st, p);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
 template <int HD>
-static int attn_launch(const AttnParams& p, int B, int T, int max_q, hipStream_t st) {
+static int attn_launch(const AttnParams& p, int B, int T, int max_q, int waves, hipStream_t st) {
   const int G = p.nh / p.nkv;
   const int row_tiles = (max_q * G + 15) / 16;
   const int rt = row_tiles >= 2 ? 2 : 1;
   dim3 grid((row_tiles + rt - 1) / rt, B * p.nkv, p.splits);
-  if (rt == 2) hipLaunchKernelGGL((attn_kernel<HD, 2>), grid, dim3(64), 0, st, p);
-  else hipLaunchKernelGGL((attn_kernel<HD, 1>), grid, dim3(64), 0, st, p);
-  if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
+  const int rc = rt == 2 ? attn_launch_rt<HD, 2>(p, grid, waves, st) : attn_launch_rt<HD, 1>(p, grid, waves, st);
+  if (rc != SSD_OK) return rc;
   if (p.splits > 1) {
     hipLaunchKernelGGL((attn_combine_kernel<HD>), dim3(T * p.nh), dim3(HD / 4), 0, st, p.ws_o, p.ws_ml, p.splits, p.nh,
                        p.out_rows, p.out_frag);
@@ -305,5 +383,9 @@ extern "C" int ssd_attn_paged(const void* q_rows, const void* k_cache, const voi
   p.splits = splits; p.use_tr = (flags & 1) ? 0 : 1; p.p_split = (flags & 2) ? 0 : 1;
   p.scale_log2e = scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;
-  return hd == 128 ? attn_launch<128>(p, B, T, max_q, st) : attn_launch<64>(p, B, T, max_q, st);
+  // flags bits 8..11: waves per workgroup that split the key range and merge in LDS (default 1; 1..8)
+  int waves = (flags >> 8) & 0xf;
+  if (waves < 1) waves = 1;
+  if (waves > 8) waves = 8;
+  return hd == 128 ? attn_launch<128>(p, B, T, max_q, waves, st) : attn_launch<64>(p, B, T, max_q, waves, st);
 }

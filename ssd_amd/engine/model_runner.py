@@ -91,6 +91,7 @@ class ModelRunner:
         self.h_packed = torch.zeros(B, self.K + 3, dtype=torch.int64).pin_memory()
         self.h_next = torch.zeros(max(self.max_decode_tokens, B), dtype=torch.int64).pin_memory()
         self._stage: dict = {}
+        self._ctx_hint = 4096
         self.graphs: dict = {}
         self.graph_pool = None
         self.stream = torch.cuda.Stream(device)
@@ -142,6 +143,7 @@ class ModelRunner:
             max_q = max(max_q, n - cached)
         T = len(ids)
         assert T <= self.d_ids.numel(), "prefill exceeds max_num_batched_tokens"
+        self._note_ctx(max(ctx))
         self._upload(self.d_ids, ids, torch.int64)
         self._upload(self.d_pos, pos, torch.int64)
         self._upload(self.d_slots, slots, torch.int32)
@@ -161,6 +163,7 @@ class ModelRunner:
             pos.append(len(s) - 1)
             ctx.append(len(s))
             slots.append(self._slot(self._table(s), len(s) - 1))
+        self._note_ctx(max(ctx) + self.K + 1)
         self._upload(self.d_ids, ids, torch.int64)
         self._upload(self.d_pos, pos, torch.int64)
         self._upload(self.d_slots, slots, torch.int32)
@@ -182,6 +185,7 @@ class ModelRunner:
             pos.extend(range(pos0, pos0 + K + 1))
             slots.extend(self._slot(table, p) for p in range(pos0, pos0 + K + 1))
             ctx.append(len(s))
+        self._note_ctx(max(ctx))
         if ids_from_seq:
             self._upload(self.d_ids, ids, torch.int64)
         self._upload(self.d_pos, pos, torch.int64)
@@ -194,13 +198,19 @@ class ModelRunner:
     # graph bodies (all inputs already in the static buffers)
     # ---------------------------------------------------------------------------------------------
     def _meta(self, kind: str, B: int, max_q: int = 1, tree_step: int = 0) -> AttnMeta:
+        hint = self._ctx_hint
         if kind == "prefill":
-            return AttnMeta(H.MODE_CAUSAL, B, max_q, self.d_slots, self.d_ctx, self.d_bt, cu_q=self.d_cu_q)
+            return AttnMeta(H.MODE_CAUSAL, B, max_q, self.d_slots, self.d_ctx, self.d_bt, cu_q=self.d_cu_q, ctx_hint=hint)
         if kind == "decode":
-            return AttnMeta(H.MODE_CAUSAL, B, 1, self.d_slots, self.d_ctx, self.d_bt, q_per_seq=1)
+            return AttnMeta(H.MODE_CAUSAL, B, 1, self.d_slots, self.d_ctx, self.d_bt, q_per_seq=1, ctx_hint=hint)
         if kind == "verify":
-            return AttnMeta(H.MODE_CAUSAL, B, self.K + 1, self.d_slots, self.d_ctx, self.d_bt, q_per_seq=self.K + 1)
+            return AttnMeta(H.MODE_CAUSAL, B, self.K + 1, self.d_slots, self.d_ctx, self.d_bt, q_per_seq=self.K + 1, ctx_hint=hint)
         raise ValueError(kind)
+
+    def _note_ctx(self, max_ctx: int) -> None:
+        """Host-side bound on the context lengths of the batch being staged (+ this step's lookahead); the graphs
+        are keyed by its power-of-two bucket because the attention decomposition is fixed at capture."""
+        self._ctx_hint = HipDecoder.ctx_bucket(max_ctx)
 
     def _body_decode(self, B: int, chain: bool) -> None:
         self.model.forward(self.d_ids, self.d_pos, B, self._meta("decode", B))
@@ -224,6 +234,7 @@ class ModelRunner:
         if self.config.enforce_eager:
             body()
             return
+        key = (*key, self._ctx_hint)
         g = self.graphs.get(key)
         if g is None:
             body()                                   # eager warm-up on the current stream
@@ -262,12 +273,12 @@ class ModelRunner:
             T = self._prepare_verify(seqs, ids_from_seq=True)
             if self._launch(("verify_logits", B), lambda: self._body_verify(B, False)) == "captured":
                 self._prepare_verify(seqs, ids_from_seq=True)
-                self.graphs[("verify_logits", B)].replay()
+                self.graphs[("verify_logits", B, self._ctx_hint)].replay()
             return self.model.full_logits(T)
         self._prepare_decode(seqs)
         if self._launch(("decode", B), lambda: self._body_decode(B, False)) == "captured":
             self._prepare_decode(seqs)
-            self.graphs[("decode", B)].replay()
+            self.graphs[("decode", B, self._ctx_hint)].replay()
         toks = self._read_tokens(B)
         return (toks, self.model.full_logits(B)) if draft_return_logits else toks
 
@@ -296,7 +307,7 @@ class ModelRunner:
             stage()                      # the warm-up + capture runs disturbed the chained state
         else:
             first = 1
-        g = self.graphs.get(key)
+        g = self.graphs.get((*key, self._ctx_hint))
         for _ in range(first, K + 1):
             if g is not None:
                 g.replay()
@@ -319,7 +330,7 @@ class ModelRunner:
         stage()
         if self._launch(key, lambda: self._body_verify(B, True)) == "captured":
             stage()
-            self.graphs[key].replay()
+            self.graphs[(*key, self._ctx_hint)].replay()
         self.h_packed[:B].copy_(self.d_packed[:B], non_blocking=True)
         torch.cuda.current_stream().synchronize()
         rows = self.h_packed[:B].tolist()
@@ -331,6 +342,9 @@ class ModelRunner:
     # draft-server operations of asynchronous speculation (explicit arrays instead of Sequence objects;
     # reference ssd/engine/draft_runner.py:51-101,124-184,380-450,620-812)
     # ---------------------------------------------------------------------------------------------
+    def _async_lookahead(self) -> int:
+        return self.K + 1 + self.K * self.config.MQ_LEN
+
     def zeros_tokens(self, B: int, K: int) -> torch.Tensor:
         return torch.zeros(B, K, dtype=torch.int64, device=self.device)
 
@@ -352,6 +366,7 @@ class ModelRunner:
             max_q = max(max_q, n)
         B, T = len(token_lists), len(ids)
         assert T <= self.d_ids.numel()
+        self._note_ctx(max(ctx))
         self._upload(self.d_ids, ids, torch.int64)
         self._upload(self.d_pos, pos, torch.int64)
         self._upload(self.d_slots, slots, torch.int32)
@@ -365,6 +380,7 @@ class ModelRunner:
         """K chained single-token decodes from the recovery token at P = n - 1 (no host sync)."""
         B, K = len(rec), self.K
         key = ("decode_chain", B)
+        self._note_ctx(max(num_tokens) + self._async_lookahead())
 
         def stage():
             pos = [n - 1 for n in num_tokens]
@@ -381,7 +397,7 @@ class ModelRunner:
             stage()
         else:
             first = 1
-        g = self.graphs.get(key)
+        g = self.graphs.get((*key, self._ctx_hint))
         for _ in range(first, K):
             if g is not None:
                 g.replay()
@@ -418,6 +434,7 @@ class ModelRunner:
         self._ensure_tree_buffers()
         B, K = glue_ids.shape[0], self.K
         key = ("glue_fork", B)
+        self._note_ctx(max(num_tokens) + self._async_lookahead())
 
         def stage():
             pos, slots = [], []
@@ -437,13 +454,14 @@ class ModelRunner:
         stage()
         if self._launch(key, lambda: self._body_glue_fork(B)) == "captured":
             stage()
-            self.graphs[key].replay()
+            self.graphs[(*key, self._ctx_hint)].replay()
         return self.d_forks[:B].clone()
 
     def _body_tree(self, B: int, d: int) -> None:
         T = B * self.mq
         meta = AttnMeta(H.MODE_TREE, B, self.mq, self.d_tree_slots[d], self.d_tree_ctx[d], self.d_bt, q_per_seq=self.mq,
-                        tree_K=self.K, tree_mq=self.mq, tree_step=d, tree_F=1, tree_jidx=self.d_jidx)
+                        tree_K=self.K, tree_mq=self.mq, tree_step=d, tree_F=1, tree_jidx=self.d_jidx,
+                        ctx_hint=self._ctx_hint)
         self.model.forward(self.d_ids, self.d_tree_pos[d], T, meta)
         self.model.compute_logits(T)
         self.model.argmax(T, self.d_next)
@@ -457,6 +475,7 @@ class ModelRunner:
         self._ensure_tree_buffers()
         B, K, mq = forks.shape[0], self.K, self.mq
         T = B * mq
+        self._note_ctx(max(num_tokens) + self._async_lookahead())
 
         def stage():
             pos = [[0] * T for _ in range(K)]
@@ -487,7 +506,7 @@ class ModelRunner:
                     self.d_ids[:T].copy_(forks.reshape(-1))
                 else:
                     self.d_ids[:T].copy_(self.d_tree_tokens[:T, d - 1])
-                self.graphs[key].replay()
+                self.graphs[(*key, self._ctx_hint)].replay()
         return self.d_tree_tokens[:T].clone()
 
     def _stage_row(self, dst2d: torch.Tensor, row: int, values, dtype) -> None:

@@ -70,7 +70,8 @@ def rope_store_kv(qkv_rows, positions, cos_sin, slot_mapping, q_out, k_cache, v_
 
 def attn_paged(q_rows, k_cache, v_cache, block_tables, max_blocks, context_lens, B, T, max_q, nh, nkv, hd, block_size,
                scale, cu_q=None, q_per_seq=0, mode=MODE_CAUSAL, tree_K=0, tree_mq=0, tree_step=0, tree_F=1, tree_jidx=None,
-               splits=1, flags=0, ws_o=None, ws_ml=None, out_rows=None, out_frag=None):
+               splits=1, flags=0, ws_o=None, ws_ml=None, out_rows=None, out_frag=None, waves=1):
+    flags = (flags & 0xff) | ((waves & 0xf) << 8)
     _check(load_library().ssd_attn_paged(_p(q_rows), _p(k_cache), _p(v_cache), _p(block_tables), max_blocks,
                                          _p(context_lens), _p(cu_q), q_per_seq, B, T, max_q, nh, nkv, hd, block_size,
                                          scale, mode, tree_K, tree_mq, tree_step, tree_F, _p(tree_jidx), splits, flags,

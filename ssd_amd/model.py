@@ -39,6 +39,7 @@ class AttnMeta:
     tree_step: int = 0
     tree_F: int = 1
     tree_jidx: torch.Tensor | None = None
+    ctx_hint: int = 0             # host-side upper bound of the context lengths (0 = unknown -> max_model_len)
 
 
 def make_cos_sin(head_dim: int, max_pos: int, theta: float, device) -> torch.Tensor:
@@ -71,6 +72,7 @@ class HipDecoder:
         self.max_tokens = max_tokens
         self.max_logit_rows = max_logit_rows or max_tokens
         self.max_split_tokens = max_split_tokens
+        self.max_model_len = max_model_len
         self.w: dict[str, torch.Tensor] = {}
         self.kv_cache: torch.Tensor | None = None
         self.cos_sin = make_cos_sin(self.hd, max_model_len, cfg.rope_theta, device)
@@ -148,14 +150,26 @@ class HipDecoder:
         if self.use_coll:
             dist.all_reduce(t, group=self.tp_group)
 
-    def _splits(self, T: int, meta: AttnMeta) -> int:
+    @staticmethod
+    def ctx_bucket(ctx: int) -> int:
+        """Power-of-two context bucket (>= 4096): the attention decomposition is static per hipGraph."""
+        b = 4096
+        while b < ctx:
+            b *= 2
+        return b
+
+    def _attn_cfg(self, T: int, meta: AttnMeta) -> tuple[int, int]:
+        """(grid key-splits, waves per workgroup).  Up to 8 waves of one workgroup split the key range and merge
+        in LDS (one launch); grid splits + the merge kernel are added only when a wave would scan > 512 keys."""
         G = self.nh // self.nkv
         groups = (-(-(meta.max_q * G) // 16) + 1) // 2
         base = max(1, groups * meta.B * self.nkv)
-        s = max(1, min(self.max_splits, 256 // base))
-        if s > 1 and T > self.max_split_tokens:
-            s = 1
-        return s
+        waves = max(1, min(8, 512 // base))
+        ctx = self.ctx_bucket(meta.ctx_hint if meta.ctx_hint > 0 else self.max_model_len)
+        splits = max(1, min(self.max_splits, -(-ctx // (waves * 512))))
+        if base >= 256 or T > self.max_split_tokens:
+            splits = 1
+        return splits, waves
 
     def forward(self, input_ids: torch.Tensor, positions: torch.Tensor, T: int, meta: AttnMeta) -> None:
         """Runs all layers; leaves the final (pre-norm) hidden state in buf_h and the residual in buf_res."""
@@ -164,7 +178,7 @@ class HipDecoder:
         H.embedding(input_ids, w["model.embed_tokens.weight"], h, T, self.h,
                     vocab_start=self.tp_rank * self.V if self.tp_size > 1 else 0, vocab_count=self.V if self.tp_size > 1 else cfg.vocab_size)
         self._allreduce(h[:T])
-        splits = self._splits(T, meta)
+        splits, attn_waves = self._attn_cfg(T, meta)
         scale = self.hd ** -0.5
         for li in range(cfg.num_layers):
             p = f"model.layers.{li}."
@@ -181,7 +195,7 @@ class HipDecoder:
                          self.nh, self.nkv, self.hd, self.block_size, scale, cu_q=meta.cu_q, q_per_seq=meta.q_per_seq,
                          mode=meta.mode, tree_K=meta.tree_K, tree_mq=meta.tree_mq, tree_step=meta.tree_step,
                          tree_F=meta.tree_F, tree_jidx=meta.tree_jidx, splits=splits, ws_o=self.ws_o, ws_ml=self.ws_ml,
-                         out_frag=self.buf_af)
+                         out_frag=self.buf_af, waves=attn_waves)
             self._gemm(self.buf_af, self.qn, w[p + "self_attn.o_proj.weight"], self.h, h, T, self.h)
             self._allreduce(h[:T])
             H.rmsnorm(h, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps, T, self.h, res_in=res, res_out=res, out_frag=xf)

@@ -418,3 +418,32 @@ def test_draft_advance(H):
     assert d[3].cpu().tolist() == [int(bt[0, 1]) * bs + 0, int(bt[1, 1]) * bs + 1, int(bt[2, 2]) * bs + 9]
     assert d[6].cpu()[:, 2].tolist() == [11, 22, 33]
     assert d[7].cpu().item() == 2
+
+
+@pytest.mark.parametrize("waves", [2, 8])
+def test_attn_multiwave_inblock_merge(H, waves):
+    """Up to 8 waves of one workgroup split the key range and merge through LDS (single launch); also combined
+    with grid splits + the merge kernel."""
+    bs = 16
+    for nh, nkv, hd in [(32, 8, 128), (32, 8, 64), (8, 1, 128)]:
+        for (B, qps, ctx_lens, splits) in [(1, 1, [37], 1), (2, 7, [640, 77], 1), (1, 24, [1500], 2), (3, 1, [1, 64, 333], 3)]:
+            kc, vc, bt, mb = make_paged(B, ctx_lens, nkv, hd, bs, seed=B * 10 + qps)
+            torch.manual_seed(qps + waves)
+            q = torch.randn(B * qps, nh, hd).to(BF)
+            ctx = torch.tensor(ctx_lens, dtype=torch.int32)
+            cu = torch.arange(B + 1, dtype=torch.int32) * qps
+            ref = O.attn_paged(q, kc, vc, ctx, bt, hd ** -0.5, cu_q=cu).reshape(B * qps, nh * hd)
+            got = run_attn(H, q.view(B * qps, -1), kc, vc, bt, mb, ctx, nh, nkv, hd, bs, q_per_seq=qps, splits=splits, waves=waves)
+            assert_close_bf16(got, ref, what=f"attn waves{waves} B{B} q{qps} splits{splits}", **ATTN_TOL)
+    # tree mask through the multi-wave path
+    nh, nkv, hd, K, F = 32, 8, 64, 7, 3
+    MQ = F * (K + 1)
+    ctx_lens = [150 + K + 1 + 4 * MQ]
+    kc, vc, bt, mb = make_paged(1, ctx_lens, nkv, hd, bs, seed=5)
+    q = torch.randn(MQ, nh, hd).to(BF)
+    ctx = torch.tensor(ctx_lens, dtype=torch.int32)
+    jidx = [i // F for i in range(MQ)]
+    ref = O.attn_tree(q, kc, vc, ctx, bt, hd ** -0.5, 3, K, [jidx]).reshape(MQ, nh * hd)
+    got = run_attn(H, q.view(MQ, -1), kc, vc, bt, mb, ctx, nh, nkv, hd, bs, q_per_seq=MQ, splits=1, waves=waves,
+                   mode=H.MODE_TREE, tree_K=K, tree_mq=MQ, tree_step=3, tree_F=F)
+    assert_close_bf16(got, ref, what="tree multiwave", **ATTN_TOL)
