@@ -45,6 +45,10 @@ int ssd_abi_version(void);
  * 16-row groups alternate gate/up (MergedColumnParallelLinear, ssd/layers/linear.py:101-122). */
 int ssd_rows_to_frag(const void* src_rows, void* dst_frag, int R, int K, int mode, void* stream);
 int ssd_frag_to_rows(const void* src_frag, void* dst_rows, int R, int K, void* stream);
+/* QKV weights [q heads | k heads | v heads] (QKVParallelLinear, ssd/layers/linear.py:125-162) -> fragment-major with the
+ * "rotation-paired" row order: in every q/k head, 16-row group j = dims [8j..8j+7] ++ [hd/2+8j..hd/2+8j+7], so both members of
+ * a neox RoPE pair share an MFMA accumulator tile.  GEMMs on such weights emit q/k in that order (qkv_perm = 1 below). */
+int ssd_rows_to_frag_qkv(const void* src_rows, void* dst_frag, int nh, int nkv, int hd, int K, void* stream);
 
 /* VocabParallelEmbedding.forward -- ssd/layers/embed_head.py:49-57 (rows outside
  * [vocab_start, vocab_start+vocab_count) produce zeros, the TP-masked form). */
@@ -67,13 +71,25 @@ int ssd_gemm_wf(const void* x_frag, const void* w_frag, const void* bias, void* 
 int ssd_gemm_wf_cfg(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K, int ldy,
                     int epilogue, int nt, int waves, void* stream);
 
+/* Fused decode-layer GEMM for M <= 16 (csrc/gemm_fused.hip): [residual add + RMSNorm] -> F.linear ->
+ * [RoPE + paged KV store | SiLU*mul | rows] in ONE launch; replaces add_norm_forward (layernorm.py:76-88) + F.linear
+ * (linear.py:97-98) + RotaryEmbedding.forward (rotary_embedding.py:40-60) + store_kvcache (attention.py:10-41), or
+ * + SiluAndMul (activation.py:11-14).  x comes either fragment-major (x_frag) or as row-major h (+ res_in) normalised on
+ * the fly with norm_w / eps; then res_out (!= res_in) receives bf16(h + res_in).  epilogue: 0 rows, 1 SiLU*mul -> frag,
+ * 3 RoPE + KV store (weights from ssd_rows_to_frag_qkv; q_out rows [M][nh*hd], K/V into the paged cache at `slots`).
+ * nt / waves <= 0 pick the default decomposition. */
+int ssd_gemm_fused(const void* x_frag, const void* h_rows, const void* res_in, void* res_out, const void* norm_w, float eps,
+                   const void* w_frag, const void* bias, int M, int N, int K, int epilogue, void* y, int ldy,
+                   const int64_t* positions, const float* cos_sin, const int32_t* slots, void* q_out, void* k_cache,
+                   void* v_cache, int nh, int nkv, int hd, int block_size, int nt, int waves, void* stream);
+
 /* (RMSHeadNorm q/k, Qwen3: ssd/models/qwen3.py:96-104) + RotaryEmbedding.forward
  * (ssd/layers/rotary_embedding.py:40-60) + store_kvcache (ssd/layers/attention.py:10-41).
  * qkv_rows [T][(nh+2nkv)*hd]; cos_sin fp32 [max_pos][hd] (cos || sin); q_norm_w/k_norm_w bf16[hd] or NULL. */
 int ssd_rope_store_kv(const void* qkv_rows, const int64_t* positions, const float* cos_sin,
                       const int32_t* slot_mapping, void* q_out_rows, void* k_cache, void* v_cache,
                       const void* q_norm_w, const void* k_norm_w, float eps, int T, int nh, int nkv, int hd,
-                      int block_size, void* stream);
+                      int block_size, int qkv_perm, void* stream);
 
 /* Attention.forward, all branches -- ssd/layers/attention.py:73-134.
  *   mode 0: causal, bottom-right aligned over context_lens (prefill :90-93, verify/glue :105-111,

@@ -1,0 +1,391 @@
+// Fused decode-layer GEMMs for M <= 16 rows (single-token draft decode, K+1-token verify at TP = 1):
+//
+//   [residual add + RMSNorm]  ->  skinny GEMM  ->  [RoPE + paged KV store | SiLU*mul | rows]
+//
+// One launch replaces add_norm_forward + F.linear + rotary_emb + store_kvcache (reference
+// ssd/layers/layernorm.py:64-88, ssd/layers/linear.py:97-98, ssd/layers/rotary_embedding.py:40-60,
+// ssd/layers/attention.py:10-41) for the QKV projection, and add_norm_forward + F.linear + SiluAndMul
+// (ssd/layers/activation.py:11-14) for gate_up.  A decode layer becomes five launches
+// (norm+qkv+rope | attention | o | norm+gate_up+silu | down) instead of nine: at M = 1 the 1B draft is
+// launch-latency bound, so removing launches is worth more than any bandwidth tuning.
+//
+// Prologue (XNORM): every workgroup recomputes rs[m] = rsqrt(mean((h+res)^2) + eps) for its M rows from the
+// row-major bf16 h / res (<= 16 x K x 4 B, L2 resident) while its first weight tiles are in flight, then forms
+// the MFMA B operand on the fly: x^[m][k] = bf16((h+res) * rs[m] * w[k]) -- identical arithmetic and
+// rounding points to ssd_rmsnorm.  The new residual bf16(h+res) is written by the workgroups in disjoint
+// column slices into a SECOND buffer (res_out != res_in: other workgroups still read res_in).
+//
+// RoPE epilogue: the QKV weight rows were permuted at load (ssd_rows_to_frag mode 2) so that each 16-row
+// group of a q/k head holds dims [d0..d0+7] and [d0+hd/2..d0+hd/2+7]: the two halves of a rotation pair sit in
+// lanes l and l^32 of the accumulator and are exchanged with one shuffle.
+#include "common.h"
+#include <type_traits>
+
+enum { FEPI_ROWS = 0, FEPI_SILU_FRAG = 1, FEPI_QKV_ROPE = 3 };
+
+struct FusedParams {
+  const u32x4_t* Wf;
+  const u32x4_t* Xf;        // fragment-major x (when h == nullptr)
+  const bf16_t* h;          // row-major [M][K] (XNORM)
+  const bf16_t* res_in;     // row-major [M][K] or nullptr
+  bf16_t* res_out;          // row-major [M][K] or nullptr
+  const bf16_t* norm_w;     // [K]
+  const bf16_t* bias;       // [N] (in the shuffled row order) or nullptr
+  void* y;                  // FEPI_ROWS: bf16 rows [M][ldy]; FEPI_SILU_FRAG: frag [M][N/2]
+  const int64_t* positions; // rope
+  const float* cos_sin;
+  const int32_t* slots;
+  bf16_t* q_out;
+  bf16_t* k_cache;
+  bf16_t* v_cache;
+  float eps;
+  int M, N, K, ldy;
+  int nh, nkv, hd, bs;
+  int scratch_bytes;        // LDS bytes in front of the x^ image (split-K combine area, also the prologue scratch)
+};
+
+constexpr int FUSED_MAXC = 4;   // 8-element chunks of (h + res) a thread may hold in registers during the prologue
+
+template <int NT, int EPI, bool XNORM>
+__global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nw = blockDim.x >> 6;
+  const int M = p.M, K = p.K;
+  const int KT = K >> 5, K8 = K >> 3;
+  const int tile0 = blockIdx.x * NT;
+  const int kt0 = (int)(((long)KT * wave) / nw);
+  const int kt1 = (int)(((long)KT * (wave + 1)) / nw);
+  const int mcol = lane & 15, q4 = lane >> 4;
+  // LDS: [combine / prologue scratch: nw*NT KiB (>= M*K8*4 B)] [x^ image: M*K*2 B, chunk (k8, m) at (k8*M + m)*16 B]
+  u32x4_t* xlds = reinterpret_cast<u32x4_t*>(smem + p.scratch_bytes);
+
+  f32x4_t acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const u32x4_t* wp = p.Wf + ((size_t)tile0 * KT << 6) + lane;
+  const size_t wstride = (size_t)KT << 6;
+
+  constexpr int U = (NT <= 2) ? 4 : 2;
+  u32x4_t wa[2][U][NT];
+  u32x4_t xg[2][U];       // fragment-major x travels with the weights when there is no prologue
+  auto loadw = [&](int buf, int kt) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        wa[buf][u][nt] = __builtin_nontemporal_load(wp + nt * wstride + ((size_t)(kt + u) << 6));
+      if (!XNORM) xg[buf][u] = p.Xf[((size_t)(kt + u) << 6) + lane];
+    }
+  };
+  const int nmain = (kt1 - kt0) / U;
+  if (nmain > 0) loadw(0, kt0);   // the first weight tiles fly while the norm prologue runs
+
+  if (XNORM) {
+    // ---- prologue: x32 = h + res kept in registers; per-chunk sums of squares -> per-row rs (fixed order) ->
+    //      x^ = bf16(x32 * rs * w) into the LDS image; residual slice written to res_out ----
+    float* ssbuf = reinterpret_cast<float*>(smem);      // [M*K8]
+    float x32[FUSED_MAXC][8];
+    u32x4_t wv[FUSED_MAXC];
+    const int total = M * K8;
+    const bool cached = total <= FUSED_MAXC * (int)blockDim.x;     // block-uniform
+    if (!cached) {   // large M*K (or few waves): two passes over the L2-resident rows instead of registers
+      for (int c = threadIdx.x; c < total; c += blockDim.x) {
+        const int mm = c / K8, k8 = c % K8;
+        const u32x4_t hv = *reinterpret_cast<const u32x4_t*>(p.h + (size_t)mm * K + k8 * 8);
+        u32x4_t rv = {0u, 0u, 0u, 0u};
+        if (p.res_in) rv = *reinterpret_cast<const u32x4_t*>(p.res_in + (size_t)mm * K + k8 * 8);
+        float ss = 0.f;
+        u32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = bf2f(hv[j] & 0xffffu) + bf2f(rv[j] & 0xffffu);
+          const float hi = bf2f(hv[j] >> 16) + bf2f(rv[j] >> 16);
+          ss += lo * lo; ss += hi * hi;
+          o[j] = pack_bf2(lo, hi);
+        }
+        ssbuf[c] = ss;
+        if (p.res_out) {
+          const int cpb = (K8 + gridDim.x - 1) / gridDim.x;
+          if (k8 / cpb == (int)blockIdx.x) *reinterpret_cast<u32x4_t*>(p.res_out + (size_t)mm * K + k8 * 8) = o;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < FUSED_MAXC; ++i) {
+      const int c = threadIdx.x + i * blockDim.x;
+      if (cached && c < total) {
+        const int mm = c / K8, k8 = c % K8;
+        const u32x4_t hv = *reinterpret_cast<const u32x4_t*>(p.h + (size_t)mm * K + k8 * 8);
+        u32x4_t rv = {0u, 0u, 0u, 0u};
+        if (p.res_in) rv = *reinterpret_cast<const u32x4_t*>(p.res_in + (size_t)mm * K + k8 * 8);
+        wv[i] = *reinterpret_cast<const u32x4_t*>(p.norm_w + k8 * 8);
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = bf2f(hv[j] & 0xffffu) + bf2f(rv[j] & 0xffffu);
+          const float hi = bf2f(hv[j] >> 16) + bf2f(rv[j] >> 16);
+          x32[i][2 * j] = lo; x32[i][2 * j + 1] = hi;
+          ss += lo * lo; ss += hi * hi;
+        }
+        ssbuf[c] = ss;
+        // residual: workgroup b owns chunk columns [b*cpb, (b+1)*cpb)
+        if (p.res_out) {
+          const int cpb = (K8 + gridDim.x - 1) / gridDim.x;
+          if (k8 / cpb == (int)blockIdx.x) {
+            u32x4_t o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = pack_bf2(x32[i][2 * j], x32[i][2 * j + 1]);
+            *reinterpret_cast<u32x4_t*>(p.res_out + (size_t)mm * K + k8 * 8) = o;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    float* rsbuf = ssbuf + total;                        // [M], behind the chunk sums
+    for (int mm = wave; mm < M; mm += nw) {
+      float t = 0.f;
+      for (int c = lane; c < K8; c += 64) t += ssbuf[mm * K8 + c];
+      t = wave_sum(t);
+      if (lane == 0) rsbuf[mm] = 1.0f / sqrtf(t / (float)K + p.eps);
+    }
+    __syncthreads();
+    if (!cached) {
+      for (int c = threadIdx.x; c < total; c += blockDim.x) {
+        const int mm = c / K8, k8 = c % K8;
+        const float rs = rsbuf[mm];
+        const u32x4_t hv = *reinterpret_cast<const u32x4_t*>(p.h + (size_t)mm * K + k8 * 8);
+        u32x4_t rv = {0u, 0u, 0u, 0u};
+        if (p.res_in) rv = *reinterpret_cast<const u32x4_t*>(p.res_in + (size_t)mm * K + k8 * 8);
+        const u32x4_t nwv = *reinterpret_cast<const u32x4_t*>(p.norm_w + k8 * 8);
+        u32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = bf2f(hv[j] & 0xffffu) + bf2f(rv[j] & 0xffffu);
+          const float hi = bf2f(hv[j] >> 16) + bf2f(rv[j] >> 16);
+          o[j] = pack_bf2((lo * rs) * bf2f(nwv[j] & 0xffffu), (hi * rs) * bf2f(nwv[j] >> 16));
+        }
+        xlds[k8 * M + mm] = o;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < FUSED_MAXC; ++i) {
+      const int c = threadIdx.x + i * blockDim.x;
+      if (cached && c < total) {
+        const int mm = c / K8, k8 = c % K8;
+        const float rs = rsbuf[mm];
+        u32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          o[j] = pack_bf2((x32[i][2 * j] * rs) * bf2f(wv[i][j] & 0xffffu), (x32[i][2 * j + 1] * rs) * bf2f(wv[i][j] >> 16));
+        xlds[k8 * M + mm] = o;
+      }
+    }
+    __syncthreads();
+  }
+
+  auto xfrag = [&](int buf, int u, int kt) -> u32x4_t {
+    if (!XNORM) return xg[buf][u];
+    u32x4_t o = {0u, 0u, 0u, 0u};
+    if (mcol < M) o = xlds[(kt * 4 + q4) * M + mcol];
+    return o;
+  };
+
+  // ---- main loop: weights (and fragment-major x) double-buffered in registers ----
+  int kt = kt0;
+  auto stage = [&](auto curc, int it) {          // curc: compile-time buffer index (runtime-indexed register
+    constexpr int cur = decltype(curc)::value;   // arrays would go to scratch)
+    if (it + 1 < nmain) loadw(cur ^ 1, kt + U);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const u32x4_t xb = xfrag(cur, u, kt + u);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(wa[cur][u][nt], xb, acc[nt]);
+    }
+    kt += U;
+  };
+  for (int it = 0; it < nmain; it += 2) {
+    stage(std::integral_constant<int, 0>{}, it);
+    if (it + 1 < nmain) stage(std::integral_constant<int, 1>{}, it + 1);
+  }
+  for (; kt < kt1; ++kt) {
+    u32x4_t xb;
+    if (!XNORM) xb = p.Xf[((size_t)kt << 6) + lane];
+    else { xb = u32x4_t{0u, 0u, 0u, 0u}; if (mcol < M) xb = xlds[(kt * 4 + q4) * M + mcol]; }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      acc[nt] = mfma16(__builtin_nontemporal_load(wp + nt * wstride + ((size_t)kt << 6)), xb, acc[nt]);
+  }
+
+  // ---- split-K combine through LDS in wave order ----
+  f32x4_t* cred = reinterpret_cast<f32x4_t*>(smem);   // [nw][NT][64]
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) cred[(wave * NT + nt) * 64 + lane] = acc[nt];
+  __syncthreads();
+  const int nrow = q4 * 4;
+  const int m = mcol;
+
+  if (EPI == FEPI_SILU_FRAG) {
+    constexpr int PAIRS = NT / 2;
+    const int KT2 = (p.N >> 1) >> 5;
+    u32x2_t* out = reinterpret_cast<u32x2_t*>(p.y);
+    for (int pr = wave; pr < PAIRS; pr += nw) {
+      f32x4_t g = f32x4_t{0.f, 0.f, 0.f, 0.f}, u = g;
+      for (int w = 0; w < nw; ++w) {
+        g += cred[(w * NT + 2 * pr) * 64 + lane];
+        u += cred[(w * NT + 2 * pr + 1) * 64 + lane];
+      }
+      const int n = ((tile0 >> 1) + pr) * 16 + nrow;
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float gb = round_bf(g[r]), ub = round_bf(u[r]);
+        o[r] = (gb / (1.0f + __expf(-gb))) * ub;
+      }
+      if (m < M) {
+        const u32x2_t v = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+        out[frag_chunk(m, n >> 3, KT2) * 2 + ((n >> 2) & 1)] = v;
+      }
+    }
+  } else {
+    for (int nt = wave; nt < NT; nt += nw) {
+      f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int w = 0; w < nw; ++w) s += cred[(w * NT + nt) * 64 + lane];
+      const int grp = tile0 + nt;
+      if (p.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] += bf2f(p.bias[grp * 16 + nrow + r]);
+      }
+      if (EPI == FEPI_ROWS) {
+        if (m < M) {
+          const u32x2_t v = {pack_bf2(s[0], s[1]), pack_bf2(s[2], s[3])};
+          *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(p.y) + (size_t)m * p.ldy + grp * 16 + nrow) = v;
+        }
+      } else {  // FEPI_QKV_ROPE
+        const int gph = p.hd >> 4;                 // 16-row groups per head
+        const int qk_groups = (p.nh + p.nkv) * gph;
+        const int half = p.hd >> 1;
+        float x[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = round_bf(s[r]);   // the reference stores qkv as bf16 before RoPE
+        if (grp < qk_groups) {
+          const int head = grp / gph, j = grp % gph;
+          float other[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) other[r] = __shfl_xor(x[r], 32, 64);   // rotation partner: rows i <-> i + 8
+          if (m < M) {
+            const int hi = q4 >> 1;                       // 0: first half of the head dim (x1), 1: second half (x2)
+            const int d = j * 8 + (q4 & 1) * 4;           // dim within the half
+            const float* cs = p.cos_sin + (size_t)p.positions[m] * p.hd;
+            float yv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float co = cs[d + r], si = cs[half + d + r];
+              yv[r] = hi ? __fadd_rn(__fmul_rn(x[r], co), __fmul_rn(other[r], si))
+                         : __fsub_rn(__fmul_rn(x[r], co), __fmul_rn(other[r], si));
+            }
+            const u32x2_t v = {pack_bf2(yv[0], yv[1]), pack_bf2(yv[2], yv[3])};
+            const int dim = hi * half + d;
+            if (head < p.nh) {
+              *reinterpret_cast<u32x2_t*>(p.q_out + ((size_t)m * p.nh + head) * p.hd + dim) = v;
+            } else {
+              const int slot = p.slots[m];
+              if (slot >= 0) {
+                const size_t rowi = ((size_t)(slot / p.bs) * p.nkv + (head - p.nh)) * p.bs + (slot % p.bs);
+                *reinterpret_cast<u32x2_t*>(p.k_cache + rowi * p.hd + dim) = v;
+              }
+            }
+          }
+        } else if (m < M) {   // V: natural row order, straight to the paged cache
+          const int vg = grp - qk_groups;
+          const int kvh = vg / gph, dim = (vg % gph) * 16 + nrow;
+          const int slot = p.slots[m];
+          if (slot >= 0) {
+            const size_t rowi = ((size_t)(slot / p.bs) * p.nkv + kvh) * p.bs + (slot % p.bs);
+            const u32x2_t v = {pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3])};
+            *reinterpret_cast<u32x2_t*>(p.v_cache + rowi * p.hd + dim) = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int NT, int EPI, bool XNORM>
+static int launch_fused(const FusedParams& p, int waves, hipStream_t st) {
+  const int blocks = (p.N / 16) / NT;
+  size_t lds = (size_t)waves * NT * 64 * sizeof(f32x4_t);
+  FusedParams q = p;
+  if (XNORM) {
+    const size_t chunks = (size_t)p.M * (p.K / 8);
+    if (lds < chunks * 4 + 64) lds = (chunks * 4 + 64 + 15) & ~(size_t)15;    // chunk sums + rs live in the scratch area
+    q.scratch_bytes = (int)lds;
+    lds += chunks * 16;                                                       // x^ image
+    if (lds > 160 * 1024) return SSD_ERR_SHAPE;
+  } else {
+    q.scratch_bytes = (int)lds;
+  }
+  auto kern = gemm_fused_kernel<NT, EPI, XNORM>;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return SSD_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, st, q);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
+template <int EPI, bool XNORM>
+static int launch_fused_nt(const FusedParams& p, int nt, int waves, hipStream_t st) {
+  if (nt == 1) {
+    if constexpr (EPI == FEPI_SILU_FRAG) return SSD_ERR_ARG;
+    else return launch_fused<1, EPI, XNORM>(p, waves, st);
+  }
+  if (nt == 2) return launch_fused<2, EPI, XNORM>(p, waves, st);
+  if (nt == 4) return launch_fused<4, EPI, XNORM>(p, waves, st);
+  return SSD_ERR_ARG;
+}
+
+extern "C" int ssd_gemm_fused(const void* x_frag, const void* h_rows, const void* res_in, void* res_out,
+                              const void* norm_w, float eps, const void* w_frag, const void* bias, int M, int N, int K,
+                              int epilogue, void* y, int ldy, const int64_t* positions, const float* cos_sin,
+                              const int32_t* slots, void* q_out, void* k_cache, void* v_cache, int nh, int nkv, int hd,
+                              int block_size, int nt, int waves, void* stream) {
+  if (M <= 0 || M > 16 || (N & 15) || (K & 31) || N <= 0 || K <= 0) return SSD_ERR_SHAPE;
+  if ((h_rows == nullptr) == (x_frag == nullptr)) return SSD_ERR_ARG;     // exactly one x source
+  if (h_rows && !norm_w) return SSD_ERR_ARG;
+  if (res_out && res_out == res_in) return SSD_ERR_ARG;                   // in-place residual would race
+  const int groups = N / 16;
+  if (nt <= 0) {
+    nt = (epilogue == FEPI_SILU_FRAG) ? 2 : 1;
+    if (groups >= 2048 && groups % 2 == 0) nt = 2;
+  }
+  if (waves <= 0) {
+    waves = 16;
+    while (waves > 1 && (K / 32) / waves < 4) waves >>= 1;
+    if (groups / nt >= 1024 && waves > 8) waves = 8;
+  }
+  if (waves > 16 || groups % nt) return SSD_ERR_ARG;
+  if (epilogue == FEPI_SILU_FRAG && (nt & 1)) return SSD_ERR_ARG;
+  if (epilogue == FEPI_QKV_ROPE) {
+    if (!positions || !cos_sin || !slots || !q_out || !k_cache || !v_cache) return SSD_ERR_ARG;
+    if (hd != 64 && hd != 128 && hd != 256) return SSD_ERR_SHAPE;
+    if (N != (nh + 2 * nkv) * hd) return SSD_ERR_SHAPE;
+  }
+  FusedParams p;
+  p.Wf = (const u32x4_t*)w_frag; p.Xf = (const u32x4_t*)x_frag; p.h = (const bf16_t*)h_rows;
+  p.res_in = (const bf16_t*)res_in; p.res_out = (bf16_t*)res_out; p.norm_w = (const bf16_t*)norm_w;
+  p.bias = (const bf16_t*)bias; p.y = y; p.positions = positions; p.cos_sin = cos_sin; p.slots = slots;
+  p.q_out = (bf16_t*)q_out; p.k_cache = (bf16_t*)k_cache; p.v_cache = (bf16_t*)v_cache;
+  p.eps = eps; p.M = M; p.N = N; p.K = K; p.ldy = ldy; p.nh = nh; p.nkv = nkv; p.hd = hd; p.bs = block_size;
+  hipStream_t st = (hipStream_t)stream;
+  const bool xn = h_rows != nullptr;
+#define FUSED_DISPATCH(E)                                                                          \
+  return xn ? launch_fused_nt<E, true>(p, nt, waves, st) : launch_fused_nt<E, false>(p, nt, waves, st);
+  switch (epilogue) {
+    case FEPI_ROWS: FUSED_DISPATCH(FEPI_ROWS)
+    case FEPI_SILU_FRAG: FUSED_DISPATCH(FEPI_SILU_FRAG)
+    case FEPI_QKV_ROPE: FUSED_DISPATCH(FEPI_QKV_ROPE)
+    default: return SSD_ERR_ARG;
+  }
+#undef FUSED_DISPATCH
+}

@@ -13,7 +13,7 @@ __global__ void rope_store_kernel(const bf16_t* __restrict__ qkv, const int64_t*
                                   const float* __restrict__ cos_sin, const int32_t* __restrict__ slots,
                                   bf16_t* __restrict__ q_out, bf16_t* __restrict__ k_cache,
                                   bf16_t* __restrict__ v_cache, const bf16_t* __restrict__ qn_w,
-                                  const bf16_t* __restrict__ kn_w, float eps, int nh, int nkv, int hd, int bs) {
+                                  const bf16_t* __restrict__ kn_w, float eps, int nh, int nkv, int hd, int bs, int perm) {
   const int t = blockIdx.x;
   const int c16 = hd >> 4;                 // threads per rotated head (each owns 8+8 elements)
   const int rot_items = (nh + nkv) * c16;  // q and k heads
@@ -32,8 +32,10 @@ __global__ void rope_store_kernel(const bf16_t* __restrict__ qkv, const int64_t*
       const int head = it / c16, c = it % c16;
       const bool is_q = head < nh;
       const bf16_t* src = row + (size_t)head * hd;  // q heads then k heads are contiguous in qkv
-      const u32x4_t a = *reinterpret_cast<const u32x4_t*>(src + c * 8);
-      const u32x4_t b = *reinterpret_cast<const u32x4_t*>(src + half + c * 8);
+      // perm: the QKV GEMM wrote q/k heads in the rotation-paired order (layout.hip): chunk c of the first half
+      // and its partner chunk of the second half are adjacent
+      const u32x4_t a = *reinterpret_cast<const u32x4_t*>(src + (perm ? c * 16 : c * 8));
+      const u32x4_t b = *reinterpret_cast<const u32x4_t*>(src + (perm ? c * 16 + 8 : half + c * 8));
       float x1[8], x2[8];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -83,13 +85,13 @@ __global__ void rope_store_kernel(const bf16_t* __restrict__ qkv, const int64_t*
 extern "C" int ssd_rope_store_kv(const void* qkv_rows, const int64_t* positions, const float* cos_sin,
                                  const int32_t* slot_mapping, void* q_out_rows, void* k_cache, void* v_cache,
                                  const void* q_norm_w, const void* k_norm_w, float eps, int T, int nh, int nkv,
-                                 int hd, int block_size, void* stream) {
+                                 int hd, int block_size, int qkv_perm, void* stream) {
   if (T <= 0 || nh <= 0 || nkv <= 0 || (hd != 64 && hd != 128 && hd != 256) || block_size <= 0) return SSD_ERR_SHAPE;
   const int items = (nh + nkv) * (hd / 16) + nkv * (hd / 8);
   int threads = ((items + 63) / 64) * 64;
   if (threads > 512) threads = 512;
   hipLaunchKernelGGL(rope_store_kernel, dim3(T), dim3(threads), 0, (hipStream_t)stream, (const bf16_t*)qkv_rows,
                      positions, cos_sin, slot_mapping, (bf16_t*)q_out_rows, (bf16_t*)k_cache, (bf16_t*)v_cache,
-                     (const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w, eps, nh, nkv, hd, block_size);
+                     (const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w, eps, nh, nkv, hd, block_size, qkv_perm);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }

@@ -21,12 +21,16 @@ SIGNATURES = {
     "ssd_abi_version": [],
     "ssd_rows_to_frag": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "ssd_frag_to_rows": [c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "ssd_rows_to_frag_qkv": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "ssd_gemm_fused": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int,
+                       c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                       c_int, c_int, c_int, c_int, c_void_p],
     "ssd_embedding": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_long, c_void_p],
     "ssd_rmsnorm": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "ssd_gemm_wf": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "ssd_gemm_wf_cfg": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "ssd_rope_store_kv": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                          c_float, c_int, c_int, c_int, c_int, c_int, c_void_p],
+                          c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "ssd_attn_paged": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                        c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int,
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],

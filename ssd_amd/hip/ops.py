@@ -62,10 +62,27 @@ def gemm(x_frag, w_frag, y, M: int, N: int, K: int, ldy: int, epilogue: int = EP
 
 
 def rope_store_kv(qkv_rows, positions, cos_sin, slot_mapping, q_out, k_cache, v_cache, T, nh, nkv, hd, block_size,
-                  q_norm_w=None, k_norm_w=None, eps: float = 0.0):
+                  q_norm_w=None, k_norm_w=None, eps: float = 0.0, qkv_perm: int = 0):
     _check(load_library().ssd_rope_store_kv(_p(qkv_rows), _p(positions), _p(cos_sin), _p(slot_mapping), _p(q_out),
                                             _p(k_cache), _p(v_cache), _p(q_norm_w), _p(k_norm_w), eps, T, nh, nkv, hd,
-                                            block_size, _stream()), "ssd_rope_store_kv")
+                                            block_size, qkv_perm, _stream()), "ssd_rope_store_kv")
+
+
+def rows_to_frag_qkv(src, dst, nh: int, nkv: int, hd: int, K: int):
+    _check(load_library().ssd_rows_to_frag_qkv(_p(src), _p(dst), nh, nkv, hd, K, _stream()), "ssd_rows_to_frag_qkv")
+
+
+FEPI_ROWS, FEPI_SILU_FRAG, FEPI_QKV_ROPE = 0, 1, 3
+
+
+def gemm_fused(w_frag, M: int, N: int, K: int, epilogue: int, *, x_frag=None, h_rows=None, res_in=None, res_out=None,
+               norm_w=None, eps: float = 0.0, bias=None, y=None, ldy: int = 0, positions=None, cos_sin=None, slots=None,
+               q_out=None, k_cache=None, v_cache=None, nh: int = 0, nkv: int = 0, hd: int = 0, block_size: int = 0,
+               nt: int = 0, waves: int = 0):
+    _check(load_library().ssd_gemm_fused(_p(x_frag), _p(h_rows), _p(res_in), _p(res_out), _p(norm_w), eps, _p(w_frag),
+                                         _p(bias), M, N, K, epilogue, _p(y), ldy, _p(positions), _p(cos_sin), _p(slots),
+                                         _p(q_out), _p(k_cache), _p(v_cache), nh, nkv, hd, block_size, nt, waves,
+                                         _stream()), "ssd_gemm_fused")
 
 
 def attn_paged(q_rows, k_cache, v_cache, block_tables, max_blocks, context_lens, B, T, max_q, nh, nkv, hd, block_size,

@@ -83,6 +83,7 @@ class HipDecoder:
         T = max_tokens
         self.buf_h = z(T, self.h)
         self.buf_res = z(T, self.h)
+        self.buf_res2 = z(min(T, 16), self.h)      # second residual buffer of the fused decode path (ping-pong)
         self.buf_xf = z(H.frag_numel(T, self.h))
         self.buf_qkv = z(T, self.qkv_n)
         self.buf_q = z(T, self.qn)
@@ -106,7 +107,14 @@ class HipDecoder:
         layout (gate_up with gate/up row groups interleaved for the fused SiLU epilogue)."""
         for name, w in weight_iter:
             w = w.to(self.device).contiguous()
-            if w.dim() == 2 and not name.endswith("embed_tokens.weight"):
+            if name.endswith("qkv_proj.weight"):
+                # rotation-paired row order: RoPE pairs share an accumulator tile (fused epilogue) -- layout.hip
+                out = torch.empty(w.numel(), dtype=BF16, device=self.device)
+                H.rows_to_frag_qkv(w, out, self.nh, self.nkv, self.hd, w.shape[1])
+                self.w[name] = out
+            elif name.endswith("qkv_proj.bias"):
+                self.w[name] = w[self._qkv_row_perm().to(self.device)].contiguous()
+            elif w.dim() == 2 and not name.endswith("embed_tokens.weight"):
                 R, K = w.shape
                 out = torch.empty(H.frag_numel(R, K), dtype=BF16, device=self.device)
                 H.rows_to_frag(w, out, R, K, mode=1 if name.endswith("gate_up_proj.weight") else 0)
@@ -120,6 +128,17 @@ class HipDecoder:
             else:
                 self.w[name] = w
         torch.cuda.synchronize(self.device)
+
+    def _qkv_row_perm(self) -> torch.Tensor:
+        """Source row of every destination row of the rotation-paired QKV order (same map as ssd_rows_to_frag_qkv)."""
+        hd, half, gph = self.hd, self.hd // 2, self.hd // 16
+        idx = []
+        for head in range(self.nh + self.nkv):
+            for j in range(gph):
+                idx.extend(head * hd + 8 * j + i for i in range(8))
+                idx.extend(head * hd + half + 8 * j + i for i in range(8))
+        idx.extend(range((self.nh + self.nkv) * hd, (self.nh + 2 * self.nkv) * hd))
+        return torch.tensor(idx, dtype=torch.int64)
 
     def weight_bytes(self) -> int:
         """HBM bytes one forward must stream (every matrix once; the embedding table is only gathered)."""
@@ -180,17 +199,34 @@ class HipDecoder:
         self._allreduce(h[:T])
         splits, attn_waves = self._attn_cfg(T, meta)
         scale = self.hd ** -0.5
+        # T <= 16: fused decode-layer GEMMs (csrc/gemm_fused.hip).  RoPE + KV store always ride the QKV epilogue;
+        # the residual add + RMSNorm ride the GEMM prologue when no all-reduce sits between producer and norm.
+        small = T <= 16 and not cfg.qk_norm
+        # the norm prologue keeps (h + res) in registers: <= 4 chunks of 8 per thread at 16 waves per workgroup
+        norm_fuse = small and not self.use_coll and T * self.h // 8 <= 4096
+        res2 = self.buf_res2
         for li in range(cfg.num_layers):
             p = f"model.layers.{li}."
-            # residual is None on layer 0 (llama3.py:187-190): residual := embeddings, x := norm(embeddings)
-            H.rmsnorm(h, w[p + "input_layernorm.weight"], cfg.rms_norm_eps, T, self.h,
-                      res_in=None if li == 0 else res, res_out=res, out_frag=xf)
-            self._gemm(xf, self.h, w[p + "self_attn.qkv_proj.weight"], self.qkv_n, self.buf_qkv, T, self.qkv_n,
-                       bias=w.get(p + "self_attn.qkv_proj.bias"))
             kc, vc = self.kv_cache[li, 0], self.kv_cache[li, 1]
-            H.rope_store_kv(self.buf_qkv, positions, self.cos_sin, meta.slot_mapping, self.buf_q, kc, vc, T, self.nh,
-                            self.nkv, self.hd, self.block_size, q_norm_w=w.get(p + "self_attn.q_norm.weight"),
-                            k_norm_w=w.get(p + "self_attn.k_norm.weight"), eps=cfg.rms_norm_eps)
+            rope = dict(positions=positions, cos_sin=self.cos_sin, slots=meta.slot_mapping, q_out=self.buf_q, k_cache=kc,
+                        v_cache=vc, nh=self.nh, nkv=self.nkv, hd=self.hd, block_size=self.block_size)
+            if norm_fuse:
+                H.gemm_fused(w[p + "self_attn.qkv_proj.weight"], T, self.qkv_n, self.h, H.FEPI_QKV_ROPE, h_rows=h,
+                             res_in=None if li == 0 else res, res_out=res2, norm_w=w[p + "input_layernorm.weight"],
+                             eps=cfg.rms_norm_eps, bias=w.get(p + "self_attn.qkv_proj.bias"), waves=16, **rope)
+            else:
+                # residual is None on layer 0 (llama3.py:187-190): residual := embeddings, x := norm(embeddings)
+                H.rmsnorm(h, w[p + "input_layernorm.weight"], cfg.rms_norm_eps, T, self.h,
+                          res_in=None if li == 0 else res, res_out=res, out_frag=xf)
+                if small:
+                    H.gemm_fused(w[p + "self_attn.qkv_proj.weight"], T, self.qkv_n, self.h, H.FEPI_QKV_ROPE, x_frag=xf,
+                                 bias=w.get(p + "self_attn.qkv_proj.bias"), **rope)
+                else:
+                    self._gemm(xf, self.h, w[p + "self_attn.qkv_proj.weight"], self.qkv_n, self.buf_qkv, T, self.qkv_n,
+                               bias=w.get(p + "self_attn.qkv_proj.bias"))
+                    H.rope_store_kv(self.buf_qkv, positions, self.cos_sin, meta.slot_mapping, self.buf_q, kc, vc, T, self.nh,
+                                    self.nkv, self.hd, self.block_size, q_norm_w=w.get(p + "self_attn.q_norm.weight"),
+                                    k_norm_w=w.get(p + "self_attn.k_norm.weight"), eps=cfg.rms_norm_eps, qkv_perm=1)
             H.attn_paged(self.buf_q, kc, vc, meta.block_tables, self.max_blocks, meta.context_lens, meta.B, T, meta.max_q,
                          self.nh, self.nkv, self.hd, self.block_size, scale, cu_q=meta.cu_q, q_per_seq=meta.q_per_seq,
                          mode=meta.mode, tree_K=meta.tree_K, tree_mq=meta.tree_mq, tree_step=meta.tree_step,
@@ -198,8 +234,13 @@ class HipDecoder:
                          out_frag=self.buf_af, waves=attn_waves)
             self._gemm(self.buf_af, self.qn, w[p + "self_attn.o_proj.weight"], self.h, h, T, self.h)
             self._allreduce(h[:T])
-            H.rmsnorm(h, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps, T, self.h, res_in=res, res_out=res, out_frag=xf)
-            self._gemm(xf, self.h, w[p + "mlp.gate_up_proj.weight"], 2 * self.I, self.buf_actf, T, 0, epi=H.EPI_SILU_FRAG)
+            if norm_fuse:
+                H.gemm_fused(w[p + "mlp.gate_up_proj.weight"], T, 2 * self.I, self.h, H.FEPI_SILU_FRAG, h_rows=h, res_in=res2,
+                             res_out=res, norm_w=w[p + "post_attention_layernorm.weight"], eps=cfg.rms_norm_eps,
+                             y=self.buf_actf, waves=16)
+            else:
+                H.rmsnorm(h, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps, T, self.h, res_in=res, res_out=res, out_frag=xf)
+                self._gemm(xf, self.h, w[p + "mlp.gate_up_proj.weight"], 2 * self.I, self.buf_actf, T, 0, epi=H.EPI_SILU_FRAG)
             self._gemm(self.buf_actf, self.I, w[p + "mlp.down_proj.weight"], self.h, h, T, self.h)
             self._allreduce(h[:T])
 
