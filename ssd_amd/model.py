@@ -202,8 +202,10 @@ class HipDecoder:
         # T <= 16: fused decode-layer GEMMs (csrc/gemm_fused.hip).  RoPE + KV store always ride the QKV epilogue;
         # the residual add + RMSNorm ride the GEMM prologue when no all-reduce sits between producer and norm.
         small = T <= 16 and not cfg.qk_norm
-        # the norm prologue keeps (h + res) in registers: <= 4 chunks of 8 per thread at 16 waves per workgroup
-        norm_fuse = small and not self.use_coll and T * self.h // 8 <= 4096
+        # The norm prologue is paid by EVERY workgroup and its LDS image limits residency, so it only wins while
+        # M*K is tiny (single-token draft decode): measured on MI355X, M=7 x K=4096 made gate_up 73 us vs 49 us
+        # unfused, while M=1 x K=2048 made norm+qkv+rope 5.6 us vs 14.8 us.
+        norm_fuse = small and not self.use_coll and T * self.h // 8 <= 1024
         res2 = self.buf_res2
         for li in range(cfg.num_layers):
             p = f"model.layers.{li}."
