@@ -83,22 +83,24 @@ def gemm_roofline(engine, steps_k):
             continue
         m = runner.model
         L = m.cfg.num_layers
-        kinds = [("qkv", "self_attn.qkv_proj.weight", m.buf_xf, m.h, m.qkv_n, m.buf_qkv, m.qkv_n, H.EPI_ROWS),
-                 ("o", "self_attn.o_proj.weight", m.buf_af, m.qn, m.h, m.buf_h, m.h, H.EPI_ROWS),
-                 ("gate_up", "mlp.gate_up_proj.weight", m.buf_xf, m.h, 2 * m.I, m.buf_actf, 0, H.EPI_SILU_FRAG),
-                 ("down", "mlp.down_proj.weight", m.buf_actf, m.I, m.h, m.buf_h, m.h, H.EPI_ROWS)]
-        for kind, wname, x, K, N, y, ldy, epi in kinds:
-            ws = [m.w[f"model.layers.{i}.{wname}"] for i in range(L)]
-            for w in ws[:2]:
-                H.gemm(x, w, y, M, N, K, ldy, epi)
+        # the GEMM kernels are exactly the ones the forward issues for M tokens (HipDecoder.launch_*, fused norm /
+        # RoPE / SiLU variants included); separate add+RMSNorm / RoPE launches of the unfused variants are left out
+        kinds = [("qkv", m.qkv_n * m.h * 2, lambda li: m.launch_qkv(li, M, runner.d_pos, runner.d_slots, gemm_only=True)),
+                 ("o", m.h * m.qn * 2, lambda li: m.launch_o(li, M)),
+                 ("gate_up", 2 * m.I * m.h * 2, lambda li: m.launch_gate_up(li, M, gemm_only=True)),
+                 ("down", m.h * m.I * 2, lambda li: m.launch_down(li, M))]
+        runner.d_slots[:M].fill_(-1)          # timing only: do not touch the KV cache
+        for kind, b, launch in kinds:
+            for li in range(min(2, L)):
+                launch(li)
             reps = max(2, 128 // L)
             # the L launches are captured in a hipGraph and the replay is timed: the real forward is a graph
             # replay too, and eager launches through ctypes are host-bound (~8 us each) for the small shapes
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                for w in ws:
-                    H.gemm(x, w, y, M, N, K, ldy, epi)
+                for li in range(L):
+                    launch(li)
             graph.replay()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
@@ -108,17 +110,25 @@ def gemm_roofline(engine, steps_k):
             e1.record()
             torch.cuda.synchronize()
             dt = e0.elapsed_time(e1) * 1e-3 / (reps * L)
-            b = N * K * 2
             tag = ("draft." if runner.is_draft else "target.") + kind
             per_kind[tag] = {"us": round(dt * 1e6, 2), "GBps": round(b / dt / 1e9, 1), "MB": round(b / 1e6, 1)}
             tot_bytes += b * L * fwd_per_step
             tot_time += dt * L * fwd_per_step
             tot_launch += L * fwd_per_step
-        # LM head (one launch per forward; measured with the LM head alone -> partly cache-resident for the
-        # 0.5 GB draft head, so it is reported but not rotated)
     achieved = tot_bytes / tot_time
-    return {"bound": "hbm", "kernel": "gemm_wf_kernel", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
+    # HBM traffic per launch: PMC counters cannot be collected from inside this process; the committed separate
+    # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (profiles/r01_c2_pmc_traffic.csv, FETCH_SIZE doubled
+    # as the gfx950 guide prescribes) measured read+write bytes = ratio x algorithmic bytes for this kernel family
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_r01.json")) as f:
+            traffic = int(tot_bytes / tot_launch * json.load(f)["gemm_traffic_over_algorithmic"])
+    except Exception:
+        pass
+    return {"bound": "hbm", "kernel": "gemm_wf_kernel + gemm_fused_kernel (skinny weight-streaming GEMM family)",
+            "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
+            "traffic_source": "separate rocprofv3 --pmc passes, profiles/r01_c2_pmc_traffic.csv (x1.0125 of algorithmic)",
             "launches_per_step": tot_launch, "avg_launch_us": round(tot_time / tot_launch * 1e6, 2),
             "bytes_per_launch_avg": int(tot_bytes / tot_launch), "per_kind": per_kind}
 

@@ -190,60 +190,86 @@ class HipDecoder:
             splits = 1
         return splits, waves
 
+    # ---- the four GEMM launches of a layer (also used one by one by bench.py's roofline timing) ----
+    def fusion_plan(self, T: int) -> tuple[bool, bool]:
+        """(small, norm_fuse).  T <= 16: RoPE + KV store ride the QKV epilogue (csrc/gemm_fused.hip).  The residual
+        add + RMSNorm ride the GEMM prologue only while M*K is tiny (single-token draft decode) and no all-reduce sits
+        between producer and norm: the prologue is paid by EVERY workgroup and its LDS image limits residency --
+        measured on MI355X, M=7 x K=4096 made gate_up 73 us vs 49 us unfused, M=1 x K=2048 made norm+qkv+rope 5.6 us
+        vs 14.8 us."""
+        small = T <= 16 and not self.cfg.qk_norm
+        return small, small and not self.use_coll and T * self.h // 8 <= 1024
+
+    def launch_qkv(self, li: int, T: int, positions, slot_mapping, gemm_only: bool = False) -> None:
+        """gemm_only: skip the separate add+RMSNorm / RoPE launches of the unfused variants (kernel timing)."""
+        cfg, w = self.cfg, self.w
+        p = f"model.layers.{li}."
+        small, norm_fuse = self.fusion_plan(T)
+        kc, vc = self.kv_cache[li, 0], self.kv_cache[li, 1]
+        rope = dict(positions=positions, cos_sin=self.cos_sin, slots=slot_mapping, q_out=self.buf_q, k_cache=kc, v_cache=vc,
+                    nh=self.nh, nkv=self.nkv, hd=self.hd, block_size=self.block_size)
+        h, res, xf = self.buf_h, self.buf_res, self.buf_xf
+        if norm_fuse:
+            H.gemm_fused(w[p + "self_attn.qkv_proj.weight"], T, self.qkv_n, self.h, H.FEPI_QKV_ROPE, h_rows=h,
+                         res_in=None if li == 0 else res, res_out=self.buf_res2, norm_w=w[p + "input_layernorm.weight"],
+                         eps=cfg.rms_norm_eps, bias=w.get(p + "self_attn.qkv_proj.bias"), waves=16, **rope)
+            return
+        # residual is None on layer 0 (llama3.py:187-190): residual := embeddings, x := norm(embeddings)
+        if not gemm_only:
+            H.rmsnorm(h, w[p + "input_layernorm.weight"], cfg.rms_norm_eps, T, self.h, res_in=None if li == 0 else res,
+                      res_out=res, out_frag=xf)
+        if small:
+            H.gemm_fused(w[p + "self_attn.qkv_proj.weight"], T, self.qkv_n, self.h, H.FEPI_QKV_ROPE, x_frag=xf,
+                         bias=w.get(p + "self_attn.qkv_proj.bias"), **rope)
+        else:
+            self._gemm(xf, self.h, w[p + "self_attn.qkv_proj.weight"], self.qkv_n, self.buf_qkv, T, self.qkv_n,
+                       bias=w.get(p + "self_attn.qkv_proj.bias"))
+            if gemm_only:
+                return
+            H.rope_store_kv(self.buf_qkv, positions, self.cos_sin, slot_mapping, self.buf_q, kc, vc, T, self.nh, self.nkv,
+                            self.hd, self.block_size, q_norm_w=w.get(p + "self_attn.q_norm.weight"),
+                            k_norm_w=w.get(p + "self_attn.k_norm.weight"), eps=cfg.rms_norm_eps, qkv_perm=1)
+
+    def launch_o(self, li: int, T: int) -> None:
+        self._gemm(self.buf_af, self.qn, self.w[f"model.layers.{li}.self_attn.o_proj.weight"], self.h, self.buf_h, T, self.h)
+
+    def launch_gate_up(self, li: int, T: int, gemm_only: bool = False) -> None:
+        cfg, w = self.cfg, self.w
+        p = f"model.layers.{li}."
+        _, norm_fuse = self.fusion_plan(T)
+        if norm_fuse:
+            H.gemm_fused(w[p + "mlp.gate_up_proj.weight"], T, 2 * self.I, self.h, H.FEPI_SILU_FRAG, h_rows=self.buf_h,
+                         res_in=self.buf_res2, res_out=self.buf_res, norm_w=w[p + "post_attention_layernorm.weight"],
+                         eps=cfg.rms_norm_eps, y=self.buf_actf, waves=16)
+        else:
+            if not gemm_only:
+                H.rmsnorm(self.buf_h, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps, T, self.h,
+                          res_in=self.buf_res, res_out=self.buf_res, out_frag=self.buf_xf)
+            self._gemm(self.buf_xf, self.h, w[p + "mlp.gate_up_proj.weight"], 2 * self.I, self.buf_actf, T, 0, epi=H.EPI_SILU_FRAG)
+
+    def launch_down(self, li: int, T: int) -> None:
+        self._gemm(self.buf_actf, self.I, self.w[f"model.layers.{li}.mlp.down_proj.weight"], self.h, self.buf_h, T, self.h)
+
     def forward(self, input_ids: torch.Tensor, positions: torch.Tensor, T: int, meta: AttnMeta) -> None:
         """Runs all layers; leaves the final (pre-norm) hidden state in buf_h and the residual in buf_res."""
         cfg, w = self.cfg, self.w
-        h, res, xf = self.buf_h, self.buf_res, self.buf_xf
+        h = self.buf_h
         H.embedding(input_ids, w["model.embed_tokens.weight"], h, T, self.h,
                     vocab_start=self.tp_rank * self.V if self.tp_size > 1 else 0, vocab_count=self.V if self.tp_size > 1 else cfg.vocab_size)
         self._allreduce(h[:T])
         splits, attn_waves = self._attn_cfg(T, meta)
         scale = self.hd ** -0.5
-        # T <= 16: fused decode-layer GEMMs (csrc/gemm_fused.hip).  RoPE + KV store always ride the QKV epilogue;
-        # the residual add + RMSNorm ride the GEMM prologue when no all-reduce sits between producer and norm.
-        small = T <= 16 and not cfg.qk_norm
-        # The norm prologue is paid by EVERY workgroup and its LDS image limits residency, so it only wins while
-        # M*K is tiny (single-token draft decode): measured on MI355X, M=7 x K=4096 made gate_up 73 us vs 49 us
-        # unfused, while M=1 x K=2048 made norm+qkv+rope 5.6 us vs 14.8 us.
-        norm_fuse = small and not self.use_coll and T * self.h // 8 <= 1024
-        res2 = self.buf_res2
         for li in range(cfg.num_layers):
-            p = f"model.layers.{li}."
-            kc, vc = self.kv_cache[li, 0], self.kv_cache[li, 1]
-            rope = dict(positions=positions, cos_sin=self.cos_sin, slots=meta.slot_mapping, q_out=self.buf_q, k_cache=kc,
-                        v_cache=vc, nh=self.nh, nkv=self.nkv, hd=self.hd, block_size=self.block_size)
-            if norm_fuse:
-                H.gemm_fused(w[p + "self_attn.qkv_proj.weight"], T, self.qkv_n, self.h, H.FEPI_QKV_ROPE, h_rows=h,
-                             res_in=None if li == 0 else res, res_out=res2, norm_w=w[p + "input_layernorm.weight"],
-                             eps=cfg.rms_norm_eps, bias=w.get(p + "self_attn.qkv_proj.bias"), waves=16, **rope)
-            else:
-                # residual is None on layer 0 (llama3.py:187-190): residual := embeddings, x := norm(embeddings)
-                H.rmsnorm(h, w[p + "input_layernorm.weight"], cfg.rms_norm_eps, T, self.h,
-                          res_in=None if li == 0 else res, res_out=res, out_frag=xf)
-                if small:
-                    H.gemm_fused(w[p + "self_attn.qkv_proj.weight"], T, self.qkv_n, self.h, H.FEPI_QKV_ROPE, x_frag=xf,
-                                 bias=w.get(p + "self_attn.qkv_proj.bias"), **rope)
-                else:
-                    self._gemm(xf, self.h, w[p + "self_attn.qkv_proj.weight"], self.qkv_n, self.buf_qkv, T, self.qkv_n,
-                               bias=w.get(p + "self_attn.qkv_proj.bias"))
-                    H.rope_store_kv(self.buf_qkv, positions, self.cos_sin, meta.slot_mapping, self.buf_q, kc, vc, T, self.nh,
-                                    self.nkv, self.hd, self.block_size, q_norm_w=w.get(p + "self_attn.q_norm.weight"),
-                                    k_norm_w=w.get(p + "self_attn.k_norm.weight"), eps=cfg.rms_norm_eps, qkv_perm=1)
-            H.attn_paged(self.buf_q, kc, vc, meta.block_tables, self.max_blocks, meta.context_lens, meta.B, T, meta.max_q,
-                         self.nh, self.nkv, self.hd, self.block_size, scale, cu_q=meta.cu_q, q_per_seq=meta.q_per_seq,
-                         mode=meta.mode, tree_K=meta.tree_K, tree_mq=meta.tree_mq, tree_step=meta.tree_step,
-                         tree_F=meta.tree_F, tree_jidx=meta.tree_jidx, splits=splits, ws_o=self.ws_o, ws_ml=self.ws_ml,
-                         out_frag=self.buf_af, waves=attn_waves)
-            self._gemm(self.buf_af, self.qn, w[p + "self_attn.o_proj.weight"], self.h, h, T, self.h)
+            self.launch_qkv(li, T, positions, meta.slot_mapping)
+            H.attn_paged(self.buf_q, self.kv_cache[li, 0], self.kv_cache[li, 1], meta.block_tables, self.max_blocks,
+                         meta.context_lens, meta.B, T, meta.max_q, self.nh, self.nkv, self.hd, self.block_size, scale,
+                         cu_q=meta.cu_q, q_per_seq=meta.q_per_seq, mode=meta.mode, tree_K=meta.tree_K, tree_mq=meta.tree_mq,
+                         tree_step=meta.tree_step, tree_F=meta.tree_F, tree_jidx=meta.tree_jidx, splits=splits,
+                         ws_o=self.ws_o, ws_ml=self.ws_ml, out_frag=self.buf_af, waves=attn_waves)
+            self.launch_o(li, T)
             self._allreduce(h[:T])
-            if norm_fuse:
-                H.gemm_fused(w[p + "mlp.gate_up_proj.weight"], T, 2 * self.I, self.h, H.FEPI_SILU_FRAG, h_rows=h, res_in=res2,
-                             res_out=res, norm_w=w[p + "post_attention_layernorm.weight"], eps=cfg.rms_norm_eps,
-                             y=self.buf_actf, waves=16)
-            else:
-                H.rmsnorm(h, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps, T, self.h, res_in=res, res_out=res, out_frag=xf)
-                self._gemm(xf, self.h, w[p + "mlp.gate_up_proj.weight"], 2 * self.I, self.buf_actf, T, 0, epi=H.EPI_SILU_FRAG)
-            self._gemm(self.buf_actf, self.I, w[p + "mlp.down_proj.weight"], self.h, h, T, self.h)
+            self.launch_gate_up(li, T)
+            self.launch_down(li, T)
             self._allreduce(h[:T])
 
     def compute_logits(self, T: int, gather: torch.Tensor | None = None, rows: int | None = None) -> int:
