@@ -212,8 +212,10 @@ class ModelRunner:
         are keyed by its power-of-two bucket because the attention decomposition is fixed at capture."""
         self._ctx_hint = HipDecoder.ctx_bucket(max_ctx)
 
-    def _body_decode(self, B: int, chain: bool) -> None:
+    def _body_decode(self, B: int, chain: bool, head: bool = True) -> None:
         self.model.forward(self.d_ids, self.d_pos, B, self._meta("decode", B))
+        if not head:        # KV deposit only (the (K+1)-th draft forward, speculator_sync.py:55-56): no LM head / sampling
+            return
         self.model.compute_logits(B)
         self.model.argmax(B, self.d_next)
         if chain:
@@ -308,11 +310,14 @@ class ModelRunner:
         else:
             first = 1
         g = self.graphs.get((*key, self._ctx_hint))
-        for _ in range(first, K + 1):
+        for _ in range(first, K):
             if g is not None:
                 g.replay()
             else:
                 self._body_decode(B, True)
+        # the (K+1)-th forward only deposits x_K's KV: same inputs (already advanced on the device), no LM head
+        if self._launch(("decode_deposit", B), lambda: self._body_decode(B, False, head=False)) == "captured":
+            self.graphs[("decode_deposit", B, self._ctx_hint)].replay()     # idempotent: same token, same slot
         return self.d_spec[:B]
 
     @torch.inference_mode()
