@@ -135,6 +135,22 @@ int ssd_draft_advance(const int64_t* next, int64_t* input_ids, int64_t* position
                       int32_t* context_lens, const int32_t* block_tables, int max_blocks, int block_size,
                       int64_t* spec, int K, int32_t* step, int B, void* stream);
 
+/* One-shot full-mesh all-reduce (sum, bf16 in/out, fp32 accumulate in rank order) over hipIpc-shared fine-grained
+ * buffers -- replaces dist.all_reduce after o_proj / down_proj / the embedding (ssd/layers/linear.py:195-199,
+ * ssd/layers/embed_head.py:53-56) for the small decode-time messages; csrc/comm.hip describes the protocol.
+ * Setup (not hot path): ssd_comm_alloc (fine-grained device memory, zeroed) / ssd_comm_ipc_export (64-byte handle) /
+ * ssd_comm_ipc_open (map a peer's allocation) / ssd_comm_ipc_close / ssd_comm_free.
+ * ssd_allreduce_bf16: slots[r] / flags[r] = rank r's staging area (2 * slot_elems bf16) and flag array (8*8 uint32);
+ * counters uint32[8] and err uint32[1] are local device words (zeroed once); err becomes 1 if a peer did not arrive
+ * within spin_budget polls (the call then leaves `out` undefined and the caller must fall back). */
+int ssd_comm_alloc(void** out, long bytes);
+int ssd_comm_free(void* p);
+int ssd_comm_ipc_export(void* p, void* handle64);
+int ssd_comm_ipc_open(const void* handle64, void** out);
+int ssd_comm_ipc_close(void* p);
+int ssd_allreduce_bf16(const void* in, void* out, long n, int rank, int world, void* const* slots, void* const* flags,
+                       long slot_elems, void* counters, void* err, long spin_budget, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,7 +27,8 @@ class ModelRunner:
     def __init__(self, config, model_cfg: ModelConfig, *, is_draft: bool, device: torch.device, tp_rank: int = 0,
                  tp_size: int = 1, tp_group=None, model_path: str | None = None, weights_seed: int = 0,
                  gen_device: str | None = None, num_kvcache_blocks: int = -1, memory_utilization: float | None = None,
-                 max_decode_tokens: int | None = None, weight_source=None, force_collectives: bool = False):
+                 max_decode_tokens: int | None = None, weight_source=None, force_collectives: bool = False,
+                 custom_ar: bool | None = None):
         if not torch.cuda.is_available():
             raise RuntimeError("ssd_amd.ModelRunner needs an MI355X; there is no CPU fallback on the product path")
         load_library()  # fail loudly before allocating anything
@@ -90,11 +91,44 @@ class ModelRunner:
         self.d_packed = torch.zeros(B, self.K + 3, dtype=torch.int64, **dev)
         self.h_packed = torch.zeros(B, self.K + 3, dtype=torch.int64).pin_memory()
         self.h_next = torch.zeros(max(self.max_decode_tokens, B), dtype=torch.int64).pin_memory()
+        self._setup_custom_ar(custom_ar)
         self._stage: dict = {}
         self._ctx_hint = 4096
         self.graphs: dict = {}
         self.graph_pool = None
         self.stream = torch.cuda.Stream(device)
+
+    def _setup_custom_ar(self, want: bool | None) -> None:
+        """Enable the one-shot all-reduce for the small TP sums when (a) tensor parallelism is on, (b) it is not
+        disabled (SSD_CUSTOM_AR=0), and (c) EVERY rank's throw-away validation helper succeeded -- a fault in the IPC /
+        peer-access path can then only kill a helper, never this process.  Otherwise RCCL carries all collectives."""
+        import os
+        m = self.model
+        if not m.use_coll or self.is_draft:
+            return
+        if want is None:
+            want = os.environ.get("SSD_CUSTOM_AR", "1") != "0"
+        if not want:
+            return
+        from ssd_amd.utils import custom_ar as CA
+        world = dist.get_world_size(self.tp_group)
+        try:
+            if world > 1:
+                port = int(os.environ.get("MASTER_PORT", "29531")) + 17
+                ok = CA.validate_in_subprocess(self.tp_rank, world, self.device.index or 0, port)
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.tp_group)
+                if int(flag.item()) != 1:
+                    return
+            m.custom_ar = CA.OneShotAllReduce(self.tp_group, self.device)
+        except Exception:
+            m.custom_ar = None
+
+    def _check_collectives(self) -> None:
+        ar = self.model.custom_ar
+        if ar is not None and ar.failed():
+            raise RuntimeError("one-shot all-reduce timed out waiting for a peer; results of this step are invalid "
+                               "(rerun with SSD_CUSTOM_AR=0 to use RCCL)")
 
     # ---------------------------------------------------------------------------------------------
     # host -> device input staging
@@ -287,6 +321,7 @@ class ModelRunner:
     def _read_tokens(self, n: int) -> list[int]:
         self.h_next[:n].copy_(self.d_next[:n], non_blocking=True)
         torch.cuda.current_stream().synchronize()
+        self._check_collectives()
         return self.h_next[:n].tolist()
 
     # ---- fast path of synchronous speculation: no host sync until the verify result ----
@@ -338,6 +373,7 @@ class ModelRunner:
             self.graphs[(*key, self._ctx_hint)].replay()
         self.h_packed[:B].copy_(self.d_packed[:B], non_blocking=True)
         torch.cuda.current_stream().synchronize()
+        self._check_collectives()
         rows = self.h_packed[:B].tolist()
         suffixes = [r[2:3 + r[0]] for r in rows]
         recovery = [r[1] for r in rows]

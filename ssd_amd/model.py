@@ -60,6 +60,7 @@ class HipDecoder:
         # force_collectives: issue the RCCL calls even at tp_size == 1 (lets a single-GPU box exercise the
         # collective + hipGraph-capture path that the multi-GPU runs depend on)
         self.use_coll = tp_size > 1 or (force_collectives and tp_group is not None)
+        self.custom_ar = None      # OneShotAllReduce (ssd_amd/utils/custom_ar.py) once the runner has validated it
         assert cfg.num_heads % tp_size == 0 and cfg.num_kv_heads % tp_size == 0
         assert cfg.intermediate_size % (tp_size * 32) == 0 and cfg.vocab_size % (tp_size * 16) == 0
         self.nh, self.nkv = cfg.num_heads // tp_size, cfg.num_kv_heads // tp_size
@@ -166,7 +167,11 @@ class HipDecoder:
             H.gemm(xf[x_off:], w, yf[y_off:], m, N, K, ldy, epi, bias)
 
     def _allreduce(self, t):
-        if self.use_coll:
+        if not self.use_coll:
+            return
+        if self.custom_ar is not None and self.custom_ar.fits(t):
+            self.custom_ar.all_reduce(t)        # one-shot full-mesh sum over xGMI (csrc/comm.hip)
+        else:
             dist.all_reduce(t, group=self.tp_group)
 
     @staticmethod

@@ -1,0 +1,174 @@
+"""One-shot full-mesh all-reduce over hipIpc-shared buffers (device side: ssd_amd/csrc/comm.hip).
+
+Used for the small, latency-bound tensor-parallel sums of the decode / verify forwards; larger messages (prefill)
+stay on RCCL.  Safety net: the kernel's spins are bounded and raise an error word instead of hanging; before the engine
+enables this path every rank validates it in a throw-away helper process (``python -m ssd_amd.utils.custom_ar``),
+so that a driver / topology problem (no peer access, IPC refused, a fault) can only kill the helper -- the engine then
+simply keeps using RCCL.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import torch
+import torch.distributed as dist
+
+from ssd_amd.hip.lib import load_library
+
+SLOT_ELEMS = 1 << 19          # bf16 elements per staging slot (1 MiB); messages above this go to RCCL
+FLAG_BYTES = 4096
+SPIN_BUDGET = 20_000_000      # polls (~ seconds) before a wait gives up and sets the error word
+
+
+class OneShotAllReduce:
+    def __init__(self, group, device: torch.device):
+        self.lib = load_library()
+        self.group, self.device = group, device
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        torch.cuda.set_device(device)
+        self._own = []
+        slot = self._alloc(2 * SLOT_ELEMS * 2)
+        flags = self._alloc(FLAG_BYTES)
+        handles = [None] * self.world
+        dist.all_gather_object(handles, (self._export(slot), self._export(flags)), group=group)
+        self._opened = []
+        slots, flgs = [], []
+        for r, (hs, hf) in enumerate(handles):
+            if r == self.rank:
+                slots.append(slot)
+                flgs.append(flags)
+            else:
+                slots.append(self._open(hs))
+                flgs.append(self._open(hf))
+        self.slots = (C.c_void_p * self.world)(*slots)
+        self.flags = (C.c_void_p * self.world)(*flgs)
+        self.counters = torch.zeros(8, dtype=torch.int32, device=device)
+        self.err = torch.zeros(1, dtype=torch.int32, device=device)
+        dist.barrier(group=group)
+
+    def _alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        if self.lib.ssd_comm_alloc(C.byref(p), nbytes) != 0:
+            raise RuntimeError("ssd_comm_alloc failed")
+        self._own.append(p.value)
+        return p.value
+
+    def _export(self, ptr: int) -> bytes:
+        buf = C.create_string_buffer(64)
+        if self.lib.ssd_comm_ipc_export(C.c_void_p(ptr), buf) != 0:
+            raise RuntimeError("hipIpcGetMemHandle failed")
+        return buf.raw
+
+    def _open(self, handle: bytes) -> int:
+        p = C.c_void_p()
+        if self.lib.ssd_comm_ipc_open(C.create_string_buffer(handle, 64), C.byref(p)) != 0:
+            raise RuntimeError("hipIpcOpenMemHandle failed")
+        self._opened.append(p.value)
+        return p.value
+
+    def fits(self, t: torch.Tensor) -> bool:
+        n = t.numel()
+        return t.dtype == torch.bfloat16 and n <= SLOT_ELEMS and n % 4 == 0 and t.is_contiguous() and t.data_ptr() % 8 == 0
+
+    def all_reduce(self, t: torch.Tensor) -> None:
+        """In-place sum over the group (bf16, fp32 accumulation in rank order); enqueued on the current stream."""
+        rc = self.lib.ssd_allreduce_bf16(t.data_ptr(), t.data_ptr(), t.numel(), self.rank, self.world, self.slots, self.flags,
+                                         SLOT_ELEMS, self.counters.data_ptr(), self.err.data_ptr(), SPIN_BUDGET,
+                                         torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"ssd_allreduce_bf16 failed with code {rc}")
+
+    def failed(self) -> bool:
+        return bool(self.err.item())
+
+    def close(self) -> None:
+        for p in self._opened:
+            self.lib.ssd_comm_ipc_close(C.c_void_p(p))
+        for p in self._own:
+            self.lib.ssd_comm_free(C.c_void_p(p))
+        self._opened, self._own = [], []
+
+
+# --------------------------------------------------------------------------------------------------
+# validation helper: run as its own process group (gloo rendezvous), one helper per rank
+# --------------------------------------------------------------------------------------------------
+def _selftest_main() -> int:
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dev = torch.device("cuda", int(os.environ.get("SSD_AR_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ar = OneShotAllReduce(dist.group.WORLD, dev)
+    ok = True
+    g = torch.Generator().manual_seed(1234)
+    for n in (4, 4096, 7 * 8192, 24 * 2048, SLOT_ELEMS):
+        for it in range(6):
+            xs = [torch.randn(n, generator=g).to(torch.bfloat16) for _ in range(world)]      # same on every rank
+            want = torch.stack([x.float() for x in xs]).sum(0).to(torch.bfloat16)
+            t = xs[rank].to(dev)
+            ar.all_reduce(t)
+            torch.cuda.synchronize()
+            if ar.failed() or not torch.equal(t.cpu().view(torch.int16), want.view(torch.int16)):
+                print(f"[custom_ar selftest] rank {rank}: mismatch at n={n} it={it} failed={ar.failed()}", flush=True)
+                ok = False
+                break
+    # captured in a hipGraph and replayed (the way the engine uses it): two dependent all-reduces per replay
+    if ok:
+        n = 7 * 8192
+        buf = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+        src = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+        s = torch.cuda.Stream()
+
+        def body():
+            buf.copy_(src)
+            ar.all_reduce(buf)
+            ar.all_reduce(buf)
+        with torch.cuda.stream(s):
+            body()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            body()
+        for it in range(20):
+            xs = [torch.randn(n, generator=g).to(torch.bfloat16) for _ in range(world)]
+            once = torch.stack([x.float() for x in xs]).sum(0).to(torch.bfloat16)
+            want = (once.float() * world).to(torch.bfloat16)
+            src.copy_(xs[rank].to(dev))
+            graph.replay()
+            torch.cuda.synchronize()
+            if ar.failed() or not torch.equal(buf.cpu().view(torch.int16), want.view(torch.int16)):
+                print(f"[custom_ar selftest] rank {rank}: graph replay mismatch it={it} failed={ar.failed()}", flush=True)
+                ok = False
+                break
+    flag = torch.tensor([1 if ok else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    dist.barrier()
+    ar.close()
+    dist.destroy_process_group()
+    return 0 if int(flag.item()) == 1 else 1
+
+
+def validate_in_subprocess(rank: int, world: int, local_rank: int, port: int, timeout: float = 180.0) -> bool:
+    """Spawn this rank's validation helper; True iff the whole helper group succeeded."""
+    env = dict(os.environ)
+    env.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    try:
+        p = subprocess.Popen([sys.executable, "-m", "ssd_amd.utils.custom_ar"], env=env, stdout=subprocess.DEVNULL,
+                             stderr=subprocess.DEVNULL)
+        try:
+            return p.wait(timeout=timeout) == 0
+        except subprocess.TimeoutExpired:
+            p.kill()
+            return False
+    except Exception:
+        return False
+
+
+if __name__ == "__main__":
+    sys.exit(_selftest_main())

@@ -39,8 +39,9 @@ def init_process_group_if_needed(backend: str | None = None) -> tuple[int, int]:
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+            # SSD_DIST_BACKEND=gloo lets two ranks share ONE GPU in tests (RCCL refuses duplicate devices)
+            backend = os.environ.get("SSD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", str(rank))))
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world

@@ -221,7 +221,8 @@ def test_engine_sync_sd(gpu, golden, tag):
         assert lens[0] == K + 1
 
 
-def test_collective_path_single_rank_nccl(gpu, golden):
+@pytest.mark.parametrize("custom", [False, True])
+def test_collective_path_single_rank_nccl(gpu, golden, custom):
     """The RCCL calls of the tensor-parallel forward (all-reduce after o_proj / down_proj / embedding, the
     vocab-parallel argmax all-gather) captured inside the hipGraphs and replayed, on a 1-rank NCCL group:
     the same code the N-GPU runs execute, minus the peers.  Tokens must equal the collective-free run."""
@@ -242,11 +243,12 @@ def test_collective_path_single_rank_nccl(gpu, golden):
 
     def factory(config, model_cfg, *, is_draft, topo, **kw):
         return hip_runner_factory(config, model_cfg, is_draft=is_draft, topo=topo, force_collectives=not is_draft,
-                                  weight_source=iter((wd if is_draft else wt).items()), **kw)
+                                  custom_ar=custom, weight_source=iter((wd if is_draft else wt).items()), **kw)
 
     eng = LLMEngine("tiny", hf_config=mk_cfg(g, "llama", "t_"), draft="d", draft_hf_config=mk_cfg(g, "llama", "d_"),
                     speculate=True, speculate_k=K, runner_factory=factory, topology=topo, **COMMON)
     assert eng.model_runner.model.use_coll
+    assert (eng.model_runner.model.custom_ar is not None) == custom     # one-shot all-reduce inside the hipGraphs
     want = g["sd_diff_tokens"].tolist()
     out, _ = eng.generate([g["prompt"].tolist()], SamplingParams(temperature=0, max_new_tokens=len(want), ignore_eos=True), use_tqdm=False)
     assert out[0]["token_ids"] == want
