@@ -110,12 +110,12 @@ int ssd_attn_paged(const void* q_rows, const void* k_cache, const void* v_cache,
 /* Sampler.forward at temperature 0 -- ssd/layers/sampler.py:15-20; verify.py:34.  out2 optional copy. */
 int ssd_argmax_rows(const void* logits_rows, long ld, int T, int V, int64_t* out, int64_t* out2, void* stream);
 /* Vocab-parallel form of the same argmax (ParallelLMHead gather + cat, ssd/layers/embed_head.py:88-92, followed by
- * argmax): each rank reduces its shard to (max value, global index = local + idx_offset); the [tp][stride] pairs are
+ * argmax): each rank reduces its shard to (max value, global index = local + idx_offset); the per-rank rows (strides in elements of each array) are
  * all-gathered (16 bytes per row instead of the logits) and merged: larger value, then lower index. */
 int ssd_argmax_rows_val(const void* logits_rows, long ld, int T, int V, long idx_offset, int64_t* out_idx,
                         float* out_val, void* stream);
-int ssd_argmax_merge(const float* vals, const int64_t* idxs, int tp, int T, long stride, int64_t* out, int64_t* out2,
-                     void* stream);
+int ssd_argmax_merge(const float* vals, const int64_t* idxs, int tp, int T, long stride, long stride_idx, int64_t* out,
+                     int64_t* out2, void* stream);
 
 /* verify(), greedy branch -- ssd/utils/verify.py:28-48.  preds/speculations int64 [B][K+1].
  * packed (optional) int64 [B][K+3] = (accept_len, recovery, spec_0..spec_K): the step's whole result in one D2H
@@ -150,6 +150,10 @@ int ssd_comm_ipc_open(const void* handle64, void** out);
 int ssd_comm_ipc_close(void* p);
 int ssd_allreduce_bf16(const void* in, void* out, long n, int rank, int world, void* const* slots, void* const* flags,
                        long slot_elems, void* counters, void* err, long spin_budget, void* stream);
+/* Same transport as an all-gather of n8 opaque 8-byte words per rank: out [world][n8] (replaces the logits gather of
+ * ParallelLMHead, ssd/layers/embed_head.py:88-92, by a (value, index) exchange of 12 bytes per row). */
+int ssd_allgather_u64(const void* in, void* out, long n8, int rank, int world, void* const* slots, void* const* flags,
+                      long slot_elems, void* counters, void* err, long spin_budget, void* stream);
 
 #ifdef __cplusplus
 }

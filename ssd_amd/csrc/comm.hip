@@ -37,7 +37,7 @@ __device__ __forceinline__ unsigned long long ld_sys64(const unsigned long long*
 __global__ void __launch_bounds__(AR_THREADS)
 allreduce_bf16_kernel(const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out, long n8,
                       long slot_words, ArPeers peers, int rank, int world, unsigned int* __restrict__ counters,
-                      unsigned int* __restrict__ err, long spin_budget) {
+                      unsigned int* __restrict__ err, long spin_budget, int gather) {
   __shared__ unsigned int s_epoch;
   __shared__ int s_fail;
   const int blk = blockIdx.x;
@@ -58,7 +58,9 @@ allreduce_bf16_kernel(const unsigned long long* __restrict__ in, unsigned long l
     long spins = 0;
     // epochs are compared with wrap-around-safe signed difference
     while ((int)(__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
-      __builtin_amdgcn_s_sleep(1);
+      // fast polls first (latency), then ~1 us polls: ranks can be skewed by SECONDS of host work (hipGraph capture,
+      // Python GC), which must not read as a failure -- the budget only exists so that a dead peer cannot hang the GPU
+      if (spins < 4096) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(32);
       if (++spins > spin_budget) { s_fail = 1; break; }
     }
   }
@@ -70,6 +72,11 @@ allreduce_bf16_kernel(const unsigned long long* __restrict__ in, unsigned long l
   }
   __syncthreads();
   if (s_fail) return;
+  if (gather) {   // all-gather of opaque 8-byte words: out[r][i] = rank r's in[i]
+    for (long i = i0 + threadIdx.x; i < i1; i += AR_THREADS)
+      for (int r = 0; r < world; ++r) out[(long)r * n8 + i] = ld_sys64(peers.slot[r] + (long)(epoch & 1u) * slot_words + i);
+    return;
+  }
   for (long i = i0 + threadIdx.x; i < i1; i += AR_THREADS) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     for (int r = 0; r < world; ++r) {
@@ -126,6 +133,26 @@ extern "C" int ssd_allreduce_bf16(const void* in, void* out, long n, int rank, i
   if (blocks > AR_BLOCKS) blocks = AR_BLOCKS;
   hipLaunchKernelGGL(allreduce_bf16_kernel, dim3(blocks), dim3(AR_THREADS), 0, (hipStream_t)stream,
                      (const unsigned long long*)in, (unsigned long long*)out, n8, slot_elems / 4, peers, rank, world,
-                     (unsigned int*)counters, (unsigned int*)err, spin_budget);
+                     (unsigned int*)counters, (unsigned int*)err, spin_budget, 0);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
+// All-gather of n8 opaque 8-byte words per rank through the same staging slots / flags / counters:
+// out [world][n8] (in must not alias out).  Used for the vocab-parallel argmax (value, index) exchange.
+extern "C" int ssd_allgather_u64(const void* in, void* out, long n8, int rank, int world, void* const* slots,
+                                 void* const* flags, long slot_elems, void* counters, void* err, long spin_budget,
+                                 void* stream) {
+  if (world < 1 || world > AR_MAX_RANKS || rank < 0 || rank >= world || n8 <= 0 || n8 * 4 > slot_elems) return SSD_ERR_SHAPE;
+  ArPeers peers;
+  for (int r = 0; r < AR_MAX_RANKS; ++r) {
+    peers.slot[r] = (unsigned long long*)(r < world ? slots[r] : nullptr);
+    peers.flags[r] = (unsigned int*)(r < world ? flags[r] : nullptr);
+  }
+  int blocks = (int)((n8 + 2047) / 2048);
+  if (blocks < 1) blocks = 1;
+  if (blocks > AR_BLOCKS) blocks = AR_BLOCKS;
+  hipLaunchKernelGGL(allreduce_bf16_kernel, dim3(blocks), dim3(AR_THREADS), 0, (hipStream_t)stream,
+                     (const unsigned long long*)in, (unsigned long long*)out, n8, slot_elems / 4, peers, rank, world,
+                     (unsigned int*)counters, (unsigned int*)err, spin_budget, 1);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }

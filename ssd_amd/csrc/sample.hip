@@ -67,28 +67,29 @@ argmax_rows_kernel(const bf16_t* __restrict__ logits, long ld, int V, int64_t* _
   }
 }
 
-// Vocab-parallel argmax merge: vals/idxs [tp][stride >= T] (per-rank local maxima with GLOBAL indices) -> out[T].
+// Vocab-parallel argmax merge: vals [tp][stride >= T] floats, idxs [tp][stride_idx >= T] int64 (per-rank local maxima with GLOBAL indices) -> out[T].
 // Equivalent to argmax over the concatenated logits (ParallelLMHead gather + cat, reference
 // ssd/layers/embed_head.py:88-92): larger value wins, lowest global index on ties.
 __global__ void argmax_merge_kernel(const float* __restrict__ vals, const int64_t* __restrict__ idxs, int tp, int T,
-                                    long stride, int64_t* __restrict__ out, int64_t* __restrict__ out2) {
+                                    long stride, long stride_idx, int64_t* __restrict__ out, int64_t* __restrict__ out2) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= T) return;
   float bv = vals[t];
   int64_t bi = idxs[t];
   for (int r = 1; r < tp; ++r) {
     const float v = vals[(size_t)r * stride + t];
-    const int64_t i = idxs[(size_t)r * stride + t];
+    const int64_t i = idxs[(size_t)r * stride_idx + t];
     if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
   }
   out[t] = bi;
   if (out2) out2[t] = bi;
 }
 
-extern "C" int ssd_argmax_merge(const float* vals, const int64_t* idxs, int tp, int T, long stride, int64_t* out,
-                                int64_t* out2, void* stream) {
-  if (tp <= 0 || T <= 0 || stride < T) return SSD_ERR_SHAPE;
-  hipLaunchKernelGGL(argmax_merge_kernel, dim3((T + 63) / 64), dim3(64), 0, (hipStream_t)stream, vals, idxs, tp, T, stride, out, out2);
+extern "C" int ssd_argmax_merge(const float* vals, const int64_t* idxs, int tp, int T, long stride, long stride_idx,
+                                int64_t* out, int64_t* out2, void* stream) {
+  if (tp <= 0 || T <= 0 || stride < T || stride_idx < T) return SSD_ERR_SHAPE;
+  hipLaunchKernelGGL(argmax_merge_kernel, dim3((T + 63) / 64), dim3(64), 0, (hipStream_t)stream, vals, idxs, tp, T, stride,
+                     stride_idx, out, out2);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 

@@ -36,7 +36,7 @@ SIGNATURES = {
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "ssd_argmax_rows": [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "ssd_argmax_rows_val": [c_void_p, c_long, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p],
-    "ssd_argmax_merge": [c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p],
+    "ssd_argmax_merge": [c_void_p, c_void_p, c_int, c_int, c_long, c_long, c_void_p, c_void_p, c_void_p],
     "ssd_verify_greedy": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "ssd_fork_topf": [c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "ssd_comm_alloc": [C.POINTER(c_void_p), c_long],
@@ -46,6 +46,8 @@ SIGNATURES = {
     "ssd_comm_ipc_close": [c_void_p],
     "ssd_allreduce_bf16": [c_void_p, c_void_p, c_long, c_int, c_int, C.POINTER(c_void_p), C.POINTER(c_void_p), c_long,
                            c_void_p, c_void_p, c_long, c_void_p],
+    "ssd_allgather_u64": [c_void_p, c_void_p, c_long, c_int, c_int, C.POINTER(c_void_p), C.POINTER(c_void_p), c_long,
+                          c_void_p, c_void_p, c_long, c_void_p],
     "ssd_draft_advance": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
                           c_void_p, c_int, c_void_p],
 }

@@ -104,8 +104,9 @@ def argmax_rows_val(logits, ld: int, T: int, V: int, idx_offset: int, out_idx, o
            "ssd_argmax_rows_val")
 
 
-def argmax_merge(vals, idxs, tp: int, T: int, stride: int, out, out2=None):
-    _check(load_library().ssd_argmax_merge(_p(vals), _p(idxs), tp, T, stride, _p(out), _p(out2), _stream()), "ssd_argmax_merge")
+def argmax_merge(vals, idxs, tp: int, T: int, stride: int, out, out2=None, stride_idx: int | None = None):
+    _check(load_library().ssd_argmax_merge(_p(vals), _p(idxs), tp, T, stride, stride if stride_idx is None else stride_idx,
+                                           _p(out), _p(out2), _stream()), "ssd_argmax_merge")
 
 
 def verify_greedy(preds, speculations, B: int, K: int, accept_len, recovery, packed=None):

@@ -101,6 +101,10 @@ class HipDecoder:
         self.am_idx = z(tp_size, self.max_logit_rows, dtype=torch.int64)
         self.am_val_l = z(self.max_logit_rows, dtype=torch.float32)
         self.am_idx_l = z(self.max_logit_rows, dtype=torch.int64)
+        # packed form for the one-shot exchange: per rank [R int64 indices | R fp32 values (+ pad to 8 bytes)]
+        self.am_words = self.max_logit_rows + (self.max_logit_rows + 1) // 2
+        self.am_pack_l = z(self.am_words, dtype=torch.int64)
+        self.am_pack = z(tp_size, self.am_words, dtype=torch.int64)
 
     # ---------------------------------------------------------------------------------------------
     def load_weights(self, weight_iter) -> None:
@@ -292,8 +296,18 @@ class HipDecoder:
         if not self.use_coll:
             H.argmax_rows(self.logits, self.V, n, self.V, out, out2)
             return
-        H.argmax_rows_val(self.logits, self.V, n, self.V, self.tp_rank * self.V, self.am_idx_l, self.am_val_l)
         R = self.max_logit_rows
+        if self.custom_ar is not None:
+            # local (value, global index) straight into the packed buffer, one one-shot all-gather, merge
+            idx_l = self.am_pack_l[:R]
+            val_l = self.am_pack_l[R:].view(torch.float32)[:R]
+            H.argmax_rows_val(self.logits, self.V, n, self.V, self.tp_rank * self.V, idx_l, val_l)
+            self.custom_ar.all_gather_words(self.am_pack_l, self.am_pack, self.am_words)
+            # rank r's indices start at word r*am_words, its values R words later: one strided merge
+            vals = self.am_pack.view(-1)[R:].view(torch.float32)
+            H.argmax_merge(vals, self.am_pack, self.tp_size, n, 2 * self.am_words, out, out2, stride_idx=self.am_words)
+            return
+        H.argmax_rows_val(self.logits, self.V, n, self.V, self.tp_rank * self.V, self.am_idx_l, self.am_val_l)
         dist.all_gather_into_tensor(self.am_val.view(-1), self.am_val_l, group=self.tp_group)
         dist.all_gather_into_tensor(self.am_idx.view(-1), self.am_idx_l, group=self.tp_group)
         # gathered layout is [tp][R]; rows beyond n are ignored by the merge (T = n, stride R)

@@ -20,7 +20,7 @@ from ssd_amd.hip.lib import load_library
 
 SLOT_ELEMS = 1 << 19          # bf16 elements per staging slot (1 MiB); messages above this go to RCCL
 FLAG_BYTES = 4096
-SPIN_BUDGET = 20_000_000      # polls (~ seconds) before a wait gives up and sets the error word
+SPIN_BUDGET = 100_000_000     # polls (~1 us each after the first 4096: ~100 s) before a wait gives up and sets the error word
 
 
 class OneShotAllReduce:
@@ -81,6 +81,14 @@ class OneShotAllReduce:
                                          torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             raise RuntimeError(f"ssd_allreduce_bf16 failed with code {rc}")
+
+    def all_gather_words(self, src: torch.Tensor, dst: torch.Tensor, n8: int) -> None:
+        """dst [world][n8] 8-byte words <- every rank's src[:n8] (device buffers, 8-byte aligned)."""
+        rc = self.lib.ssd_allgather_u64(src.data_ptr(), dst.data_ptr(), n8, self.rank, self.world, self.slots, self.flags,
+                                        SLOT_ELEMS, self.counters.data_ptr(), self.err.data_ptr(), SPIN_BUDGET,
+                                        torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"ssd_allgather_u64 failed with code {rc}")
 
     def failed(self) -> bool:
         return bool(self.err.item())
