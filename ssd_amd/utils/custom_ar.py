@@ -161,7 +161,9 @@ def _selftest_main() -> int:
 
 def validate_in_subprocess(rank: int, world: int, local_rank: int, port: int, timeout: float = 180.0) -> bool:
     """Spawn this rank's validation helper; True iff the whole helper group succeeded."""
-    env = dict(os.environ)
+    # under torchrun the workers carry TORCHELASTIC_USE_AGENT_STORE=True, which makes env:// rendezvous look for the
+    # agent's store on MASTER_PORT instead of creating one: the helpers form their own little group, so drop those
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC") and not k.startswith("TORCH_NCCL")}
     env.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank), MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -42,14 +42,22 @@ def init_process_group_if_needed(backend: str | None = None) -> tuple[int, int]:
             # SSD_DIST_BACKEND=gloo lets two ranks share ONE GPU in tests (RCCL refuses duplicate devices)
             backend = os.environ.get("SSD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", str(rank))))
+            torch.cuda.set_device(_local_device(rank))
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world
 
 
+def _local_device(rank: int) -> int:
+    """GPU index of this rank: LOCAL_RANK, unless SSD_LOCAL_DEVICE pins every rank to one GPU (single-GPU tests of
+    the multi-rank paths, together with SSD_DIST_BACKEND=gloo)."""
+    if "SSD_LOCAL_DEVICE" in os.environ:
+        return int(os.environ["SSD_LOCAL_DEVICE"])
+    return int(os.environ.get("LOCAL_RANK", str(rank)))
+
+
 def resolve_topology(config) -> Topology:
     rank, world = init_process_group_if_needed()
-    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    local = _local_device(rank)
     device = torch.device("cuda", local) if torch.cuda.is_available() else torch.device("cpu")
     if world == 1:
         assert config.num_gpus == 1, (f"num_gpus={config.num_gpus} needs one process per GPU: launch with "
