@@ -419,8 +419,81 @@ def gen_engine():
     print("engine_golden.npz written; seed", seed, "min margin", mm)
 
 
+
+
+def gen_scheduler():
+    """Drive the REFERENCE BlockManager / Scheduler / Sequence with a deterministic request stream (prefix sharing,
+    speculation lookahead, rollback, preemption under KV pressure, EOS / max_new_tokens) and record every externally
+    visible decision: scheduled ids, prefill/decode, block tables, cached-token counters, free-list size."""
+    import json
+    import random
+    from ssd.engine.scheduler import Scheduler
+    from ssd.engine.block_manager import BlockManager
+    from ssd.engine.sequence import Sequence
+    from ssd.sampling_params import SamplingParams
+    from collections import deque
+
+    traces = {}
+    for name, (speculate, K, nblocks, max_seqs) in {"ar": (False, 1, 24, 3), "spec": (True, 3, 40, 2), "tight": (True, 3, 14, 3)}.items():
+        rnd = random.Random(11)
+        bs = 16
+        Sequence.block_size = bs
+        Sequence.counter = __import__("itertools").count()
+        sch = Scheduler.__new__(Scheduler)      # bypass AutoTokenizer / Config: set exactly the fields __init__ sets
+        sch.max_num_seqs, sch.max_num_batched_tokens, sch.max_model_len = max_seqs, 256, 256
+        sch.eos, sch.speculate, sch.F, sch.K, sch.block_size, sch.verbose, sch.draft_async = 5, speculate, 3, K, bs, False, False
+        sch.fan_out_list = sch.fan_out_list_miss = None
+        sch.block_manager = BlockManager(nblocks, bs, is_draft=False, max_model_len=256)
+        if speculate:
+            sch.draft_block_manager = BlockManager(nblocks, bs, is_draft=True, speculate_k=K, max_model_len=256)
+        sch.waiting, sch.running = deque(), deque()
+        shared = [rnd.randrange(6, 200) for _ in range(40)]
+        reqs = []
+        for i in range(6):
+            n = rnd.randrange(5, 45)
+            toks = shared[:32] + [rnd.randrange(6, 200) for _ in range(n)] if i % 2 == 0 else [rnd.randrange(6, 200) for _ in range(n + 10)]
+            sp = SamplingParams(temperature=0.0, max_new_tokens=rnd.randrange(8, 30), ignore_eos=(i % 3 != 0))
+            reqs.append((toks, sp.max_new_tokens, sp.ignore_eos))
+            sch.add(Sequence(toks, sp))
+        events = []
+        for step in range(400):
+            if sch.is_finished():
+                break
+            seqs, is_prefill = sch.schedule()
+            ev = {"prefill": is_prefill, "ids": [s.seq_id for s in seqs], "bt": [list(s.block_table) for s in seqs],
+                  "dbt": [list(s.draft_block_table) for s in seqs], "cached": [s.num_cached_tokens for s in seqs],
+                  "dcached": [s.num_draft_cached_tokens for s in seqs], "free": len(sch.block_manager.free_block_ids)}
+            if not speculate:
+                toks = [rnd.randrange(5, 200) if rnd.random() > 0.05 else 5 for _ in seqs]
+                ev["tokens"] = toks
+                sch.postprocess(seqs, toks, is_prefill)
+            elif is_prefill:
+                for s in seqs:
+                    s.recovery_token_id = rnd.randrange(6, 200)
+                    s.num_cached_tokens = s.num_prompt_tokens
+                    s.num_draft_cached_tokens = s.num_prompt_tokens
+                ev["rec"] = [s.recovery_token_id for s in seqs]
+            else:
+                sfx, rec = [], []
+                for s in seqs:
+                    n = rnd.randrange(0, K + 1)
+                    sfx.append([s.recovery_token_id] + [rnd.randrange(5, 200) if rnd.random() > 0.04 else 5 for _ in range(n)])
+                    rec.append(rnd.randrange(6, 200))
+                ev["suffixes"], ev["rec"] = sfx, rec
+                sch.postprocess_speculate(seqs, sfx, rec)
+            ev["after_len"] = [s.num_tokens for s in seqs]
+            ev["finished"] = [s.is_finished for s in seqs]
+            ev["waiting"] = [s.seq_id for s in sch.waiting]
+            ev["running"] = [s.seq_id for s in sch.running]
+            events.append(ev)
+        traces[name] = {"speculate": speculate, "K": K, "nblocks": nblocks, "max_seqs": max_seqs, "reqs": reqs, "events": events}
+    with open(os.path.join(HERE, "scheduler_golden.json"), "w") as f:
+        json.dump(traces, f)
+    print("scheduler_golden.json written:", {k: len(v["events"]) for k, v in traces.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "logic", "llama", "qwen", "engine"]
+    which = sys.argv[1:] or ["ops", "logic", "llama", "qwen", "engine", "scheduler"]
     if "ops" in which:
         gen_ops()
     if "logic" in which:
@@ -431,3 +504,5 @@ if __name__ == "__main__":
         gen_tiny_qwen()
     if "engine" in which:
         gen_engine()
+    if "scheduler" in which:
+        gen_scheduler()
