@@ -281,3 +281,27 @@ def test_engine_async_ssd_loopback(gpu, golden, tag):
     if tag == "same":
         assert metrics["cache_hits"][0] == 0.0 and metrics["cache_hits"][1] == 1.0
         assert metrics["accepted_suffix_lens_with_recovery"][0] == K + 1
+
+
+def test_engine_batch_prefix_cache_and_preemption_gpu(gpu):
+    """b > 1 with shared prompt prefixes (block-level prefix-cache hits -> partial prefill through the page table) and a
+    KV pool small enough to force preemption; HIP engine vs the CPU oracle engine on the same synthetic weights.
+    Streams must agree up to near-ties (compared per sequence; at least the first 6 tokens)."""
+    from oracle.runner import oracle_runner_factory
+    from ssd_amd.engine.llm_engine import LLMEngine
+    from ssd_amd.model_config import ModelConfig
+    from ssd_amd.sampling_params import SamplingParams
+    t = ModelConfig("llama", 256, 2, 4, 2, 64, 512, 512, 1e-5, 5e5, 1024, False)
+    d = ModelConfig("llama", 128, 1, 2, 1, 64, 256, 512, 1e-5, 5e5, 1024, True)
+    shared = [(7 * j + 3) % 512 for j in range(40)]
+    prompts = [shared + [(11 * i + j) % 512 for j in range(5 + 3 * i)] for i in range(4)]
+    kw = dict(hf_config=t, draft="d", draft_hf_config=d, speculate=True, speculate_k=3, max_num_seqs=3, max_model_len=256,
+              max_num_batched_tokens=256, kvcache_block_size=16, num_kvcache_blocks=16, num_draft_kvcache_blocks=16, weights_std=0.1)
+    sp = SamplingParams(temperature=0, max_new_tokens=14, ignore_eos=True)
+    gpu_out, gm = LLMEngine("t", **kw).generate(prompts, sp, use_tqdm=False)
+    cpu_out, cm = LLMEngine("t", runner_factory=oracle_runner_factory(), **kw).generate(prompts, sp, use_tqdm=False)
+    for a, b in zip(gpu_out, cpu_out):
+        n = common_prefix(a["token_ids"], b["token_ids"])
+        print("prefix-cache/batch/preempt: identical tokens", n, "of", len(b["token_ids"]))
+        assert n >= 6
+    assert len(gpu_out) == 4 and all(len(o["token_ids"]) == 14 for o in gpu_out)
