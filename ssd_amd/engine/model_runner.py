@@ -39,6 +39,9 @@ class ModelRunner:
         self.max_blocks = config.max_blocks
         self.K = config.speculate_k if config.speculate else 0
         self.max_bs = config.max_num_seqs
+        # prefill admits by token budget, not by max_num_seqs (reference scheduler.py:69-86): per-sequence buffers hold
+        # seq_cap sequences and larger prefill batches are run in slices
+        self.seq_cap = max(self.max_bs, 16)
         torch.cuda.set_device(device)
 
         mq = config.MQ_LEN if (config.speculate and config.draft_async) else 0
@@ -48,7 +51,7 @@ class ModelRunner:
         self.model = HipDecoder(model_cfg, max_tokens=max_tokens, max_seqs=self.max_bs, max_blocks=self.max_blocks,
                                 block_size=self.block_size, max_model_len=config.max_model_len, device=device,
                                 tp_rank=tp_rank, tp_size=tp_size, tp_group=tp_group,
-                                max_logit_rows=max(self.max_decode_tokens, self.max_bs),
+                                max_logit_rows=max(self.max_decode_tokens, self.seq_cap),
                                 max_split_tokens=max(256, self.max_decode_tokens), force_collectives=force_collectives)
         if weight_source is not None:
             src = weight_source
@@ -74,7 +77,7 @@ class ModelRunner:
         self.model.alloc_kv(num_kvcache_blocks)
 
         # ---- static inputs (device) + pinned host staging ----
-        T, B = max_tokens, self.max_bs
+        T, B = max_tokens, self.seq_cap
         dev = dict(device=device)
         self.d_ids = torch.zeros(T, dtype=torch.int64, **dev)
         self.d_pos = torch.zeros(T, dtype=torch.int64, **dev)
@@ -298,6 +301,12 @@ class ModelRunner:
         """ModelRunner.run (model_runner.py:634-680).  Greedy only on this path (temperature 0): returns token
         ids (last_only) or the flat logits [B*(K+1), V] (verify with last_only=False)."""
         B = len(seqs)
+        if is_prefill and B > self.seq_cap:
+            assert not draft_return_logits
+            toks = []
+            for i in range(0, B, self.seq_cap):
+                toks.extend(self.run(seqs[i:i + self.seq_cap], True, last_only))
+            return toks
         if is_prefill:
             T, max_q = self._prepare_prefill(seqs)
             self.model.forward(self.d_ids, self.d_pos, T, self._meta("prefill", B, max_q))
@@ -394,6 +403,10 @@ class ModelRunner:
 
     @torch.inference_mode()
     def draft_prefill(self, token_lists, tables) -> None:
+        if len(token_lists) > self.seq_cap:
+            for i in range(0, len(token_lists), self.seq_cap):
+                self.draft_prefill(token_lists[i:i + self.seq_cap], tables[i:i + self.seq_cap])
+            return
         ids, pos, slots, ctx, cu, gather = [], [], [], [], [0], []
         max_q = 0
         for toks, tb in zip(token_lists, tables):
