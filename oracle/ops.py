@@ -241,3 +241,93 @@ def fork_topf(logits: torch.Tensor, returned_tokens: torch.Tensor, fan_out_lists
             toks.extend(order[b, j, :fan_out_lists[b][j]].tolist())
         rows.append(toks)
     return torch.tensor(rows, dtype=torch.int64)
+
+
+# --------------------------------------------------------------------------------------------------
+# temperature > 0 (stochastic) -- same torch RNG call sequence as the reference, so with the same manual seed the
+# CPU results are identical to the reference's (pinned in tests/test_oracle_golden.py::test_verify_stochastic)
+# --------------------------------------------------------------------------------------------------
+def sample(logits: torch.Tensor, temperatures: torch.Tensor) -> torch.Tensor:
+    """Sampler.forward -- ssd/layers/sampler.py:15-36 (without sampler_x): greedy where T == 0, else
+    argmax(softmax(logits / T) / Exp(1))."""
+    lg = logits.to(torch.float)
+    greedy = lg.argmax(dim=-1)
+    lg = lg / temperatures.unsqueeze(1)
+    probs = torch.softmax(lg, dim=-1, dtype=torch.float)
+    scores = probs.div_(torch.empty_like(probs).exponential_(1) + 1e-10)
+    return torch.where(temperatures == 0, greedy, scores.argmax(dim=-1))
+
+
+def verify_full(logits_p, logits_q, speculations, temps_t, temps_q, cache_hits=None, jit_speculate=False):
+    """verify() -- ssd/utils/verify.py:5-181 (sampler_x = None).  Returns (suffixes, recovery, accept_probs or None)."""
+    B, Kp1, V = logits_p.shape
+    K = Kp1 - 1
+    draft = speculations[:, 1:]
+    preds_p = logits_p.argmax(dim=-1)
+    matches = draft == preds_p[:, :-1]
+    any_mis = (~matches).any(dim=1)
+    first_mis = (~matches).int().argmax(dim=1)
+    accept_greedy = torch.where(any_mis, first_mis, torch.full_like(first_mis, K))
+    bidx = torch.arange(B)
+    rec_greedy = preds_p[bidx, accept_greedy]
+    base = (temps_t > 0) | (temps_q > 0)
+    if jit_speculate:
+        ratio_rows = base
+    else:
+        ratio_rows = base & (cache_hits.to(torch.bool) if cache_hits is not None else torch.zeros_like(base))
+    do_ratio = bool(ratio_rows.any())
+    need_p = bool((temps_t > 0).any()) or do_ratio
+    probs_p = None
+    if need_p:
+        probs_p = torch.zeros(B, Kp1, V, dtype=torch.float32)
+        nz = temps_t > 0
+        if nz.any():
+            t = temps_t[nz].unsqueeze(1).unsqueeze(2).clamp(min=1e-8)
+            probs_p[nz] = torch.softmax((logits_p[nz] / t).to(torch.float32), dim=-1)
+        if (~nz).any():
+            oh = torch.zeros_like(logits_p[~nz], dtype=torch.float32)
+            oh.scatter_(2, logits_p[~nz].argmax(dim=-1).unsqueeze(-1), 1.0)
+            probs_p[~nz] = oh
+    accept_probs = None
+    if do_ratio:
+        probs_q = torch.zeros(B, K, V, dtype=torch.float32)
+        nzq = temps_q > 0
+        if nzq.any():
+            tq = temps_q[nzq].unsqueeze(1).unsqueeze(2).clamp(min=1e-8)
+            probs_q[nzq] = torch.softmax((logits_q[nzq] / tq).to(torch.float32), dim=-1)
+        if (~nzq).any():
+            ohq = torch.zeros_like(logits_q[~nzq], dtype=torch.float32)
+            ohq.scatter_(2, logits_q[~nzq].argmax(dim=-1).unsqueeze(-1), 1.0)
+            probs_q[~nzq] = ohq
+        gi = draft.unsqueeze(2)
+        p_vals = probs_p[:, :K, :].gather(2, gi).squeeze(2)
+        q_vals = probs_q.gather(2, gi).squeeze(2)
+        accept_probs = (p_vals / (q_vals + 1e-10)).clamp(max=1.0)
+        rand = torch.rand_like(accept_probs)
+        accepts = rand <= accept_probs
+        rej_any = (~accepts).any(dim=1)
+        first_rej = (~accepts).int().argmax(dim=1)
+        accept_ratio = torch.where(rej_any, first_rej, torch.full_like(first_rej, K))
+        accept_until = torch.where(ratio_rows, accept_ratio, accept_greedy)
+    else:
+        accept_until = accept_greedy
+    if probs_p is None:
+        rec_ratio = rec_greedy
+    else:
+        p_fb = probs_p[bidx, accept_until]
+        fb = p_fb / p_fb.sum(dim=1, keepdim=True)
+        if do_ratio:
+            q_slice = probs_q[bidx, accept_until.clamp(max=K - 1)]
+            mask_adjust = (temps_t > 0) & (accept_until < K) & ratio_rows
+            adj = (p_fb - q_slice).clamp(min=0.0)
+            sums = adj.sum(dim=1, keepdim=True)
+            adj_norm = torch.where(sums > 0, adj / sums, fb)
+            r1 = torch.multinomial(adj_norm, 1).squeeze(1)
+            r2 = torch.multinomial(fb, 1).squeeze(1)
+            rec_ratio = torch.where(mask_adjust, r1, r2)
+        else:
+            rec_ratio = torch.multinomial(fb, 1).squeeze(1)
+    rec = torch.where(temps_t > 0, rec_ratio, rec_greedy)
+    starts = speculations[:, 0].tolist()
+    sfx = [[starts[b]] + draft[b, :n].tolist() for b, n in enumerate(accept_until.tolist())]
+    return sfx, rec.tolist(), accept_probs

@@ -492,8 +492,34 @@ def gen_scheduler():
     print("scheduler_golden.json written:", {k: len(v["events"]) for k, v in traces.items()})
 
 
+def gen_stochastic():
+    """verify() with temperature > 0 (ratio acceptance, residual resampling, hit/miss rows, jit) and Sampler, under fixed
+    torch CPU seeds -- the oracle restatement makes the same RNG calls in the same order and must reproduce them."""
+    torch.manual_seed(7)
+    B, K, V = 6, 4, 50
+    lp = torch.randn(B, K + 1, V).to(BF)
+    lq = torch.randn(B, K, V).to(BF)
+    spec = torch.randint(0, V, (B, K + 1))
+    spec[:, 1:] = lq.argmax(-1)
+    tt = torch.tensor([0.7, 0.0, 1.0, 0.5, 0.0, 1.3])
+    tq = torch.tensor([0.7, 0.0, 0.0, 0.9, 0.6, 1.3])
+    hits = torch.tensor([1, 1, 0, 1, 1, 0])
+    out = {"lp": lp, "lq": lq, "spec": spec, "tt": tt, "tq": tq, "hits": hits}
+    for jit in (0, 1):
+        torch.manual_seed(123)
+        sfx, rec = verify(lp, lq, spec, tt, tq, cache_hits=hits, jit_speculate=bool(jit))
+        flat = torch.full((B, K + 1), -1, dtype=torch.int64)
+        for b, s_ in enumerate(sfx):
+            flat[b, :len(s_)] = torch.tensor(s_)
+        out[f"sfx{jit}"], out[f"rec{jit}"] = flat, torch.tensor(rec)
+    torch.manual_seed(5)
+    out["sample"] = Sampler()(lp[:, 0].clone(), tt)
+    save_npz(os.path.join(HERE, "stochastic_golden.npz"), out)
+    print("stochastic_golden.npz written")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "logic", "llama", "qwen", "engine", "scheduler"]
+    which = sys.argv[1:] or ["ops", "logic", "llama", "qwen", "engine", "scheduler", "stochastic"]
     if "ops" in which:
         gen_ops()
     if "logic" in which:
@@ -506,3 +532,5 @@ if __name__ == "__main__":
         gen_engine()
     if "scheduler" in which:
         gen_scheduler()
+    if "stochastic" in which:
+        gen_stochastic()

@@ -168,3 +168,18 @@ def test_tiny_qwen3_forward(golden):
                   Ctx("verify", slot_mapping=slots(table, range(P, P + n)), context_lens=torch.tensor([P + n], dtype=torch.int32),
                       block_tables=bt, cu_q=torch.tensor([0, n], dtype=torch.int32)))
     assert_ulp(m.compute_logits(h), g["verify_logits"], max_ulp=0, max_frac=0.0)
+
+
+def test_verify_stochastic_and_sampler(golden):
+    """Temperature > 0: the oracle issues the reference's torch RNG calls in the same order, so a fixed CPU seed pins
+    ratio acceptance, residual resampling, hit/miss rows, the jit switch and the exponential-noise sampler exactly."""
+    g = golden("stochastic_golden")
+    for jit in (0, 1):
+        torch.manual_seed(123)
+        sfx, rec, _ = O.verify_full(g["lp"], g["lq"], g["spec"], g["tt"], g["tq"], cache_hits=g["hits"], jit_speculate=bool(jit))
+        for b, s in enumerate(sfx):
+            assert s == g[f"sfx{jit}"][b, :len(s)].tolist()
+            assert int((g[f"sfx{jit}"][b] >= 0).sum()) == len(s)
+        assert rec == g[f"rec{jit}"].tolist()
+    torch.manual_seed(5)
+    assert torch.equal(O.sample(g["lp"][:, 0].clone(), g["tt"]), g["sample"])
