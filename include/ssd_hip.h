@@ -153,6 +153,10 @@ int ssd_draft_advance(const int64_t* next, int64_t* input_ids, int64_t* position
                       int32_t* context_lens, const int32_t* block_tables, int max_blocks, int block_size,
                       int64_t* spec, int K, int32_t* step, int B, void* stream);
 
+/* logits_q[b][*step] <- src row b (bf16 [B][K][V]); collects the draft logits of a device-side chain step
+ * (torch.stack(logits_q), ssd/engine/speculator_sync.py:58,67). */
+int ssd_store_step_rows(const void* src_rows, long src_ld, void* dst, int B, int V, int K, const int32_t* step, void* stream);
+
 /* One-shot full-mesh all-reduce (sum, bf16 in/out, fp32 accumulate in rank order) over hipIpc-shared fine-grained
  * buffers -- replaces dist.all_reduce after o_proj / down_proj / the embedding (ssd/layers/linear.py:195-199,
  * ssd/layers/embed_head.py:53-56) for the small decode-time messages; csrc/comm.hip describes the protocol.

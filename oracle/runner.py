@@ -57,6 +57,15 @@ class OracleRunner:
     def call(self, method, *args):
         return getattr(self, method)(*args)
 
+    def _temps(self, seqs):
+        return torch.tensor([float(s.draft_temperature) if (self.is_draft and s.draft_temperature is not None) else float(s.temperature)
+                             for s in seqs])
+
+    def _pick(self, lg, seqs):
+        """Sampler.forward (sampler.py:15-36): greedy rows at temperature 0, exponential-noise draw otherwise."""
+        t = self._temps(seqs)
+        return (O.sample(lg, t) if bool((t > 0).any()) else O.argmax_rows(lg)).tolist()
+
     @torch.inference_mode()
     def run(self, seqs, is_prefill: bool, last_only: bool = True, draft_return_logits: bool = False):
         if is_prefill:
@@ -75,7 +84,7 @@ class OracleRunner:
                       block_tables=self._bt(seqs) if paged else None)
             h = self.model.forward(torch.tensor(ids), torch.tensor(pos), ctx)
             lg = self._logits(h[(cu_q_t[1:] - 1).long()])
-            toks = O.argmax_rows(lg).tolist()
+            toks = self._pick(lg, seqs)
             return (toks, lg) if draft_return_logits else toks
         if not last_only:
             lg = self._verify_logits(seqs, None)
@@ -87,7 +96,7 @@ class OracleRunner:
             slots.append(self._slot(self._table(s), len(s) - 1))
             ctx_lens.append(len(s))
         lg = self._decode(ids, pos, slots, ctx_lens, self._bt(seqs))
-        toks = O.argmax_rows(lg).tolist()
+        toks = self._pick(lg, seqs)
         return (toks, lg) if draft_return_logits else toks
 
     def _decode(self, ids, pos, slots, ctx_lens, bt):
@@ -118,21 +127,33 @@ class OracleRunner:
         spec[:, 0] = torch.tensor(recovery_tokens)
         cur = list(recovery_tokens)
         bt = self._bt(seqs)
+        lq = []
         for k in range(K + 1):
             pos = [len(s) - 1 + k for s in seqs]
             slots = [self._slot(self._table(s), p) for s, p in zip(seqs, pos)]
             lg = self._decode(cur, pos, slots, [p + 1 for p in pos], bt)
             if k == K:
                 break
-            cur = O.argmax_rows(lg).tolist()
+            lq.append(lg)
+            cur = self._pick(lg, seqs)
             spec[:, k + 1] = torch.tensor(cur)
+        self._lq = torch.stack(lq, dim=1)
         return spec
 
+    def logits_q(self, B):
+        return self._lq[:B]
+
     @torch.inference_mode()
-    def verify_chain(self, seqs, speculations):
+    def verify_chain(self, seqs, speculations, logits_q=None, temps_q=None, ratio_rows=None):
         B, K = len(seqs), self.K
         lg = self._verify_logits(seqs, speculations).view(B, K + 1, -1)
-        return O.verify_suffixes(lg, speculations)
+        if temps_q is None:
+            return O.verify_suffixes(lg, speculations)
+        # verify() with explicit ratio rows == jit_speculate=True on the rows flagged, greedy fallback elsewhere
+        sfx, rec, _ = O.verify_full(lg, logits_q if logits_q is not None else torch.zeros(B, K, lg.shape[-1], dtype=lg.dtype),
+                                    speculations, self._temps(seqs), torch.tensor(temps_q), cache_hits=torch.tensor(ratio_rows),
+                                    jit_speculate=False)
+        return sfx, rec
 
     # ---- draft-server operations of asynchronous speculation (explicit arrays, no Sequence objects) ----
     def zeros_tokens(self, B, K):

@@ -38,3 +38,20 @@ extern "C" int ssd_draft_advance(const int64_t* next, int64_t* input_ids, int64_
                      slots, context_lens, block_tables, max_blocks, block_size, spec, K, step, B);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
+
+// Keep the draft's logits of chain step `*step` as logits_q[b][step] (SpeculatorSync collects them with torch.stack,
+// reference ssd/engine/speculator_sync.py:58,67); the step index lives on the device so the launch is graph-replayable.
+__global__ void store_step_rows_kernel(const u32x4_t* __restrict__ src, long src_ld8, u32x4_t* __restrict__ dst, int V8, int K,
+                                       const int32_t* __restrict__ step) {
+  const int b = blockIdx.x, s = *step;
+  if (s >= K) return;
+  for (int c = threadIdx.x; c < V8; c += blockDim.x) dst[((size_t)b * K + s) * V8 + c] = src[(size_t)b * src_ld8 + c];
+}
+
+extern "C" int ssd_store_step_rows(const void* src_rows, long src_ld, void* dst, int B, int V, int K, const int32_t* step,
+                                   void* stream) {
+  if (B <= 0 || V <= 0 || (V & 7) || (src_ld & 7) || K <= 0) return SSD_ERR_SHAPE;
+  hipLaunchKernelGGL(store_step_rows_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, (const u32x4_t*)src_rows, src_ld / 8,
+                     (u32x4_t*)dst, V / 8, K, step);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}

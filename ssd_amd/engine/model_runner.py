@@ -127,6 +127,21 @@ class ModelRunner:
         except Exception:
             m.custom_ar = None
 
+    def _ensure_stochastic(self) -> None:
+        """Buffers of the temperature > 0 path (allocated on first use: the benchmark configs are greedy)."""
+        if hasattr(self, "d_rng"):
+            return
+        B, K, V = self.seq_cap, max(self.K, 1), self.cfg.vocab_size
+        dev = dict(device=self.device)
+        self.d_rng = torch.tensor([0x5D5D0000 + (7 if self.is_draft else 3) + 1000 * self.config.weights_seed], dtype=torch.int64, **dev)
+        self.d_temps = torch.zeros(B, dtype=torch.float32, **dev)       # temperatures this model samples with
+        self.d_temps_q = torch.zeros(B, dtype=torch.float32, **dev)     # (target) the draft's temperatures
+        self.d_ratio = torch.zeros(B, dtype=torch.int32, **dev)
+        self.d_lse_p = torch.zeros(B * (K + 1), dtype=torch.float32, **dev)
+        self.d_lse_q = torch.zeros(B * K, dtype=torch.float32, **dev)
+        if self.is_draft:
+            self.d_logits_q = torch.zeros(B, K, V, dtype=torch.bfloat16, **dev)
+
     def _check_collectives(self) -> None:
         ar = self.model.custom_ar
         if ar is not None and ar.failed():
@@ -249,20 +264,38 @@ class ModelRunner:
         are keyed by its power-of-two bucket because the attention decomposition is fixed at capture."""
         self._ctx_hint = HipDecoder.ctx_bucket(max_ctx)
 
-    def _body_decode(self, B: int, chain: bool, head: bool = True) -> None:
+    def _body_decode(self, B: int, chain: bool, head: bool = True, sample: bool = False) -> None:
         self.model.forward(self.d_ids, self.d_pos, B, self._meta("decode", B))
         if not head:        # KV deposit only (the (K+1)-th draft forward, speculator_sync.py:55-56): no LM head / sampling
             return
         self.model.compute_logits(B)
-        self.model.argmax(B, self.d_next)
+        if sample:          # temperature > 0: keep logits_q for the ratio test and draw with the Gumbel-max sampler
+            lg = self.model.full_logits(B)
+            V = self.cfg.vocab_size
+            if chain:
+                H.store_step_rows(lg, V, self.d_logits_q, B, V, self.K, self.d_step)
+            H.sample_rows(lg, V, B, V, self.d_temps, 1, self.d_rng, 1, self.d_next)
+            H.rng_advance(self.d_rng)
+        else:
+            self.model.argmax(B, self.d_next)
         if chain:
             H.draft_advance(self.d_next, self.d_ids, self.d_pos, self.d_slots, self.d_ctx, self.d_bt, self.max_blocks,
                             self.block_size, self.d_spec, self.K, self.d_step, B)
 
-    def _body_verify(self, B: int, greedy_tail: bool) -> None:
+    def _body_verify(self, B: int, greedy_tail: bool, logits_q=None) -> None:
         T = B * (self.K + 1)
         self.model.forward(self.d_ids, self.d_pos, T, self._meta("verify", B))
         self.model.compute_logits(T)
+        if logits_q is not None:     # temperature > 0: ratio acceptance + residual resampling (utils/verify.py:50-167)
+            K, V = self.K, self.cfg.vocab_size
+            lg = self.model.full_logits(T)
+            self.model.argmax(T, self.d_next)
+            H.row_lse(lg, V, T, V, self.d_temps, K + 1, self.d_lse_p)
+            H.row_lse(logits_q, V, B * K, V, self.d_temps_q, K, self.d_lse_q)
+            H.verify_ratio(lg, V, logits_q, V, V, B, K, self.d_ids, self.d_next, self.d_lse_p, self.d_lse_q, self.d_temps,
+                           self.d_temps_q, self.d_ratio, self.d_rng, 2, self.d_accept, self.d_recovery, self.d_packed)
+            H.rng_advance(self.d_rng)
+            return
         if greedy_tail:
             self.model.argmax(T, self.d_next)
             H.verify_greedy(self.d_next, self.d_ids, B, self.K, self.d_accept, self.d_recovery, self.d_packed)
@@ -311,7 +344,7 @@ class ModelRunner:
             T, max_q = self._prepare_prefill(seqs)
             self.model.forward(self.d_ids, self.d_pos, T, self._meta("prefill", B, max_q))
             self.model.compute_logits(T, gather=self.d_gather, rows=B)
-            self.model.argmax(B, self.d_next)
+            self._sample_or_argmax(seqs, B)
             toks = self._read_tokens(B)
             return (toks, self.model.full_logits(B)) if draft_return_logits else toks
         if not last_only:
@@ -321,11 +354,34 @@ class ModelRunner:
                 self.graphs[("verify_logits", B, self._ctx_hint)].replay()
             return self.model.full_logits(T)
         self._prepare_decode(seqs)
-        if self._launch(("decode", B), lambda: self._body_decode(B, False)) == "captured":
+        temps = self._seq_temps(seqs)
+        if any(t > 0 for t in temps):       # autoregressive sampling (AutoRegressiveStep at temperature > 0)
+            self._ensure_stochastic()
+            self._upload(self.d_temps, temps, torch.float32)
+            if self._launch(("decode_s", B), lambda: self._body_decode(B, False, sample=True)) == "captured":
+                self._prepare_decode(seqs)
+                self.graphs[("decode_s", B, self._ctx_hint)].replay()
+        elif self._launch(("decode", B), lambda: self._body_decode(B, False)) == "captured":
             self._prepare_decode(seqs)
             self.graphs[("decode", B, self._ctx_hint)].replay()
         toks = self._read_tokens(B)
         return (toks, self.model.full_logits(B)) if draft_return_logits else toks
+
+    def _seq_temps(self, seqs) -> list[float]:
+        """prepare_sample (model_runner.py:542-550): the draft uses draft_temperature when given."""
+        return [float(s.draft_temperature) if (self.is_draft and s.draft_temperature is not None) else float(s.temperature)
+                for s in seqs]
+
+    def _sample_or_argmax(self, seqs, B: int) -> None:
+        temps = self._seq_temps(seqs)
+        if any(t > 0 for t in temps):
+            self._ensure_stochastic()
+            self._upload(self.d_temps, temps, torch.float32)
+            V = self.cfg.vocab_size
+            H.sample_rows(self.model.full_logits(B), V, B, V, self.d_temps, 1, self.d_rng, 3, self.d_next)
+            H.rng_advance(self.d_rng)
+        else:
+            self.model.argmax(B, self.d_next)
 
     def _read_tokens(self, n: int) -> list[int]:
         self.h_next[:n].copy_(self.d_next[:n], non_blocking=True)
@@ -340,16 +396,22 @@ class ModelRunner:
         from the recovery token at position N = len(seq) - 1 (the caller has appended it).  Returns the device
         tensor speculations [B, K+1] = (recovery, x_1..x_K); nothing is read back."""
         B, K = len(seqs), self.K
-        key = ("decode_chain", B)
+        temps = self._seq_temps(seqs)
+        sample = any(t > 0 for t in temps)
+        key = ("decode_chain_s" if sample else "decode_chain", B)
+        if sample:
+            self._ensure_stochastic()
 
         def stage():
             self._prepare_decode(seqs)
             self.d_step.zero_()
             self.d_spec[:B, 0].copy_(self.d_ids[:B])
+            if sample:
+                self._upload(self.d_temps, temps, torch.float32)
 
         stage()
         first = 0
-        if self._launch(key, lambda: self._body_decode(B, True)) == "captured":
+        if self._launch(key, lambda: self._body_decode(B, True, sample=sample)) == "captured":
             stage()                      # the warm-up + capture runs disturbed the chained state
         else:
             first = 1
@@ -358,26 +420,45 @@ class ModelRunner:
             if g is not None:
                 g.replay()
             else:
-                self._body_decode(B, True)
+                self._body_decode(B, True, sample=sample)
         # the (K+1)-th forward only deposits x_K's KV: same inputs (already advanced on the device), no LM head
         if self._launch(("decode_deposit", B), lambda: self._body_decode(B, False, head=False)) == "captured":
             self.graphs[("decode_deposit", B, self._ctx_hint)].replay()     # idempotent: same token, same slot
         return self.d_spec[:B]
 
     @torch.inference_mode()
-    def verify_chain(self, seqs, speculations: torch.Tensor):
+    def logits_q(self, B: int) -> torch.Tensor:
+        """[B, K, V] draft logits of the last sampled chain (temperature > 0 only)."""
+        return self.d_logits_q[:B]
+
+    def verify_chain(self, seqs, speculations: torch.Tensor, logits_q=None, temps_q=None, ratio_rows=None):
         """Target forward over the K+1 speculated tokens + greedy accept/reject on the device
         (Verifier.verify + verify(), verifier.py:54-153, utils/verify.py:5-48).  One packed D2H copy.
         Returns (new_suffixes, recovery_tokens)."""
         B, K = len(seqs), self.K
-        key = ("verify", B)
+        stochastic = temps_q is not None
+        key = ("verify_s" if stochastic else "verify", B)
+        if stochastic:
+            self._ensure_stochastic()
+            if logits_q is None:        # greedy draft under a sampling target: q is one-hot, its logits are never read
+                if not hasattr(self, "_lq_dummy"):
+                    self._lq_dummy = torch.zeros(self.seq_cap, K, self.cfg.vocab_size, dtype=torch.bfloat16, device=self.device)
+                logits_q = self._lq_dummy[:B]
+            assert logits_q.is_contiguous() and tuple(logits_q.shape) == (B, K, self.cfg.vocab_size)
+            if getattr(self, "_lq_ptr", None) not in (None, logits_q.data_ptr()):
+                self.graphs = {k: v for k, v in self.graphs.items() if k[0] != "verify_s"}   # pointer is baked in the graph
+            self._lq_ptr = logits_q.data_ptr()
 
         def stage():
             self._prepare_verify(seqs, ids_from_seq=False)
             self.d_ids[:B * (K + 1)].copy_(speculations.reshape(-1))
+            if stochastic:
+                self._upload(self.d_temps, self._seq_temps(seqs), torch.float32)
+                self._upload(self.d_temps_q, [float(t) for t in temps_q], torch.float32)
+                self._upload(self.d_ratio, [int(r) for r in ratio_rows], torch.int32)
 
         stage()
-        if self._launch(key, lambda: self._body_verify(B, True)) == "captured":
+        if self._launch(key, lambda: self._body_verify(B, True, logits_q=logits_q)) == "captured":
             stage()
             self.graphs[(*key, self._ctx_hint)].replay()
         self.h_packed[:B].copy_(self.d_packed[:B], non_blocking=True)

@@ -35,9 +35,10 @@ class SpeculatorSync(SpeculatorBase):
             recovery.append(seq.recovery_token_id)
             seq.append_token(seq.recovery_token_id)
         speculations = self.draft_model_runner.speculate_chain(seqs, recovery)
+        sampled = any((s.draft_temperature if s.draft_temperature is not None else s.temperature) > 0 for s in seqs)
         for seq in seqs:
             for _ in range(K):
                 seq.append_token(PLACEHOLDER)
             seq.num_draft_cached_tokens += K + 1
         # logits_q is only read on the temperature > 0 ratio path (ssd/utils/verify.py:50-64)
-        return SpeculateResult(speculations, None)
+        return SpeculateResult(speculations, self.draft_model_runner.logits_q(len(seqs)) if sampled else None)

@@ -24,11 +24,21 @@ class Verifier(VerifierBase):
         return VerifyResult([], [seq.recovery_token_id for seq in seqs], None)
 
     def verify(self, seqs, speculate_result: SpeculateResult, eagle: bool = False) -> VerifyResult:
-        for seq in seqs:
-            if seq.temperature != 0 or (seq.draft_temperature or 0) != 0:
-                raise NotImplementedError("stochastic verification (temperature > 0) is a 'next' row (SURVEY.md 8f)")
+        temps_t = [float(s.temperature) for s in seqs]
+        temps_q = [float(s.draft_temperature) if s.draft_temperature is not None else float(s.temperature) for s in seqs]
         t0 = perf_counter()
-        new_suffixes, recovery = self.target_model_runner.verify_chain(seqs, speculate_result.speculations)
+        if any(t > 0 for t in temps_t + temps_q):
+            if self.sampler_x is not None:
+                raise NotImplementedError("sampler_x rescaling of the draft distribution is not implemented")
+            # rows whose draft tokens really came from q: JIT speculation, or a speculation-cache hit (verify.py:57-62)
+            hits = speculate_result.cache_hits
+            hl = None if hits is None else (hits if isinstance(hits, list) else hits.tolist())
+            ratio = [1 if (self.jit_speculate or (hl is not None and hl[b] == 1)) else 0 for b in range(len(seqs))]
+            new_suffixes, recovery = self.target_model_runner.verify_chain(seqs, speculate_result.speculations,
+                                                                           logits_q=speculate_result.logits_q,
+                                                                           temps_q=temps_q, ratio_rows=ratio)
+        else:
+            new_suffixes, recovery = self.target_model_runner.verify_chain(seqs, speculate_result.speculations)
         for seq in seqs:
             seq.num_cached_tokens += self.lookahead + 1
         self.metrics.setdefault("target_verify_times", []).append(perf_counter() - t0)

@@ -53,6 +53,7 @@ SIGNATURES = {
     "ssd_row_lse": [c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p],
     "ssd_verify_ratio": [c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                          c_void_p, c_void_p, c_void_p, c_void_p, C.c_uint, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "ssd_store_step_rows": [c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "ssd_draft_advance": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
                           c_void_p, c_int, c_void_p],
 }

@@ -144,3 +144,7 @@ def verify_ratio(logits_p, ld_p: int, logits_q, ld_q: int, V: int, B: int, K: in
                                            _p(lse_q), _p(temps_t), _p(temps_q), _p(ratio_rows), _p(rng_state), salt,
                                            _p(accept_len), _p(recovery), _p(packed), _p(accept_prob), _stream()),
            "ssd_verify_ratio")
+
+
+def store_step_rows(src, src_ld: int, dst, B: int, V: int, K: int, step):
+    _check(load_library().ssd_store_step_rows(_p(src), src_ld, _p(dst), B, V, K, _p(step), _stream()), "ssd_store_step_rows")

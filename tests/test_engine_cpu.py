@@ -92,3 +92,49 @@ def test_batch_of_sequences_and_eos():
     b, _ = sd2.generate(prompts, sp2, use_tqdm=False)
     assert [o["token_ids"] for o in a] == [o["token_ids"] for o in b]
     assert a[0]["token_ids"][-1] == eos and len(a[0]["token_ids"]) <= 3
+
+
+def _tiny_pair():
+    cfg = ModelConfig("llama", 64, 2, 2, 1, 32, 128, 256, 1e-5, 5e5, 512, False)
+    dcfg = ModelConfig("llama", 64, 1, 2, 1, 32, 128, 256, 1e-5, 5e5, 512, False)
+    kw = dict(max_model_len=256, max_num_batched_tokens=256, kvcache_block_size=16, num_kvcache_blocks=40, weights_std=0.1)
+    return cfg, dcfg, kw
+
+
+def test_temperature_sd_draft_equals_target_accepts_everything():
+    """verify.py:50-120 -- with q == p the ratio min(1, p/q) is 1 at every position, so a JIT-speculating sync draft
+    at temperature > 0 has every token accepted; without jit_speculate the sync path has no cache hits and the
+    acceptance rule falls back to the greedy comparison (verify.py:57-62), so sampled drafts get rejected."""
+    cfg, _, kw = _tiny_pair()
+    prompts = [[3, 9, 27, 81, 243 % 256], [5, 6, 7]]
+    sp = SamplingParams(temperature=0.9, max_new_tokens=16, ignore_eos=True)
+    torch.manual_seed(0)
+    eng = LLMEngine("t", hf_config=cfg, draft="d", draft_hf_config=cfg, speculate=True, speculate_k=3, max_num_seqs=2,
+                    jit_speculate=True, draft_weights_seed=0, weights_seed=0, runner_factory=oracle_runner_factory(), **kw)
+    out, m = eng.generate(prompts, sp, use_tqdm=False)
+    assert all(n == 4 for n in m["accepted_suffix_lens_with_recovery"])
+    assert all(len(o["token_ids"]) == 16 for o in out)
+    torch.manual_seed(0)
+    eng2 = LLMEngine("t", hf_config=cfg, draft="d", draft_hf_config=cfg, speculate=True, speculate_k=3, max_num_seqs=2,
+                     draft_weights_seed=0, weights_seed=0, runner_factory=oracle_runner_factory(), **kw)
+    _, m2 = eng2.generate(prompts, sp, use_tqdm=False)
+    assert min(m2["accepted_suffix_lens_with_recovery"]) < 4
+
+
+def test_temperature_mixed_batch_and_greedy_draft():
+    """Per-sequence temperatures in one batch (greedy rows keep the exact greedy stream), and a greedy draft under a
+    sampling target (draft_temperature=0: q is one-hot, acceptance probability is p(x))."""
+    cfg, dcfg, kw = _tiny_pair()
+    prompts = [[(7 * i + j) % 256 for j in range(5 + 3 * i)] for i in range(3)]
+    sps = [SamplingParams(temperature=0, max_new_tokens=12, ignore_eos=True),
+           SamplingParams(temperature=1.0, max_new_tokens=12, ignore_eos=True),
+           SamplingParams(temperature=0.7, draft_temperature=0.0, max_new_tokens=12, ignore_eos=True)]
+    ar = LLMEngine("t", hf_config=cfg, max_num_seqs=4, runner_factory=oracle_runner_factory(), **kw)
+    ref, _ = ar.generate(prompts[:1], sps[0], use_tqdm=False)
+    torch.manual_seed(1)
+    sd = LLMEngine("t", hf_config=cfg, draft="d", draft_hf_config=dcfg, speculate=True, speculate_k=3, max_num_seqs=4,
+                   jit_speculate=True, runner_factory=oracle_runner_factory(), **kw)
+    got, m = sd.generate(prompts, sps, use_tqdm=False)
+    assert got[0]["token_ids"] == ref[0]["token_ids"]
+    assert all(len(o["token_ids"]) == 12 for o in got)
+    assert all(0 <= t < cfg.vocab_size for o in got for t in o["token_ids"])
