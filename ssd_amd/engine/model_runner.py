@@ -426,11 +426,11 @@ class ModelRunner:
             self.graphs[("decode_deposit", B, self._ctx_hint)].replay()     # idempotent: same token, same slot
         return self.d_spec[:B]
 
-    @torch.inference_mode()
     def logits_q(self, B: int) -> torch.Tensor:
         """[B, K, V] draft logits of the last sampled chain (temperature > 0 only)."""
         return self.d_logits_q[:B]
 
+    @torch.inference_mode()
     def verify_chain(self, seqs, speculations: torch.Tensor, logits_q=None, temps_q=None, ratio_rows=None):
         """Target forward over the K+1 speculated tokens + greedy accept/reject on the device
         (Verifier.verify + verify(), verifier.py:54-153, utils/verify.py:5-48).  One packed D2H copy.

@@ -32,6 +32,23 @@ KW = dict(max_model_len=128, max_num_batched_tokens=1024, kvcache_block_size=16,
 PROMPT = [(5 * j + 1) % 128 for j in range(9)]
 
 
+def perturbed_pair(noise: float):
+    """Target weights and a draft of the same architecture whose weights are the target's plus noise: a correlated
+    draft, so that both the accept and the reject/residual branches are exercised."""
+    from ssd_amd import weights as W
+    from ssd_amd.engine.llm_engine import hip_runner_factory
+    t, _ = cfgs()
+    wt = W.synthetic_state_dict(t, 0, KW["weights_std"])
+    g = torch.Generator().manual_seed(99)
+    wd = {k: (v.float() + noise * KW["weights_std"] * torch.randn(v.shape, generator=g)).to(v.dtype) if "norm" not in k else v
+          for k, v in wt.items()}
+
+    def factory(config, model_cfg, *, is_draft, topo, **kw):
+        ws = wd if is_draft else wt
+        return hip_runner_factory(config, model_cfg, is_draft=is_draft, topo=topo, weight_source=iter(ws.items()), **kw)
+    return t, factory
+
+
 def two_sample_ok(a: torch.Tensor, b: torch.Tensor, V: int, what: str):
     from scipy.stats import chi2_contingency
     ca, cb = torch.bincount(a, minlength=V).double(), torch.bincount(b, minlength=V).double()
@@ -57,18 +74,18 @@ def draw(eng, sp, rounds, per_round, n_new):
 def test_speculative_sampling_matches_autoregressive_distribution(gpu, draft_temp):
     from ssd_amd.engine.llm_engine import LLMEngine
     from ssd_amd.sampling_params import SamplingParams
-    t, d = cfgs()
+    t, factory = perturbed_pair(0.03)
     B, R, n_new = 48, 40, 5
     sp = SamplingParams(temperature=0.7, draft_temperature=draft_temp, max_new_tokens=n_new, ignore_eos=True)
-    ar = LLMEngine("t", hf_config=t, max_num_seqs=B, **KW)
+    ar = LLMEngine("t", hf_config=t, max_num_seqs=B, runner_factory=factory, **KW)
     a, _ = draw(ar, SamplingParams(temperature=0.7, max_new_tokens=n_new, ignore_eos=True), R, B, n_new)
     del ar
-    sd = LLMEngine("t", hf_config=t, draft="d", draft_hf_config=d, speculate=True, speculate_k=3, max_num_seqs=B,
-                   jit_speculate=True, **KW)
+    sd = LLMEngine("t", hf_config=t, draft="d", draft_hf_config=t, speculate=True, speculate_k=3, max_num_seqs=B,
+                   jit_speculate=True, runner_factory=factory, **KW)
     s, lens = draw(sd, sp, R, B, n_new)
     print("mean accepted (+recovery):", sum(lens) / len(lens), "distinct tokens at pos 1:", a[:, 1].unique().numel())
     assert a[:, 1].unique().numel() >= 8, "degenerate test distribution"
-    assert 1.0 < sum(lens) / len(lens) < 4.0          # some accepted, some rejected: both branches exercised
+    assert 1.4 < sum(lens) / len(lens) < 3.8          # some accepted, some rejected: both branches exercised
     for pos in range(1, n_new):
         two_sample_ok(a[:, pos], s[:, pos], t.vocab_size, f"marginal of generated position {pos} (draft_temp={draft_temp})")
 
