@@ -71,6 +71,18 @@ int ssd_gemm_wf(const void* x_frag, const void* w_frag, const void* bias, void* 
 int ssd_gemm_wf_cfg(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K, int ldy,
                     int epilogue, int nt, int waves, void* stream);
 
+/* Prefill-chunk GEMM, 16 < M <= 128 (csrc/gemm_pf.hip): the reference's eager prefill F.linear calls
+ * (ssd/engine/model_runner.py:602 -> ssd/layers/linear.py:65,98,196).  Same operands and epilogues (SSD_EPI_ROWS,
+ * SSD_EPI_SILU_FRAG) as ssd_gemm_wf; the x tile of a k-step is shared by a workgroup through LDS and K is split
+ * across workgroups into fp32 partials in `workspace` (>= ssd_gemm_pf_workspace_bytes), summed in a fixed order.
+ * N % 128 == 0, K % 128 == 0; splits <= 0 picks the default. */
+int ssd_gemm_pf_workspace_bytes(int M, int N, int K, int64_t* bytes);
+int ssd_gemm_pf(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K, int ldy,
+                int epilogue, void* workspace, int64_t workspace_bytes, int splits, void* stream);
+/* Same with an explicit decomposition: nt = 16-row groups per wave (2 or 4; a workgroup owns 4*nt), splits of K. */
+int ssd_gemm_pf_cfg(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K, int ldy,
+                    int epilogue, void* workspace, int64_t workspace_bytes, int nt, int splits, void* stream);
+
 /* Fused decode-layer GEMM for M <= 16 (csrc/gemm_fused.hip): [residual add + RMSNorm] -> F.linear ->
  * [RoPE + paged KV store | SiLU*mul | rows] in ONE launch; replaces add_norm_forward (layernorm.py:76-88) + F.linear
  * (linear.py:97-98) + RotaryEmbedding.forward (rotary_embedding.py:40-60) + store_kvcache (attention.py:10-41), or

@@ -34,6 +34,7 @@ struct AttnParams {
   int mode;                  // 0 = causal (bottom-right aligned), 1 = tree
   int tree_K, tree_mq, tree_step, tree_F;
   int splits, use_tr, p_split;
+  int bs_shift;              // log2(bs); block sizes are powers of two >= 16
   float scale_log2e;
 };
 
@@ -48,7 +49,7 @@ __device__ __forceinline__ const bf16_t* kv_row(const bf16_t* base, const int32_
 template <int HD, int RT>
 constexpr int attn_region_bytes() { return RT * 16 * HD * 4 + RT * 16 * 8; }
 
-template <int HD, int RT>
+template <int HD, int RT, int KT>
 __global__ void __launch_bounds__(512) attn_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int DS = HD / 32;  // k-steps of QK^T
@@ -94,17 +95,15 @@ __global__ void __launch_bounds__(512) attn_kernel(const AttnParams p) {
     }
   }
 
-  // ---- key range of this (grid split z, wave) pair, derived on device so the launch is capture-static ----
+  // ---- key tiles of this (grid split z, wave) pair: 32-key tiles dealt round-robin over all parts, so the
+  // first tile's address needs nothing but the wave index (its page-table entry loads in parallel with ctx) ----
   int kmax = ctx;
   if (p.mode == 0) {  // rows of this tile never look past the last row's causal limit
     const int last_row = min(rows - 1, (tile_base + RT) * 16 - 1);
     kmax = ctx - (Tq - 1 - last_row / G);
   }
-  const int parts = p.splits * W;
-  int chunk = (kmax + parts - 1) / parts;
-  chunk = ((chunk + 31) >> 5) << 5;
-  const int k_begin = (z * W + wave) * chunk;
-  const int k_end = min(kmax, k_begin + chunk);
+  const int stride = p.splits * W * 32;
+  int k0 = (z * W + wave) * 32;
 
   float m[RT], lsum[RT];
   f32x4_t o[RT][DT];
@@ -115,33 +114,101 @@ __global__ void __launch_bounds__(512) attn_kernel(const AttnParams p) {
     for (int dt = 0; dt < DT; ++dt) o[rt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
 
-  for (int k0 = k_begin; k0 < k_end; k0 += 32) {
-    // -- stage the V tile [32 keys][HD] into this wave's LDS region as DT sub-tiles of [32 keys][16 d] --
-    constexpr int CH = HD / 8;  // 16-byte chunks per key row
+  constexpr int CH = HD / 8;             // 16-byte chunks per key row
+  constexpr int NV = (32 * CH) / 64;     // V chunks per lane per tile
+  // page-table entries of a tile are wave-uniform (scalar loads): keys k..k+15 share a page and so do k+16..k+31
+  // (block sizes are multiples of 16); a key clamped to ctx-1 falls into one of the two.  The index is clamped to
+  // the table, not to ctx, so the lookup can be issued before ctx is known; entries past ctx are never used.
+  auto blk = [&](int key) { return key >> p.bs_shift; };   // block sizes are powers of two (checked on the host)
+  auto pages = [&](int kt, int& pa, int& pb) {
+    pa = bt[min(blk(kt), p.max_blocks - 1)];
+    pb = bt[min(blk(kt + 16), p.max_blocks - 1)];
+  };
+  // Addresses = a wave-uniform 64-bit base per (tile, 16-key half) + a 32-bit per-lane offset.  Rows past ctx-1 are
+  // clamped to the last valid row of the tile (never an unwritten row, never an unallocated page): if the second half
+  // starts at or past ctx it is redirected to the first half's page.
+  auto half_base = [&](const bf16_t* base, int page, int key0) -> const char* {
+    return reinterpret_cast<const char*>(base + (((size_t)page * p.nkv + h) * p.bs + (key0 & (p.bs - 1))) * HD);
+  };
+  auto issue_k = [&](int kt, int pa, int pb, u32x4_t (&kf)[2][DS]) {
+    const int cl = ctx - 1 - kt;                  // >= 0 for every tile we touch
+    const bool bvalid = cl >= 16;
+    const char* b0 = half_base(p.kc, pa, kt);
+    const char* b1 = bvalid ? half_base(p.kc, pb, kt + 16) : b0;
+    const uint32_t o0 = (uint32_t)(min(r16, cl) * HD + g4 * 8) * 2u;
+    const uint32_t o1 = (uint32_t)(min(r16, bvalid ? cl - 16 : cl) * HD + g4 * 8) * 2u;
 #pragma unroll
-    for (int it = 0; it < (32 * CH) / 64; ++it) {
+    for (int ds = 0; ds < DS; ++ds) {
+      kf[0][ds] = *reinterpret_cast<const u32x4_t*>(b0 + o0 + ds * 64);
+      kf[1][ds] = *reinterpret_cast<const u32x4_t*>(b1 + o1 + ds * 64);
+    }
+  };
+  auto issue_v = [&](int kt, int pa, int pb, u32x4_t (&vf)[NV]) {
+    const int cl = ctx - 1 - kt;
+    const bool bvalid = cl >= 16;
+    const char* b0 = half_base(p.vc, pa, kt);
+    const char* b1 = bvalid ? half_base(p.vc, pb, kt + 16) : b0;
+    const int clb = bvalid ? cl - 16 : cl;
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+      constexpr int KPI = 64 / CH;                // keys covered by one 64-lane pass
+      const int key = it * KPI + lane / CH;       // 0..31; the half is static per `it`
+      const bool second = (it * KPI) >= 16;
+      const int r = second ? min(key - 16, clb) : min(key, cl);
+      const uint32_t off = (uint32_t)(r * HD + (lane % CH) * 8) * 2u;
+      vf[it] = *reinterpret_cast<const u32x4_t*>((second ? b1 : b0) + off);
+    }
+  };
+
+  // KT tiles are in flight per wave: their K/V loads are issued together and a slot's registers are refilled with
+  // the tile KT ahead as soon as they have been consumed (the loads fly during the softmax and P.V of this and the
+  // following tiles); the page entries for that refill were fetched (scalar loads) one round earlier.
+  constexpr bool PIPE_K = !(HD == 128 && RT == 2);   // the widest variant has no registers to hold K ahead of time
+  u32x4_t kreg[KT][2][DS], vreg[KT][NV];
+  int ca[KT], cb[KT], na[KT], nb[KT];
+#pragma unroll
+  for (int j = 0; j < KT; ++j) {
+    pages(k0 + j * stride, ca[j], cb[j]);
+    pages(k0 + (j + KT) * stride, na[j], nb[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < KT; ++j)
+    if (k0 + j * stride < kmax) {
+      if constexpr (PIPE_K) issue_k(k0 + j * stride, ca[j], cb[j], kreg[j]);
+      issue_v(k0 + j * stride, ca[j], cb[j], vreg[j]);
+    }
+
+  for (; k0 < kmax; k0 += KT * stride) {
+#pragma unroll
+   for (int j = 0; j < KT; ++j) {
+    const int kt = k0 + j * stride;        // this tile
+    if (kt >= kmax) break;                 // wave-uniform
+    const int kn = kt + KT * stride;       // the tile that refills slot j
+    const bool more = kn < kmax;
+    if constexpr (!PIPE_K) issue_k(kt, ca[j], cb[j], kreg[j]);
+    // -- stage the V tile [32 keys][HD] into this wave's LDS region as DT sub-tiles of [32 keys][16 d] --
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
       const int c = it * 64 + lane;
       const int key = c / CH, d8 = c % CH;
-      const int kk = min(k0 + key, ctx - 1);
-      const u32x4_t v = *reinterpret_cast<const u32x4_t*>(kv_row<HD>(p.vc, bt, kk, h, p.nkv, p.bs) + d8 * 8);
-      *reinterpret_cast<u32x4_t*>(vlds + ((d8 >> 1) * 32 + key) * 16 + (d8 & 1) * 8) = v;
+      *reinterpret_cast<u32x4_t*>(vlds + ((d8 >> 1) * 32 + key) * 16 + (d8 & 1) * 8) = vreg[j][it];
     }
+    if (more) issue_v(kn, na[j], nb[j], vreg[j]);
     // -- S^T = K . Q^T --
     f32x4_t st[2][RT];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
-      const int kk = min(k0 + hf * 16 + r16, ctx - 1);
-      const bf16_t* kp = kv_row<HD>(p.kc, bt, kk, h, p.nkv, p.bs) + g4 * 8;
-      u32x4_t kf[DS];
-#pragma unroll
-      for (int ds = 0; ds < DS; ++ds) kf[ds] = *reinterpret_cast<const u32x4_t*>(kp + ds * 32);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         st[hf][rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ds = 0; ds < DS; ++ds) st[hf][rt] = mfma16(kf[ds], qf[rt][ds], st[hf][rt]);
+        for (int ds = 0; ds < DS; ++ds) st[hf][rt] = mfma16(kreg[j][hf][ds], qf[rt][ds], st[hf][rt]);
       }
     }
+    if constexpr (PIPE_K) { if (more) issue_k(kn, na[j], nb[j], kreg[j]); }
+    ca[j] = na[j]; cb[j] = nb[j];
+    pages(kn + KT * stride, na[j], nb[j]);
+    const int k0t = kt;
     // -- mask + online softmax; P^T stays in the accumulator layout --
     u32x4_t pf[RT], pl[RT];
 #pragma unroll
@@ -152,8 +219,8 @@ __global__ void __launch_bounds__(512) attn_kernel(const AttnParams p) {
       for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int key = k0 + hf * 16 + g4 * 4 + r;
-          bool ok = rvalid[rt] && key < k_end;
+          const int key = k0t + hf * 16 + g4 * 4 + r;
+          bool ok = rvalid[rt] && key < kmax;
           if (p.mode == 0) {
             ok = ok && key < lim[rt];
           } else {
@@ -223,6 +290,7 @@ __global__ void __launch_bounds__(512) attn_kernel(const AttnParams p) {
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
+   }
   }
 
   // ---- epilogue ----
@@ -335,10 +403,10 @@ __global__ void attn_combine_kernel(const float* __restrict__ ws_o, const float*
   }
 }
 
-template <int HD, int RT>
+template <int HD, int RT, int KT>
 static int attn_launch_rt(const AttnParams& p, dim3 grid, int waves, hipStream_t st) {
   const int lds = waves * attn_region_bytes<HD, RT>();
-  auto kern = attn_kernel<HD, RT>;
+  auto kern = attn_kernel<HD, RT, KT>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
     return SSD_ERR_LAUNCH;
@@ -346,13 +414,17 @@ static int attn_launch_rt(const AttnParams& p, dim3 grid, int waves, hipStream_t
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
+// Row tiles per workgroup: two for prefill-sized query blocks (K/V bytes shared by 32 rows), one for the decode-side
+// shapes (more workgroups: the scan is bound by per-CU load bandwidth and latency, not by K/V bytes).
 template <int HD>
 static int attn_launch(const AttnParams& p, int B, int T, int max_q, int waves, hipStream_t st) {
   const int G = p.nh / p.nkv;
   const int row_tiles = (max_q * G + 15) / 16;
-  const int rt = row_tiles >= 2 ? 2 : 1;
+  const int rt = row_tiles > 4 ? 2 : 1;
   dim3 grid((row_tiles + rt - 1) / rt, B * p.nkv, p.splits);
-  const int rc = rt == 2 ? attn_launch_rt<HD, 2>(p, grid, waves, st) : attn_launch_rt<HD, 1>(p, grid, waves, st);
+  // one key tile in flight per wave (KT = 1): measured on MI355X, KT = 2/4 buy nothing -- with 8 waves per workgroup
+  // the scan is bound by the handful of CUs it occupies, not by a single wave's load latency
+  const int rc = rt == 2 ? attn_launch_rt<HD, 2, 1>(p, grid, waves, st) : attn_launch_rt<HD, 1, 1>(p, grid, waves, st);
   if (rc != SSD_OK) return rc;
   if (p.splits > 1) {
     hipLaunchKernelGGL((attn_combine_kernel<HD>), dim3(T * p.nh), dim3(HD / 4), 0, st, p.ws_o, p.ws_ml, p.splits, p.nh,
@@ -370,6 +442,7 @@ extern "C" int ssd_attn_paged(const void* q_rows, const void* k_cache, const voi
                               void* out_rows, void* out_frag, void* stream) {
   if (B <= 0 || T <= 0 || max_q <= 0 || nh <= 0 || nkv <= 0 || nh % nkv) return SSD_ERR_SHAPE;
   if (hd != 64 && hd != 128) return SSD_ERR_SHAPE;
+  if (block_size < 16 || (block_size & (block_size - 1)) != 0 || max_blocks <= 0) return SSD_ERR_SHAPE;
   if (((nh * hd) & 31) != 0) return SSD_ERR_SHAPE;
   if (splits < 1) return SSD_ERR_ARG;
   if (splits > 1 && (!ws_o || !ws_ml)) return SSD_ERR_ARG;
@@ -379,6 +452,7 @@ extern "C" int ssd_attn_paged(const void* q_rows, const void* k_cache, const voi
   p.block_tables = block_tables; p.context_lens = context_lens; p.cu_q = cu_q; p.tree_jidx = tree_jidx;
   p.ws_o = (float*)ws_o; p.ws_ml = (float*)ws_ml; p.out_rows = (bf16_t*)out_rows; p.out_frag = (u32x2_t*)out_frag;
   p.max_blocks = max_blocks; p.q_per_seq = q_per_seq; p.nh = nh; p.nkv = nkv; p.bs = block_size;
+  p.bs_shift = __builtin_ctz(block_size);
   p.mode = mode; p.tree_K = tree_K; p.tree_mq = tree_mq; p.tree_step = tree_step; p.tree_F = tree_F;
   p.splits = splits; p.use_tr = (flags & 1) ? 0 : 1; p.p_split = (flags & 2) ? 0 : 1;
   p.scale_log2e = scale * 1.4426950408889634f;

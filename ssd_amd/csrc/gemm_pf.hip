@@ -1,0 +1,236 @@
+// Prefill GEMM  y[M,N] = x[M,K] . W[N,K]^T  for 32 < M <= 128 token rows (one prefill chunk).  Replaces the cuBLAS
+// F.linear calls of the reference's eager prefill (ssd/layers/linear.py:65,98,196; model_runner.py:602).
+//
+// Still HBM-bound on MI355X (128 FLOP/B against a ridge of ~312), but unlike the skinny kernel (gemm.hip) the x
+// operand is no longer negligible: a wave that owns NT row groups of W needs 128/(16 NT) bytes of x per byte of W.
+// Measured with gemm_wf_kernel<8,2>: every CU pulls 5 bytes through L2 per weight byte and the GEMM runs at ~2.5 TB/s.
+// Here:
+//  * a workgroup = 4 waves that own 4*NT ADJACENT row groups (256 rows of W for NT = 4) over the same K range, so the
+//    x tile of a k-step ([128 rows] x [32 k] = 8 KiB, fragment-major) is fetched from L2 ONCE per workgroup, staged in
+//    LDS (double-buffered ring, one barrier per k-step) and read by all four waves as ready-made MFMA B operands:
+//    0.5 bytes of x per byte of W;
+//  * W streams HBM -> VGPRs as before (1 KiB fragment tiles, non-temporal, U k-steps in flight per wave);
+//  * N alone gives too few workgroups (N = 8192 -> 32), so K is split across gridDim.y and every split writes its
+//    fp32 partial tile to a workspace; gemm_pf_epilogue_kernel sums the splits in a fixed order (deterministic, no
+//    atomics), adds the bias, rounds once to bf16 and applies the same epilogues as gemm.hip (rows | SiLU*mul ->
+//    fragment-major).  The partials are ~6-25 % extra traffic and mostly live in the 256 MiB Infinity Cache.
+#include "common.h"
+
+enum { PF_EPI_ROWS = 0, PF_EPI_SILU_FRAG = 1 };
+
+constexpr int PF_WAVES = 4;
+constexpr int PF_U = 4;      // k-steps of W in flight per wave; every K split is a multiple of this many k-steps
+
+template <int MT, int NT>
+__global__ void __launch_bounds__(256, 2)
+gemm_pf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, float* __restrict__ ws,
+               int M, int N, int K, int kt_per_split, int mt_valid) {
+  __shared__ u32x4_t xs[2][MT][64];                      // ring of two k-steps, MT fragment tiles each
+  constexpr int U = PF_U;                                 // W k-steps in flight per wave
+  constexpr int FPW = (MT + PF_WAVES - 1) / PF_WAVES;     // x fragment tiles each wave fetches per k-step
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int KT = K >> 5;
+  const int g0 = (blockIdx.x * PF_WAVES + wave) * NT;     // first row group of this wave
+  const int kz0 = blockIdx.y * kt_per_split;
+  const int nk = kt_per_split;                            // multiple of U, >= U (host-checked)
+
+  f32x4_t acc[NT][MT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const u32x4_t* wp = Wf + (((size_t)g0 * KT + kz0) << 6) + lane;
+  const size_t wstride = (size_t)KT << 6;
+  // x fragment tiles this wave stages: mt = wave + PF_WAVES * f (clamped to a valid tile; extra rows are never stored)
+  const u32x4_t* xp[FPW];
+  int xmt[FPW];
+#pragma unroll
+  for (int f = 0; f < FPW; ++f) {
+    xmt[f] = wave + PF_WAVES * f;
+    const int src = min(xmt[f], mt_valid - 1);
+    xp[f] = Xf + (((size_t)src * KT + kz0) << 6) + lane;
+  }
+
+  u32x4_t a[U][NT], xr[2][FPW];
+  auto load_w = [&](u32x4_t (&d)[NT], int kt) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) d[nt] = __builtin_nontemporal_load(wp + nt * wstride + ((size_t)kt << 6));
+  };
+  auto load_x = [&](u32x4_t (&d)[FPW], int kt) {
+#pragma unroll
+    for (int f = 0; f < FPW; ++f) d[f] = xp[f][(size_t)kt << 6];
+  };
+  auto stage_x = [&](const u32x4_t (&d)[FPW], int slot) {
+#pragma unroll
+    for (int f = 0; f < FPW; ++f)
+      if (xmt[f] < MT) xs[slot][xmt[f]][lane] = d[f];
+  };
+  auto compute = [&](const u32x4_t (&w)[NT], int slot) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const u32x4_t b = xs[slot][mt][lane];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = mfma16(w[nt], b, acc[nt][mt]);
+    }
+  };
+
+  // prologue: x(0) -> LDS slot 0; x(1), x(2) in registers; W(0..U-1) in flight.
+  // Every load in the loop is issued unconditionally (tail iterations re-read the last k-step instead of being
+  // predicated off), so the number of loads in flight is static and the compiler can wait for exactly the one it
+  // needs (s_waitcnt vmcnt(n > 0)) instead of draining the queue at every k-step.
+  load_x(xr[0], 0);
+#pragma unroll
+  for (int u = 0; u < U; ++u) load_w(a[u], u);
+  load_x(xr[1], 1);
+  stage_x(xr[0], 0);
+  load_x(xr[0], 2);          // nk >= U = 4 > 2
+  __syncthreads();
+  const int klast = nk - 1;
+  for (int kt = 0; kt < nk; kt += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = kt + u;
+      // x(k+1) registers (parity (k+1)&1, loaded two k-steps ago) -> the other ring slot, whose last readers
+      // finished before the previous barrier; then the freed registers fetch x(k+3)
+      stage_x(xr[(u + 1) & 1], (u + 1) & 1);
+      load_x(xr[(u + 1) & 1], min(k + 3, klast));
+      compute(a[u], u & 1);
+      load_w(a[u], min(k + U, klast));
+      __syncthreads();
+    }
+  }
+
+  // fp32 partial tile of this split: ws[z][m][n]
+  float* out = ws + (size_t)blockIdx.y * M * N;
+  const int mcol = lane & 15, nrow = (lane >> 4) * 4;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = (g0 + nt) * 16 + nrow;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mt * 16 + mcol;
+      if (m < M) *reinterpret_cast<f32x4_t*>(out + (size_t)m * N + n) = acc[nt][mt];
+    }
+  }
+}
+
+// Sum the K-splits in order, + bias, one rounding to bf16, then the same epilogues as gemm.hip.
+template <int EPI>
+__global__ void __launch_bounds__(256)
+gemm_pf_epilogue_kernel(const float* __restrict__ ws, const bf16_t* __restrict__ bias, void* __restrict__ Yv,
+                        int M, int N, int splits, int ldy) {
+  const size_t MN = (size_t)M * N;
+  if (EPI == PF_EPI_ROWS) {
+    const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= MN) return;
+    const int m = (int)(i4 / N), n = (int)(i4 % N);
+    f32x4_t s = *reinterpret_cast<const f32x4_t*>(ws + i4);
+    for (int z = 1; z < splits; ++z) s += *reinterpret_cast<const f32x4_t*>(ws + z * MN + i4);
+    if (bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[r] += bf2f(bias[n + r]);
+    }
+    const u32x2_t v = {pack_bf2(s[0], s[1]), pack_bf2(s[2], s[3])};
+    *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(Yv) + (size_t)m * ldy + n) = v;
+  } else {
+    // W row groups come in (gate, up) pairs; act = silu(bf16(g)) * bf16(u) in fp32, one rounding
+    // (ssd/layers/activation.py:11-14 as compiled), written fragment-major as down_proj's input (K' = N/2)
+    const int half = N >> 1;
+    const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= (size_t)M * half) return;
+    const int m = (int)(i4 / half), f = (int)(i4 % half);          // f .. f+3 inside one 16-feature group
+    const int ng = ((f >> 4) * 2) * 16 + (f & 15), nu = ng + 16;
+    f32x4_t g = *reinterpret_cast<const f32x4_t*>(ws + (size_t)m * N + ng);
+    f32x4_t u = *reinterpret_cast<const f32x4_t*>(ws + (size_t)m * N + nu);
+    for (int z = 1; z < splits; ++z) {
+      g += *reinterpret_cast<const f32x4_t*>(ws + z * MN + (size_t)m * N + ng);
+      u += *reinterpret_cast<const f32x4_t*>(ws + z * MN + (size_t)m * N + nu);
+    }
+    float o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float gb = g[r], ub = u[r];
+      if (bias) { gb += bf2f(bias[ng + r]); ub += bf2f(bias[nu + r]); }
+      gb = round_bf(gb); ub = round_bf(ub);
+      o[r] = (gb / (1.0f + __expf(-gb))) * ub;
+    }
+    const u32x2_t v = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+    reinterpret_cast<u32x2_t*>(Yv)[frag_chunk(m, f >> 3, half >> 5) * 2 + ((f >> 2) & 1)] = v;
+  }
+}
+
+template <int MT, int NT>
+static int pf_launch(const void* x, const void* w, float* ws, int M, int N, int K, int splits, hipStream_t st) {
+  const int KT = K >> 5;
+  dim3 grid(N / (16 * NT * PF_WAVES), splits);
+  hipLaunchKernelGGL((gemm_pf_kernel<MT, NT>), grid, dim3(64 * PF_WAVES), 0, st, (const u32x4_t*)w, (const u32x4_t*)x, ws,
+                     M, N, K, KT / splits, (M + 15) / 16);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
+// Default decomposition (measured on MI355X, profiles/micro/prefill_gemm_probe.py): about 160-256 workgroups fill the
+// chip; prefer the wide tile (nt = 4: half the x traffic) unless it needs more than 8 K-splits to get there, and the
+// fewest splits that do (each split costs M*N*8 bytes of partial traffic).
+static void pf_pick(int N, int K, int* nt_out, int* splits_out) {
+  const int KT = K >> 5;
+  auto fit = [&](int nt) {
+    if (N % (16 * nt * PF_WAVES) != 0) return 0;
+    const int blocks = N / (16 * nt * PF_WAVES);
+    int s = 1;
+    while (s < 16 && blocks * s < 160) s *= 2;
+    while (s > 1 && KT % (s * PF_U) != 0) s /= 2;
+    return s;
+  };
+  const int s4 = fit(4), s2 = fit(2);
+  if (s4 > 0 && (s4 <= 8 || s2 == 0)) { *nt_out = 4; *splits_out = s4; }
+  else { *nt_out = 2; *splits_out = s2; }
+}
+
+extern "C" int ssd_gemm_pf_workspace_bytes(int M, int N, int K, int64_t* bytes) {
+  if (!bytes || M <= 0 || N <= 0 || K <= 0 || N % (16 * 2 * PF_WAVES) != 0) return SSD_ERR_ARG;
+  int nt, splits;
+  pf_pick(N, K, &nt, &splits);
+  *bytes = (int64_t)splits * M * N * 4;
+  return SSD_OK;
+}
+
+extern "C" int ssd_gemm_pf_cfg(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K,
+                               int ldy, int epilogue, void* workspace, int64_t workspace_bytes, int nt, int splits,
+                               void* stream) {
+  if (M <= 16 || M > 128 || N <= 0 || K <= 0 || (K % (32 * PF_U))) return SSD_ERR_SHAPE;
+  if (epilogue != PF_EPI_ROWS && epilogue != PF_EPI_SILU_FRAG) return SSD_ERR_ARG;
+  if (nt != 2 && nt != 4) return SSD_ERR_ARG;
+  if (N % (16 * nt * PF_WAVES) != 0) return SSD_ERR_SHAPE;
+  const int KT = K >> 5;
+  if (splits <= 0) { int nt_d; pf_pick(N, K, &nt_d, &splits); if (nt_d != nt) splits = 1; }
+  if (KT % (splits * PF_U) != 0) return SSD_ERR_ARG;
+  if (!workspace || workspace_bytes < (int64_t)splits * M * N * 4) return SSD_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const int mt = (M + 15) / 16;
+  int rc;
+  if (mt <= 4) rc = nt == 4 ? pf_launch<4, 4>(x_frag, w_frag, ws, M, N, K, splits, st) : pf_launch<4, 2>(x_frag, w_frag, ws, M, N, K, splits, st);
+  else rc = nt == 4 ? pf_launch<8, 4>(x_frag, w_frag, ws, M, N, K, splits, st) : pf_launch<8, 2>(x_frag, w_frag, ws, M, N, K, splits, st);
+  if (rc != SSD_OK) return rc;
+  if (epilogue == PF_EPI_ROWS) {
+    const size_t items = (size_t)M * N / 4;
+    hipLaunchKernelGGL((gemm_pf_epilogue_kernel<PF_EPI_ROWS>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, ws,
+                       (const bf16_t*)bias, y, M, N, splits, ldy);
+  } else {
+    const size_t items = (size_t)M * (N / 2) / 4;
+    hipLaunchKernelGGL((gemm_pf_epilogue_kernel<PF_EPI_SILU_FRAG>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st,
+                       ws, (const bf16_t*)bias, y, M, N, splits, ldy);
+  }
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
+extern "C" int ssd_gemm_pf(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K,
+                           int ldy, int epilogue, void* workspace, int64_t workspace_bytes, int splits, void* stream) {
+  if (N <= 0 || K <= 0 || N % (16 * 2 * PF_WAVES) != 0) return SSD_ERR_SHAPE;
+  int nt, s;
+  pf_pick(N, K, &nt, &s);
+  if (splits > 0) s = splits;
+  return ssd_gemm_pf_cfg(x_frag, w_frag, bias, y, M, N, K, ldy, epilogue, workspace, workspace_bytes, nt, s, stream);
+}

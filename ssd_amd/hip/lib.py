@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
 _LIB = None
 
-c_void_p, c_int, c_long, c_float = C.c_void_p, C.c_int, C.c_long, C.c_float
+c_void_p, c_int, c_long, c_float, c_int64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_int64
 
 # name -> argtypes, exactly include/ssd_hip.h
 SIGNATURES = {
@@ -29,6 +29,9 @@ SIGNATURES = {
     "ssd_rmsnorm": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "ssd_gemm_wf": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "ssd_gemm_wf_cfg": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "ssd_gemm_pf_workspace_bytes": [c_int, c_int, c_int, c_void_p],
+    "ssd_gemm_pf": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int, c_void_p],
+    "ssd_gemm_pf_cfg": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int, c_int, c_void_p],
     "ssd_rope_store_kv": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "ssd_attn_paged": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

@@ -61,6 +61,25 @@ def gemm(x_frag, w_frag, y, M: int, N: int, K: int, ldy: int, epilogue: int = EP
     _check(rc, "ssd_gemm_wf")
 
 
+def gemm_pf_workspace_bytes(M: int, N: int, K: int) -> int:
+    import ctypes
+    out = ctypes.c_int64(0)
+    _check(load_library().ssd_gemm_pf_workspace_bytes(M, N, K, ctypes.addressof(out)), "ssd_gemm_pf_workspace_bytes")
+    return out.value
+
+
+def gemm_pf(x_frag, w_frag, y, M: int, N: int, K: int, ldy: int, workspace, epilogue: int = EPI_ROWS, bias=None, splits: int = 0,
+            nt: int = 0):
+    """Prefill-chunk GEMM (16 < M <= 128); workspace: a float32 device tensor of >= gemm_pf_workspace_bytes."""
+    wb = workspace.numel() * workspace.element_size()
+    if nt:
+        _check(load_library().ssd_gemm_pf_cfg(_p(x_frag), _p(w_frag), _p(bias), _p(y), M, N, K, ldy, epilogue, _p(workspace),
+                                              wb, nt, splits, _stream()), "ssd_gemm_pf_cfg")
+    else:
+        _check(load_library().ssd_gemm_pf(_p(x_frag), _p(w_frag), _p(bias), _p(y), M, N, K, ldy, epilogue, _p(workspace),
+                                          wb, splits, _stream()), "ssd_gemm_pf")
+
+
 def rope_store_kv(qkv_rows, positions, cos_sin, slot_mapping, q_out, k_cache, v_cache, T, nh, nkv, hd, block_size,
                   q_norm_w=None, k_norm_w=None, eps: float = 0.0, qkv_perm: int = 0):
     _check(load_library().ssd_rope_store_kv(_p(qkv_rows), _p(positions), _p(cos_sin), _p(slot_mapping), _p(q_out),

@@ -93,6 +93,7 @@ class HipDecoder:
         self.buf_lastf = z(H.frag_numel(self.max_logit_rows, self.h))
         self.logits = z(self.max_logit_rows, self.V)
         self.max_splits = 16
+        self._ws_pf = None           # fp32 split-K partials of the prefill GEMM, allocated by the first prefill
         st = min(T, max_split_tokens)
         self.ws_o = z(st * self.nh * self.max_splits * self.hd, dtype=torch.float32)
         self.ws_ml = z(st * self.nh * self.max_splits * 2, dtype=torch.float32)
@@ -159,16 +160,30 @@ class HipDecoder:
                                     dtype=BF16, device=self.device)
 
     # ---------------------------------------------------------------------------------------------
+    PF_MIN_WEIGHT_BYTES = 100 << 20
+
+    def _gemm_chunk(self, xf, K, w, N, y, m, ldy, epi, bias):
+        """One <= 128-row chunk.  Prefill-sized chunks of a big matrix go to the LDS-shared / split-K kernel
+        (csrc/gemm_pf.hip): measured on MI355X at M = 128, 70B layer GEMMs 611 -> 383 us, 8B gate_up 83 -> 62 us; small
+        matrices (<100 MB: too few workgroups without deep K-splits) stay on the skinny kernel."""
+        if m > 32 and 2 * N * K >= self.PF_MIN_WEIGHT_BYTES and N % 128 == 0 and K % 128 == 0:
+            need = H.gemm_pf_workspace_bytes(128, N, K) // 4
+            if self._ws_pf is None or self._ws_pf.numel() < need:
+                self._ws_pf = torch.empty(need, dtype=torch.float32, device=self.device)
+            H.gemm_pf(xf, w, y, m, N, K, ldy, self._ws_pf, epilogue=epi, bias=bias)
+        else:
+            H.gemm(xf, w, y, m, N, K, ldy, epi, bias)
+
     def _gemm(self, xf, K, w, N, y, T, ldy, epi=H.EPI_ROWS, bias=None):
         if T <= 128:
-            H.gemm(xf, w, y, T, N, K, ldy, epi, bias)
+            self._gemm_chunk(xf, K, w, N, y, T, ldy, epi, bias)
             return
         yf = y.view(-1)
         for m0 in range(0, T, 128):
             m = min(128, T - m0)
             x_off = (m0 // 16) * (K // 32) * 512
             y_off = (m0 // 16) * ((N // 2) // 32) * 512 if epi == H.EPI_SILU_FRAG else m0 * ldy
-            H.gemm(xf[x_off:], w, yf[y_off:], m, N, K, ldy, epi, bias)
+            self._gemm_chunk(xf[x_off:], K, w, N, yf[y_off:], m, ldy, epi, bias)
 
     def _allreduce(self, t):
         if not self.use_coll:
@@ -188,13 +203,17 @@ class HipDecoder:
 
     def _attn_cfg(self, T: int, meta: AttnMeta) -> tuple[int, int]:
         """(grid key-splits, waves per workgroup).  Up to 8 waves of one workgroup split the key range and merge
-        in LDS (one launch); grid splits + the merge kernel are added only when a wave would scan > 512 keys."""
+        in LDS (one launch).  A decode-side launch occupies only B*nkv*row_tiles CUs and each CU sustains a few
+        tens of GB/s of K/V loads, so beyond ~1K keys per workgroup the scan is spread over more workgroups with
+        grid key-splits + the merge kernel (measured on MI355X, 1B decode: ctx 2048 22 -> 13 us, 4096 39 -> 17 us;
+        below 1K keys the extra launch costs more than it saves)."""
         G = self.nh // self.nkv
-        groups = (-(-(meta.max_q * G) // 16) + 1) // 2
+        row_tiles = -(-(meta.max_q * G) // 16)
+        groups = -(-row_tiles // 2) if row_tiles > 4 else row_tiles       # csrc/attention.hip attn_launch
         base = max(1, groups * meta.B * self.nkv)
         waves = max(1, min(8, 512 // base))
         ctx = self.ctx_bucket(meta.ctx_hint if meta.ctx_hint > 0 else self.max_model_len)
-        splits = max(1, min(self.max_splits, -(-ctx // (waves * 512))))
+        splits = 1 if ctx <= 1024 else max(1, min(self.max_splits, ctx // 512))
         if base >= 256 or T > self.max_split_tokens:
             splits = 1
         return splits, waves

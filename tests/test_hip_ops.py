@@ -94,6 +94,43 @@ def test_gemm_configs_and_bias(H):
     assert torch.equal(y2.view(torch.int16), outs[-1].view(torch.int16))
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(128, 512, 4096, 0), (100, 1024, 512, 0), (17, 256, 1024, 2), (64, 256, 128, 1),
+                                          (33, 2048, 2048, 0), (128, 128, 8192, 16), (65, 384, 256, 0)])
+def test_gemm_prefill_vs_oracle(H, M, N, K, splits):
+    """csrc/gemm_pf.hip: x tile shared through LDS, K split across workgroups, fp32 partials summed in order."""
+    torch.manual_seed(M * 1000 + N + K)
+    x = torch.randn(M, K).to(BF)
+    w = (torch.randn(N, K) * 0.05).to(BF)
+    b = torch.randn(N).to(BF)
+    w[3, :] = 0.5
+    x[M - 1, : K // 2] = -1.0
+    xf, wf = to_frag_dev(x), to_frag_dev(w)
+    ws = torch.zeros(max(H.gemm_pf_workspace_bytes(M, N, K), 16 * M * N * 4) // 4, dtype=torch.float32, device="cuda")
+    for bias in (None, b):
+        y = torch.full((M, N), float("nan"), dtype=BF, device="cuda")
+        H.gemm_pf(xf, wf, y, M, N, K, N, ws, bias=None if bias is None else dev(bias), splits=splits)
+        assert_close_bf16(y, O.linear(x, w, bias), max_ulp=1, max_frac=0.03, rel_floor=2 ** -7, what="prefill gemm rows")
+    y2 = torch.zeros(M, N, dtype=BF, device="cuda")
+    H.gemm_pf(xf, wf, y2, M, N, K, N, ws, bias=dev(b), splits=splits)
+    assert torch.equal(y2.view(torch.int16), y.view(torch.int16))          # deterministic
+
+
+@pytest.mark.parametrize("M", [40, 128])
+def test_gemm_prefill_silu_epilogue(H, M):
+    torch.manual_seed(M)
+    I, K = 512, 1024
+    x = torch.randn(M, K).to(BF)
+    w = (torch.randn(2 * I, K) * 0.06).to(BF)
+    ref = O.silu_mul(O.linear(x, w))
+    wf = torch.zeros(2 * I * K, dtype=BF, device="cuda")
+    H.rows_to_frag(dev(w), wf, 2 * I, K, mode=1)
+    act_f = torch.zeros(H.frag_numel(M, I), dtype=BF, device="cuda")
+    ws = torch.zeros(H.gemm_pf_workspace_bytes(M, 2 * I, K) // 4, dtype=torch.float32, device="cuda")
+    H.gemm_pf(to_frag_dev(x), wf, act_f, M, 2 * I, K, 0, ws, epilogue=H.EPI_SILU_FRAG)
+    act = LY.frag_to_rows_ref(act_f.cpu(), M, I)
+    assert_close_bf16(act, ref, max_ulp=1, max_frac=0.03, rel_floor=2 ** -7, what="prefill gemm+silu")
+
+
 @pytest.mark.parametrize("M", [1, 7, 24, 70])
 def test_gemm_silu_epilogue(H, M):
     torch.manual_seed(M)

@@ -305,3 +305,31 @@ def test_engine_batch_prefix_cache_and_preemption_gpu(gpu):
         print("prefix-cache/batch/preempt: identical tokens", n, "of", len(b["token_ids"]))
         assert n >= 6
     assert len(gpu_out) == 4 and all(len(o["token_ids"]) == 14 for o in gpu_out)
+
+
+def test_prefill_gemm_kernel_in_engine(gpu, monkeypatch):
+    """Force the prefill-chunk GEMM (csrc/gemm_pf.hip, normally reserved for >= 100 MB matrices) onto a tiny model:
+    a 150-token prompt (one full 128-row chunk + a 22-row tail on the skinny kernel) must give the same greedy stream
+    as the CPU oracle engine, up to near-ties."""
+    from oracle.runner import oracle_runner_factory
+    from ssd_amd.engine.llm_engine import LLMEngine
+    from ssd_amd.model import HipDecoder
+    from ssd_amd.model_config import ModelConfig
+    from ssd_amd.sampling_params import SamplingParams
+    monkeypatch.setattr(HipDecoder, "PF_MIN_WEIGHT_BYTES", 0)
+    t = ModelConfig("llama", 256, 2, 4, 2, 64, 512, 512, 1e-5, 5e5, 1024, False)
+    prompts = [[(13 * j + 5) % 512 for j in range(150)], [(7 * j + 1) % 512 for j in range(70)]]
+    kw = dict(hf_config=t, max_num_seqs=2, max_model_len=512, max_num_batched_tokens=512, kvcache_block_size=16,
+              num_kvcache_blocks=64, weights_std=0.1)
+    sp = SamplingParams(temperature=0, max_new_tokens=10, ignore_eos=True)
+    calls = []
+    import ssd_amd.hip.ops as ops
+    real = ops.gemm_pf
+    monkeypatch.setattr(ops, "gemm_pf", lambda *a, **k: (calls.append(a[3]), real(*a, **k))[1])
+    gpu_out, _ = LLMEngine("t", **kw).generate(prompts, sp, use_tqdm=False)
+    cpu_out, _ = LLMEngine("t", runner_factory=oracle_runner_factory(), **kw).generate(prompts, sp, use_tqdm=False)
+    assert calls and max(calls) == 128, calls[:8]
+    for a, b in zip(gpu_out, cpu_out):
+        n = common_prefix(a["token_ids"], b["token_ids"])
+        print("prefill-gemm engine: identical tokens", n, "of", len(b["token_ids"]))
+        assert n >= 6
