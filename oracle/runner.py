@@ -177,18 +177,22 @@ class OracleRunner:
                                                                     cu_q=cu_t, cu_k=cu_t))
 
     @torch.inference_mode()
-    def draft_jit(self, rec, num_tokens, tables):
+    def draft_jit(self, rec, num_tokens, tables, temps=None):
         """jit_speculate (draft_runner.py:124-184): K single-token decodes from the recovery token at P = n - 1."""
         B, K = len(rec), self.K
         bt = self._bt_from(tables)
         out = torch.zeros(B, K, dtype=torch.int64)
         cur = list(rec)
+        t = None if temps is None or not any(x > 0 for x in temps) else torch.tensor(temps, dtype=torch.float32)
+        lq = []
         for i in range(K):
             pos = [n - 1 + i for n in num_tokens]
             slots = [self._slot(tb, p) for tb, p in zip(tables, pos)]
             lg = self._decode(cur, pos, slots, [p + 1 for p in pos], bt)
-            cur = O.argmax_rows(lg).tolist()
+            lq.append(lg)
+            cur = (O.argmax_rows(lg) if t is None else O.sample(lg, t)).tolist()
             out[:, i] = torch.tensor(cur)
+        self._lq = torch.stack(lq, dim=1)
         return out
 
     @torch.inference_mode()
@@ -207,13 +211,16 @@ class OracleRunner:
         return O.fork_topf(lg, glue_ids, fan_lists)
 
     @torch.inference_mode()
-    def draft_tree(self, forks, num_tokens, tables, jlists):
-        """K tree-decode steps (draft_runner.py:713-812): returns tokens [B*MQ, K]."""
+    def draft_tree(self, forks, num_tokens, tables, jlists, temps=None):
+        """K tree-decode steps (draft_runner.py:713-812): returns tokens [B*MQ, K] (and keeps the per-branch logits
+        for `tree_logits` when some temperature is > 0)."""
         B, K = forks.shape[0], self.K
         mq = forks.shape[1]
         bt = self._bt_from(tables)
         toks = forks.reshape(-1)
         out = torch.zeros(B * mq, K, dtype=torch.int64)
+        t = None if temps is None or not any(x > 0 for x in temps) else torch.tensor(temps, dtype=torch.float32).repeat_interleave(mq)
+        tl = []
         for d in range(K):
             pos, slots, ctx_lens = [], [], []
             for b, (n, tb) in enumerate(zip(num_tokens, tables)):
@@ -225,9 +232,14 @@ class OracleRunner:
             ctx = Ctx("tree", slot_mapping=torch.tensor(slots, dtype=torch.int32), context_lens=torch.tensor(ctx_lens, dtype=torch.int32),
                       block_tables=bt, tree_step=d, tree_K=K, tree_jidx=jlists)
             lg = self._logits(self.model.forward(toks, torch.tensor(pos), ctx))
-            toks = O.argmax_rows(lg)
+            toks = O.argmax_rows(lg) if t is None else O.sample(lg, t)
+            tl.append(lg)
             out[:, d] = toks
+        self._tree_lq = torch.stack(tl, dim=1) if t is not None else None
         return out
+
+    def tree_logits(self, T):
+        return self._tree_lq[:T]
 
     def exit(self, *a):
         pass

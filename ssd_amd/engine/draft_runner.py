@@ -38,6 +38,7 @@ class DraftServer:
         self.j_miss = branch_positions(config.fan_out_list_miss)
         self.cache_keys: dict[tuple[int, int, int], int] = {}
         self.cache_tokens = None            # device tensor [N, K]
+        self.cache_logits = None            # device tensor [N, K, V] when the last tree was sampled (temperature > 0)
         self.pending_forks = None           # device tensor [B, MQ] of the round whose keys are not mirrored yet
         self.pending_meta = None
         self.stats = {"requests": 0, "hits": 0, "rounds": 0}
@@ -80,14 +81,17 @@ class DraftServer:
     def _speculate(self, B: int, payload: list[int], flags: int) -> None:
         K = self.K
         keys, num_tokens, tables, temps = P.unpack_speculate(payload, B, self.max_blocks)
-        if any(t != 0 for t in temps) or (flags & P.FLAG_WANT_LOGITS):
-            raise NotImplementedError("stochastic drafting (temperature > 0) is a 'next' row (SURVEY.md 8f)")
+        want_logits = bool(flags & P.FLAG_WANT_LOGITS)
+        sample = any(t > 0 for t in temps)
+        if self.config.sampler_x is not None and sample:
+            raise NotImplementedError("sampler_x rescaling of the draft distribution is not implemented")
         self._mirror_keys()
         idx = [self.cache_keys.get(tuple(k), -1) for k in keys]
         hits = [1 if i >= 0 else 0 for i in idx]
         self.stats["requests"] += B
         self.stats["hits"] += sum(hits)
         rec = [k[2] for k in keys]
+        logits_q = None
         jit = self.config.jit_speculate
         serve_from_cache = (any(hits) and not jit) or (all(hits) and jit)
         if serve_from_cache:
@@ -95,18 +99,28 @@ class DraftServer:
             tokens = self.cache_tokens[rows]
             if not all(hits):       # "fast" backup: miss rows carry filler tokens (the reference uses random ones)
                 tokens = tokens * torch.tensor(hits, dtype=torch.int64, device=tokens.device).unsqueeze(1)
+            if want_logits and self.cache_logits is not None:
+                logits_q = self.cache_logits[rows]          # [B, K, V]: the q the hit branch was sampled from
         elif jit:
-            tokens = self.runner.draft_jit(rec, num_tokens, tables)         # [B, K] on the draft device
+            tokens = self.runner.draft_jit(rec, num_tokens, tables, temps)  # [B, K] on the draft device
+            if want_logits and sample:
+                logits_q = self.runner.logits_q(B)
         else:
             tokens = self.runner.zeros_tokens(B, K)
         resp = torch.cat([torch.tensor(hits, dtype=torch.int64, device=tokens.device), tokens.reshape(-1)])
         self.tx.send_tensor(resp)
+        if want_logits:
+            # rows that are neither hits nor JIT-drafted never take the ratio path (verify.py:57-62): zeros will do
+            if logits_q is None:
+                logits_q = torch.zeros(B, K, self.runner.cfg.vocab_size, dtype=torch.bfloat16, device=tokens.device)
+            self.tx.send_tensor(logits_q)
         # ---- from here on the target is verifying; pre-compute the next round's cache ----
         fan = [self.config.fan_out_list if h else self.config.fan_out_list_miss for h in hits]
         jl = [self.j_hit if h else self.j_miss for h in hits]
         glue_ids = torch.cat([torch.tensor(rec, dtype=torch.int64, device=tokens.device).unsqueeze(1), tokens], dim=1)
         forks = self.runner.draft_glue_fork(glue_ids, num_tokens, tables, fan)          # [B, MQ]
-        self.cache_tokens = self.runner.draft_tree(forks, num_tokens, tables, jl)        # [B*MQ, K]
+        self.cache_tokens = self.runner.draft_tree(forks, num_tokens, tables, jl, temps)  # [B*MQ, K]
+        self.cache_logits = self.runner.tree_logits(B * self.mq) if sample else None
         self.pending_forks = forks
         self.pending_meta = ([k[0] for k in keys], jl)
         self.cache_keys = {}

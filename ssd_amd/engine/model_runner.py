@@ -511,11 +511,15 @@ class ModelRunner:
         self.model.forward(self.d_ids, self.d_pos, T, self._meta("prefill", B, max_q))
 
     @torch.inference_mode()
-    def draft_jit(self, rec, num_tokens, tables) -> torch.Tensor:
-        """K chained single-token decodes from the recovery token at P = n - 1 (no host sync)."""
+    def draft_jit(self, rec, num_tokens, tables, temps=None) -> torch.Tensor:
+        """K chained single-token decodes from the recovery token at P = n - 1 (no host sync).  With some
+        temperature > 0 the tokens are sampled and the K rows of draft logits are kept for `logits_q`."""
         B, K = len(rec), self.K
-        key = ("decode_chain", B)
+        sample = temps is not None and any(t > 0 for t in temps)
+        key = ("decode_chain_s" if sample else "decode_chain", B)
         self._note_ctx(max(num_tokens) + self._async_lookahead())
+        if sample:
+            self._ensure_stochastic()
 
         def stage():
             pos = [n - 1 for n in num_tokens]
@@ -525,10 +529,12 @@ class ModelRunner:
             self._upload(self.d_ctx, list(num_tokens), torch.int32)
             self._upload_tables(tables)
             self.d_step.zero_()
+            if sample:
+                self._upload(self.d_temps, list(temps), torch.float32)
 
         stage()
         first = 0
-        if self._launch(key, lambda: self._body_decode(B, True)) == "captured":
+        if self._launch(key, lambda: self._body_decode(B, True, sample=sample)) == "captured":
             stage()
         else:
             first = 1
@@ -537,7 +543,7 @@ class ModelRunner:
             if g is not None:
                 g.replay()
             else:
-                self._body_decode(B, True)
+                self._body_decode(B, True, sample=sample)
         return self.d_spec[:B, 1:].clone()
 
     def _body_glue_fork(self, B: int) -> None:
@@ -561,6 +567,8 @@ class ModelRunner:
         self.d_tree_slots = torch.zeros(K, T, dtype=torch.int32, **dev)
         self.d_tree_ctx = torch.zeros(K, B, dtype=torch.int32, **dev)
         self.d_tree_tokens = torch.zeros(T, K, dtype=torch.int64, **dev)
+        self.d_steps_const = torch.arange(K, dtype=torch.int32, **dev)       # device-resident step indices
+        self.d_tree_logits = None       # [T, K, V] bf16, allocated by the first sampled tree (43 MB per sequence at K=7 F=3)
         assert self.model.tp_size == 1, "the draft model is not tensor-parallel"
 
     @torch.inference_mode()
@@ -592,25 +600,37 @@ class ModelRunner:
             self.graphs[(*key, self._ctx_hint)].replay()
         return self.d_forks[:B].clone()
 
-    def _body_tree(self, B: int, d: int) -> None:
+    def _body_tree(self, B: int, d: int, sample: bool = False) -> None:
         T = B * self.mq
         meta = AttnMeta(H.MODE_TREE, B, self.mq, self.d_tree_slots[d], self.d_tree_ctx[d], self.d_bt, q_per_seq=self.mq,
                         tree_K=self.K, tree_mq=self.mq, tree_step=d, tree_F=1, tree_jidx=self.d_jidx,
                         ctx_hint=self._ctx_hint)
         self.model.forward(self.d_ids, self.d_tree_pos[d], T, meta)
         self.model.compute_logits(T)
-        self.model.argmax(T, self.d_next)
+        if sample:          # one temperature per sequence = per MQ_LEN branch rows; keep every branch's logits for logits_q
+            V = self.cfg.vocab_size
+            lg = self.model.full_logits(T)
+            H.store_step_rows(lg, V, self.d_tree_logits, T, V, self.K, self.d_steps_const[d:])
+            H.sample_rows(lg, V, T, V, self.d_temps, self.mq, self.d_rng, 4, self.d_next)
+            H.rng_advance(self.d_rng)
+        else:
+            self.model.argmax(T, self.d_next)
         self.d_ids[:T].copy_(self.d_next[:T])
         self.d_tree_tokens[:T, d].copy_(self.d_next[:T])
 
     @torch.inference_mode()
-    def draft_tree(self, forks: torch.Tensor, num_tokens, tables, jlists) -> torch.Tensor:
-        """K tree-decode steps with the structural branch mask; greedy tokens are chained on the device.
-        Returns tokens [B*MQ, K]."""
+    def draft_tree(self, forks: torch.Tensor, num_tokens, tables, jlists, temps=None) -> torch.Tensor:
+        """K tree-decode steps with the structural branch mask; tokens (greedy, or sampled when some temperature is
+        > 0) are chained on the device.  Returns tokens [B*MQ, K]; the branches' logits stay in `tree_logits`."""
         self._ensure_tree_buffers()
         B, K, mq = forks.shape[0], self.K, self.mq
         T = B * mq
         self._note_ctx(max(num_tokens) + self._async_lookahead())
+        sample = temps is not None and any(t > 0 for t in temps)
+        if sample:
+            self._ensure_stochastic()
+            if self.d_tree_logits is None:
+                self.d_tree_logits = torch.zeros(self.max_bs * mq, K, self.cfg.vocab_size, dtype=torch.bfloat16, device=self.device)
 
         def stage():
             pos = [[0] * T for _ in range(K)]
@@ -631,11 +651,13 @@ class ModelRunner:
             self._upload(self.d_jidx, [list(j) for j in jlists], torch.int32)
             self._upload_tables(tables)
             self.d_ids[:T].copy_(forks.reshape(-1))
+            if sample:
+                self._upload(self.d_temps, list(temps), torch.float32)
 
         stage()
         for d in range(K):
-            key = ("tree", B, d)
-            if self._launch(key, lambda d=d: self._body_tree(B, d)) == "captured":
+            key = ("tree_s" if sample else "tree", B, d)
+            if self._launch(key, lambda d=d: self._body_tree(B, d, sample)) == "captured":
                 # the eager warm-up already advanced the chain by one step; restore this step's inputs and replay
                 if d == 0:
                     self.d_ids[:T].copy_(forks.reshape(-1))
@@ -643,6 +665,10 @@ class ModelRunner:
                     self.d_ids[:T].copy_(self.d_tree_tokens[:T, d - 1])
                 self.graphs[(*key, self._ctx_hint)].replay()
         return self.d_tree_tokens[:T].clone()
+
+    def tree_logits(self, T: int) -> torch.Tensor:
+        """[T, K, V] logits of the last sampled tree (row = sequence * MQ_LEN + branch)."""
+        return self.d_tree_logits[:T]
 
     def _stage_row(self, dst2d: torch.Tensor, row: int, values, dtype) -> None:
         key = (id(dst2d), row)

@@ -50,18 +50,27 @@ class AsyncLink:
         self.tx.send_ints([P.CMD_PREFILL, len(token_lists), len(payload), 0])
         self.tx.send_ints(payload)
 
-    def speculate(self, keys, num_tokens, block_tables, temps):
+    def speculate(self, keys, num_tokens, block_tables, temps, want_logits: bool = False):
+        """-> (hits, tokens, logits_q or None).  logits_q bf16 [B, K, V] is requested only when some temperature is
+        > 0 (FLAG_WANT_LOGITS) and reaches every TP rank: each rank runs the ratio test on its own device."""
         B, K = len(keys), self.K
-        resp = None
+        resp, lq = None, None
+        V = self.config.hf_config.vocab_size
         if self.is_head:
             payload = P.pack_speculate(keys, num_tokens, block_tables, temps, self.max_blocks)
-            self.tx.send_ints([P.CMD_SPECULATE, B, len(payload), 0])
+            self.tx.send_ints([P.CMD_SPECULATE, B, len(payload), P.FLAG_WANT_LOGITS if want_logits else 0])
             self.tx.send_ints(payload)
             resp = self.tx.recv_tensor((B + B * K,), torch.int64).tolist()
+            if want_logits:
+                lq = self.tx.recv_tensor((B, K, V), torch.bfloat16).to(self.topo.device)
         resp = self._bcast_ints(resp, B + B * K)
+        if want_logits and self.topo.tp_size > 1:
+            if lq is None:
+                lq = torch.empty(B, K, V, dtype=torch.bfloat16, device=self.topo.device)
+            dist.broadcast(lq, src=dist.get_global_rank(self.topo.tp_group, 0), group=self.topo.tp_group)
         hits = resp[:B]
         tokens = [resp[B + b * K: B + (b + 1) * K] for b in range(B)]
-        return hits, tokens
+        return hits, tokens, lq
 
     def shutdown(self) -> None:
         if self.is_head and not self._closed:
@@ -89,7 +98,9 @@ class SpeculatorAsync(SpeculatorBase):
             nts.append(seq.num_tokens)
             tables.append(list(seq.draft_block_table))
             temps.append(seq.draft_temperature if seq.draft_temperature is not None else seq.temperature)
-        hits, tokens = self.link.speculate(keys, nts, tables, temps)
+        # the target's temperature matters too: a greedy draft under a sampling target still takes the ratio path
+        want = any(t > 0 for t in temps) or any(s.temperature > 0 for s in seqs)
+        hits, tokens, logits_q = self.link.speculate(keys, nts, tables, temps, want_logits=want)
         rows = []
         for seq, toks in zip(seqs, tokens):
             rows.append([seq.recovery_token_id] + toks)
@@ -98,4 +109,4 @@ class SpeculatorAsync(SpeculatorBase):
             seq.last_token = seq.token_ids[-1]
             seq.num_draft_cached_tokens += K + 1
         speculations = torch.tensor(rows, dtype=torch.int64).to(self.device)
-        return SpeculateResult(speculations, None, hits)
+        return SpeculateResult(speculations, logits_q, hits)

@@ -22,7 +22,7 @@ KW = dict(max_model_len=512, max_num_batched_tokens=512, kvcache_block_size=32, 
 PROMPTS = [[(5 * i + 3 * j) % 256 for j in range(6 + 2 * i)] for i in range(2)]
 
 
-def run(mode, same=False, bs=1, jit=True, fan=None, fan_miss=None, **extra):
+def run(mode, same=False, bs=1, jit=True, fan=None, fan_miss=None, temperature=0.0, draft_temperature=None, **extra):
     from oracle.runner import oracle_runner_factory
     from ssd_amd.engine.llm_engine import LLMEngine
     from ssd_amd.sampling_params import SamplingParams
@@ -36,7 +36,8 @@ def run(mode, same=False, bs=1, jit=True, fan=None, fan_miss=None, **extra):
     if mode == "async":
         kw.update(draft_async=True, async_fan_out=2, jit_speculate=jit, fan_out_list=fan, fan_out_list_miss=fan_miss)
     eng = LLMEngine("t", hf_config=t, runner_factory=oracle_runner_factory(), inprocess_draft=(mode == "async" and "num_gpus" not in extra), **kw)
-    out, m = eng.generate(PROMPTS[:max(1, bs)], SamplingParams(temperature=0, max_new_tokens=14, ignore_eos=True), use_tqdm=False)
+    out, m = eng.generate(PROMPTS[:max(1, bs)], SamplingParams(temperature=temperature, draft_temperature=draft_temperature,
+                                                               max_new_tokens=14, ignore_eos=True), use_tqdm=False)
     stats = eng.draft_server.stats if eng.draft_server is not None else None
     eng.exit()
     return [o["token_ids"] for o in out], m, stats
@@ -68,6 +69,29 @@ def test_async_batch_nonuniform_fanout_and_fast_backup():
     a3, _, s3 = run("async", bs=2, same=True, fan=[1, 1, 1, 5], fan_miss=[2, 2, 2, 2])
     assert ar == a1 == a2 == a3
     assert s3["hits"] > 0
+
+
+def test_async_temperature_same_model_accepts_everything():
+    """temperature > 0 over the async protocol (FLAG_WANT_LOGITS): the server samples the JIT chain and every tree
+    branch and ships the q logits of the answered branch; with draft == target p == q, so min(1, p/q) = 1 and every
+    round after the first (a JIT-served miss) is a cache hit that is fully accepted."""
+    torch.manual_seed(0)
+    asy, m, stats = run("async", same=True, temperature=0.8)
+    lens = m["accepted_suffix_lens_with_recovery"]
+    assert all(n == 4 for n in lens[:-1]), lens
+    assert all(len(t) == 14 for t in asy)
+    # the bonus token of an all-accepted round is a fresh draw from p: whether it is one of the F forked tokens is up
+    # to chance, so hits are not guaranteed -- but a hit must have been answered from the sampled tree's logits
+    assert stats["rounds"] == len(m["cache_hits"])
+
+
+def test_async_temperature_greedy_draft_and_mixed_batch():
+    torch.manual_seed(1)
+    ar, _, _ = run("ar")
+    # a greedy draft (draft_temperature = 0) under a sampling target: q is one-hot, the reply still carries logits
+    out, m, _ = run("async", bs=2, temperature=0.7, draft_temperature=0.0)
+    assert all(len(t) == 14 for t in out)
+    assert all(1 <= n <= 4 for n in m["accepted_suffix_lens_with_recovery"])
 
 
 def _worker(rank, port, q):

@@ -119,3 +119,27 @@ def test_sync_without_jit_falls_back_to_greedy_acceptance(gpu):
     out, m = eng.generate([PROMPT] * 8, SamplingParams(temperature=0.7, max_new_tokens=12, ignore_eos=True), use_tqdm=False)
     assert all(len(o["token_ids"]) == 12 for o in out)
     assert all(1 <= n <= 4 for n in m["accepted_suffix_lens_with_recovery"])
+
+
+def test_async_speculative_sampling_matches_autoregressive_distribution(gpu):
+    """The asynchronous (SSD) protocol at temperature > 0 on the GPU, draft server in-process over the loopback
+    transport: sampled JIT chains, sampled tree branches whose logits are cached and shipped as logits_q, ratio
+    verification on hits and JIT rows.  Same exactness criterion as the synchronous test."""
+    from ssd_amd.engine.llm_engine import LLMEngine
+    from ssd_amd.sampling_params import SamplingParams
+    t, factory = perturbed_pair(0.03)
+    B, R, n_new = 8, 120, 6
+    sp = SamplingParams(temperature=0.7, max_new_tokens=n_new, ignore_eos=True)
+    ar = LLMEngine("t", hf_config=t, max_num_seqs=B, runner_factory=factory, **KW)
+    a, _ = draw(ar, sp, R, B, n_new)
+    del ar
+    kw = dict(KW, num_draft_kvcache_blocks=256)
+    sd = LLMEngine("t", hf_config=t, draft="d", draft_hf_config=t, speculate=True, speculate_k=3, max_num_seqs=B,
+                   draft_async=True, async_fan_out=3, jit_speculate=True, inprocess_draft=True, runner_factory=factory, **kw)
+    s, lens = draw(sd, sp, R, B, n_new)
+    st = sd.draft_server.stats
+    print("async: mean accepted (+recovery)", sum(lens) / len(lens), "cache hit rate", st["hits"] / max(1, st["requests"]))
+    assert st["hits"] > 0 and st["hits"] < st["requests"]          # both the cache path and the JIT path served requests
+    assert 1.3 < sum(lens) / len(lens) < 3.9
+    for pos in range(1, n_new):
+        two_sample_ok(a[:, pos], s[:, pos], t.vocab_size, f"async: marginal of generated position {pos}")
