@@ -68,6 +68,16 @@ class LLMEngine:
         config = Config(model, **{k: v for k, v in kwargs.items() if k in names})
         self.config = config
         Sequence.block_size = config.kvcache_block_size
+        # LLM(model, num_gpus=N) from a single process (reference llm_engine.py:61-127): become rank 0 and spawn the rest
+        self._followers = []
+        if config.num_gpus > 1 and "WORLD_SIZE" not in os.environ and topology is None and not inprocess_draft:
+            from ssd_amd.engine.launcher import spawn_followers
+            self._followers = spawn_followers(model, dict(kwargs, runner_factory=runner_factory) if runner_factory else dict(kwargs),
+                                              config.num_gpus)
+            import atexit
+            atexit.register(self.exit)
+        from ssd_amd.engine.launcher import resolve_factory
+        runner_factory = resolve_factory(runner_factory)
         assert config.num_gpus > 1 or not config.draft_async or inprocess_draft, "draft_async requires at least 2 gpus"
 
         from ssd_amd.utils.topology import resolve_topology, Topology
@@ -178,10 +188,28 @@ class LLMEngine:
         assert self.is_draft_process
         self.draft_server.serve_forever()
 
+    def follow(self) -> None:
+        """A rank spawned by the leader process (engine/launcher.py): the draft rank serves the wire protocol; a
+        tensor-parallel follower replays the leader's generate() calls until told to exit."""
+        import torch.distributed as dist
+        if self.is_draft_process:
+            self.serve()
+            return
+        while True:
+            box = [None]
+            dist.broadcast_object_list(box, src=0, group=self.topo.ctl_group)
+            cmd = box[0]
+            if cmd[0] == "exit":
+                return
+            self.generate(cmd[1], cmd[2], use_tqdm=False)
+
     def generate(self, prompts, sampling_params, use_tqdm: bool = True, stream_callback=None):
         if self.is_draft_process:           # SPMD launch: the draft rank serves instead of generating
             self.serve()
             return [], METRICS
+        if self._followers and self.topo.tp_size > 1:      # single-process launch: hand the request to the TP followers
+            import torch.distributed as dist
+            dist.broadcast_object_list([("generate", prompts, sampling_params)], src=0, group=self.topo.ctl_group)
         for k, v in _fresh_metrics().items():
             METRICS[k] = v
         if not isinstance(sampling_params, list):
@@ -228,5 +256,18 @@ class LLMEngine:
         return result, METRICS
 
     def exit(self, hard: bool = False) -> None:
+        if self._followers:
+            import torch.distributed as dist
+            if self.topo.tp_size > 1:
+                dist.broadcast_object_list([("exit",)], src=0, group=self.topo.ctl_group)
         if self.async_link is not None:
             self.async_link.shutdown()
+        if self._followers:
+            import torch.distributed as dist
+            for p in self._followers:
+                p.join(timeout=60)
+            self._followers = []
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+                os.environ.pop(k, None)

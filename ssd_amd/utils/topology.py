@@ -25,6 +25,7 @@ class Topology:
     tp_group: object = None
     async_group: object = None   # [rank 0, draft rank]
     draft_rank: int = -1
+    ctl_group: object = None     # gloo group of the target ranks: control messages of a single-process launch
 
     def single(self) -> "Topology":
         """Same device, no tensor parallelism (a sync-speculation draft is replicated on every rank)."""
@@ -68,8 +69,10 @@ def resolve_topology(config) -> Topology:
         tp = world - 1
         tp_group = dist.new_group(list(range(tp)))
         async_group = dist.new_group([0, tp])
+        ctl = dist.new_group(list(range(tp)), backend="gloo")
         if rank == tp:
             return Topology(rank, world, device, "draft", 0, 1, None, async_group, tp)
-        return Topology(rank, world, device, "target", rank, tp, tp_group, async_group if rank == 0 else None, tp)
+        return Topology(rank, world, device, "target", rank, tp, tp_group, async_group if rank == 0 else None, tp, ctl)
     tp_group = dist.new_group(list(range(world)))
-    return Topology(rank, world, device, "target", rank, world, tp_group)
+    ctl = dist.new_group(list(range(world)), backend="gloo")
+    return Topology(rank, world, device, "target", rank, world, tp_group, ctl_group=ctl)
