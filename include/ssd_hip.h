@@ -189,6 +189,15 @@ int ssd_allreduce_bf16(const void* in, void* out, long n, int rank, int world, v
 int ssd_allgather_u64(const void* in, void* out, long n8, int rank, int world, void* const* slots, void* const* flags,
                       long slot_elems, void* counters, void* err, long spin_budget, void* stream);
 
+/* RowParallelLinear's all_reduce (ssd/layers/linear.py:195-199) fused with the add + RMSNorm that always follows it
+ * (ssd/layers/layernorm.py:76-88; ssd/models/llama3.py:185-199): res_out = bf16(allreduce(in) + res_in),
+ * out = bf16(x32 * rsqrt(mean(x32^2) + eps) * weight) row-major and/or fragment-major.  Bit-identical to
+ * ssd_allreduce_bf16 followed by ssd_rmsnorm; same slots / flags / counters.  T*H <= slot_elems. */
+int ssd_allreduce_add_rmsnorm_bf16(const void* in, const void* res_in, void* res_out, const void* weight, float eps,
+                                   void* out_rows, void* out_frag, int T, int H, int rank, int world, void* const* slots,
+                                   void* const* flags, long slot_elems, void* counters, void* err, long spin_budget,
+                                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

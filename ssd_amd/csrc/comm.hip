@@ -88,6 +88,111 @@ allreduce_bf16_kernel(const unsigned long long* __restrict__ in, unsigned long l
   }
 }
 
+// Fused: all-reduce of this rank's [T][H] partial (o_proj / down_proj output) + residual add + RMSNorm of the sum --
+// the three launches RowParallelLinear.forward's all_reduce (linear.py:195-199) + RMSDNorm.add_norm_forward
+// (layernorm.py:76-88) cost per half layer become one.  A workgroup owns whole rows (the norm needs the full row), so
+// at most AR_BLOCKS workgroups read the peers' staged rows; per row the arithmetic and the reduction order are exactly
+// those of allreduce_bf16_kernel followed by rmsnorm_kernel (norm.hip) -- results are bit-identical to the unfused pair.
+constexpr int ARN_THREADS = 256;   // = NORM_THREADS: same chunk -> thread mapping, same sum-of-squares order
+constexpr int ARN_MAXC = 8;
+
+__global__ void __launch_bounds__(ARN_THREADS)
+allreduce_add_rmsnorm_kernel(const unsigned long long* __restrict__ in, const u32x4_t* __restrict__ res_in,
+                             u32x4_t* __restrict__ res_out, const u32x4_t* __restrict__ w, float eps,
+                             u32x4_t* __restrict__ out_rows, u32x4_t* __restrict__ out_frag, int T, int H,
+                             long slot_words, ArPeers peers, int rank, int world, unsigned int* __restrict__ counters,
+                             unsigned int* __restrict__ err, long spin_budget) {
+  __shared__ unsigned int s_epoch;
+  __shared__ int s_fail;
+  __shared__ float red[ARN_THREADS / 64];
+  const int blk = blockIdx.x;
+  if (threadIdx.x == 0) { s_epoch = counters[blk] + 1; s_fail = 0; }
+  __syncthreads();
+  const unsigned int epoch = s_epoch;
+  const int rpb = (T + gridDim.x - 1) / gridDim.x;
+  const int r0 = blk * rpb, r1 = min(T, r0 + rpb);
+  const int H8 = H >> 3, KT = H >> 5;
+  const long hw = H >> 2;                       // 8-byte words per row
+  unsigned long long* my = peers.slot[rank] + (long)(epoch & 1u) * slot_words;
+  for (long i = (long)r0 * hw + threadIdx.x; i < (long)r1 * hw; i += ARN_THREADS) st_sys64(my + i, in[i]);
+  __syncthreads();
+  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  __syncthreads();
+  if (threadIdx.x < world) {
+    const int peer = threadIdx.x;
+    __hip_atomic_store(peers.flags[peer] + blk * AR_MAX_RANKS + rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned int* mine = peers.flags[rank] + blk * AR_MAX_RANKS + peer;
+    long spins = 0;
+    while ((int)(__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+      if (spins < 4096) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(32);
+      if (++spins > spin_budget) { s_fail = 1; break; }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    counters[blk] = epoch;
+    if (s_fail) atomicExch(err, 1u);
+  }
+  __syncthreads();
+  if (s_fail) return;
+  for (int row = r0; row < r1; ++row) {
+    float v[ARN_MAXC][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < ARN_MAXC; ++i) {
+      const int c = threadIdx.x + i * ARN_THREADS;
+      if (c < H8) {
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < world; ++r) {
+          const unsigned long long* sp = peers.slot[r] + (long)(epoch & 1u) * slot_words + (long)row * hw + 2 * c;
+          const unsigned long long v0 = ld_sys64(sp), v1 = ld_sys64(sp + 1);
+          a[0] += bf2f((unsigned)(v0 & 0xffffu)); a[1] += bf2f((unsigned)((v0 >> 16) & 0xffffu));
+          a[2] += bf2f((unsigned)((v0 >> 32) & 0xffffu)); a[3] += bf2f((unsigned)(v0 >> 48));
+          a[4] += bf2f((unsigned)(v1 & 0xffffu)); a[5] += bf2f((unsigned)((v1 >> 16) & 0xffffu));
+          a[6] += bf2f((unsigned)((v1 >> 32) & 0xffffu)); a[7] += bf2f((unsigned)(v1 >> 48));
+        }
+        const u32x4_t rv = res_in[(size_t)row * H8 + c];
+        u32x4_t ro;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          // the all-reduce delivers bf16 (one rounding of the fp32 rank-order sum); the norm then works in fp32
+          const float lo = round_bf(a[2 * j]) + bf2f(rv[j] & 0xffffu);
+          const float hi = round_bf(a[2 * j + 1]) + bf2f(rv[j] >> 16);
+          v[i][2 * j] = lo; v[i][2 * j + 1] = hi;
+          ro[j] = pack_bf2(lo, hi);
+          ss += lo * lo; ss += hi * hi;
+        }
+        res_out[(size_t)row * H8 + c] = ro;
+      }
+    }
+    ss = wave_sum(ss);
+    __syncthreads();                       // red[] of the previous row has been consumed
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < ARN_THREADS / 64; ++i) tot += red[i];
+    const float rs = 1.0f / sqrtf(tot / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < ARN_MAXC; ++i) {
+      const int c = threadIdx.x + i * ARN_THREADS;
+      if (c < H8) {
+        const u32x4_t wv = w[c];
+        u32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = (v[i][2 * j] * rs) * bf2f(wv[j] & 0xffffu);
+          const float hi = (v[i][2 * j + 1] * rs) * bf2f(wv[j] >> 16);
+          o[j] = pack_bf2(lo, hi);
+        }
+        if (out_rows) out_rows[(size_t)row * H8 + c] = o;
+        if (out_frag) out_frag[frag_chunk(row, c, KT)] = o;
+      }
+    }
+  }
+}
+
 // ---- host-side helpers (setup time only; never called on the hot path) ----
 extern "C" int ssd_comm_alloc(void** out, long bytes) {
   void* p = nullptr;
@@ -154,5 +259,30 @@ extern "C" int ssd_allgather_u64(const void* in, void* out, long n8, int rank, i
   hipLaunchKernelGGL(allreduce_bf16_kernel, dim3(blocks), dim3(AR_THREADS), 0, (hipStream_t)stream,
                      (const unsigned long long*)in, (unsigned long long*)out, n8, slot_elems / 4, peers, rank, world,
                      (unsigned int*)counters, (unsigned int*)err, spin_budget, 1);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
+// All-reduce of `in` ([T][H] bf16 partial sums) fused with the residual add and the RMSNorm that follow it in every
+// decoder half-layer: res_out = bf16(allreduce(in) + res_in); out = bf16(x32 * rsqrt(mean(x32^2) + eps) * weight), written
+// row-major (out_rows) and/or fragment-major (out_frag).  Same staging slots / flags / counters as ssd_allreduce_bf16
+// (the calls may be interleaved freely as long as every rank issues the same sequence).  T*H <= slot_elems, H % 32 == 0.
+extern "C" int ssd_allreduce_add_rmsnorm_bf16(const void* in, const void* res_in, void* res_out, const void* weight,
+                                              float eps, void* out_rows, void* out_frag, int T, int H, int rank, int world,
+                                              void* const* slots, void* const* flags, long slot_elems, void* counters,
+                                              void* err, long spin_budget, void* stream) {
+  if (world < 1 || world > AR_MAX_RANKS || rank < 0 || rank >= world || T <= 0 || H <= 0 || (H & 31) ||
+      H > ARN_THREADS * ARN_MAXC * 8 || (long)T * H > slot_elems)
+    return SSD_ERR_SHAPE;
+  if (!in || !res_in || !res_out || !weight) return SSD_ERR_ARG;
+  ArPeers peers;
+  for (int r = 0; r < AR_MAX_RANKS; ++r) {
+    peers.slot[r] = (unsigned long long*)(r < world ? slots[r] : nullptr);
+    peers.flags[r] = (unsigned int*)(r < world ? flags[r] : nullptr);
+  }
+  const int blocks = T < AR_BLOCKS ? T : AR_BLOCKS;
+  hipLaunchKernelGGL(allreduce_add_rmsnorm_kernel, dim3(blocks), dim3(ARN_THREADS), 0, (hipStream_t)stream,
+                     (const unsigned long long*)in, (const u32x4_t*)res_in, (u32x4_t*)res_out, (const u32x4_t*)weight, eps,
+                     (u32x4_t*)out_rows, (u32x4_t*)out_frag, T, H, slot_elems / 4, peers, rank, world,
+                     (unsigned int*)counters, (unsigned int*)err, spin_budget);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }

@@ -14,6 +14,8 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -61,6 +63,7 @@ class HipDecoder:
         # collective + hipGraph-capture path that the multi-GPU runs depend on)
         self.use_coll = tp_size > 1 or (force_collectives and tp_group is not None)
         self.custom_ar = None      # OneShotAllReduce (ssd_amd/utils/custom_ar.py) once the runner has validated it
+        self.fuse_ar_norm = os.environ.get("SSD_FUSE_AR_NORM", "1") != "0"
         assert cfg.num_heads % tp_size == 0 and cfg.num_kv_heads % tp_size == 0
         assert cfg.intermediate_size % (tp_size * 32) == 0 and cfg.vocab_size % (tp_size * 16) == 0
         self.nh, self.nkv = cfg.num_heads // tp_size, cfg.num_kv_heads // tp_size
@@ -195,8 +198,9 @@ class HipDecoder:
 
     @staticmethod
     def ctx_bucket(ctx: int) -> int:
-        """Power-of-two context bucket (>= 4096): the attention decomposition is static per hipGraph."""
-        b = 4096
+        """Power-of-two context bucket (>= 1024): the attention decomposition is static per hipGraph, and up to
+        1024 keys a single workgroup per (sequence, kv head) with no merge kernel is the fastest one."""
+        b = 1024
         while b < ctx:
             b *= 2
         return b
@@ -228,8 +232,10 @@ class HipDecoder:
         small = T <= 16 and not self.cfg.qk_norm
         return small, small and not self.use_coll and T * self.h // 8 <= 1024
 
-    def launch_qkv(self, li: int, T: int, positions, slot_mapping, gemm_only: bool = False) -> None:
-        """gemm_only: skip the separate add+RMSNorm / RoPE launches of the unfused variants (kernel timing)."""
+    def launch_qkv(self, li: int, T: int, positions, slot_mapping, gemm_only: bool = False, pre_normed: bool = False) -> None:
+        """gemm_only: skip the separate add+RMSNorm / RoPE launches of the unfused variants (kernel timing).
+        pre_normed: buf_xf / buf_res already hold this layer's normalised input and residual (written by the fused
+        all-reduce + add + RMSNorm that closed the previous layer)."""
         cfg, w = self.cfg, self.w
         p = f"model.layers.{li}."
         small, norm_fuse = self.fusion_plan(T)
@@ -243,7 +249,7 @@ class HipDecoder:
                          eps=cfg.rms_norm_eps, bias=w.get(p + "self_attn.qkv_proj.bias"), waves=16, **rope)
             return
         # residual is None on layer 0 (llama3.py:187-190): residual := embeddings, x := norm(embeddings)
-        if not gemm_only:
+        if not gemm_only and not pre_normed:
             H.rmsnorm(h, w[p + "input_layernorm.weight"], cfg.rms_norm_eps, T, self.h, res_in=None if li == 0 else res,
                       res_out=res, out_frag=xf)
         if small:
@@ -261,7 +267,7 @@ class HipDecoder:
     def launch_o(self, li: int, T: int) -> None:
         self._gemm(self.buf_af, self.qn, self.w[f"model.layers.{li}.self_attn.o_proj.weight"], self.h, self.buf_h, T, self.h)
 
-    def launch_gate_up(self, li: int, T: int, gemm_only: bool = False) -> None:
+    def launch_gate_up(self, li: int, T: int, gemm_only: bool = False, pre_normed: bool = False) -> None:
         cfg, w = self.cfg, self.w
         p = f"model.layers.{li}."
         _, norm_fuse = self.fusion_plan(T)
@@ -270,7 +276,7 @@ class HipDecoder:
                          res_in=self.buf_res2, res_out=self.buf_res, norm_w=w[p + "post_attention_layernorm.weight"],
                          eps=cfg.rms_norm_eps, y=self.buf_actf, waves=16)
         else:
-            if not gemm_only:
+            if not gemm_only and not pre_normed:
                 H.rmsnorm(self.buf_h, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps, T, self.h,
                           res_in=self.buf_res, res_out=self.buf_res, out_frag=self.buf_xf)
             self._gemm(self.buf_xf, self.h, w[p + "mlp.gate_up_proj.weight"], 2 * self.I, self.buf_actf, T, 0, epi=H.EPI_SILU_FRAG)
@@ -287,18 +293,30 @@ class HipDecoder:
         self._allreduce(h[:T])
         splits, attn_waves = self._attn_cfg(T, meta)
         scale = self.hd ** -0.5
-        for li in range(cfg.num_layers):
-            self.launch_qkv(li, T, positions, meta.slot_mapping)
+        # tensor parallel with the one-shot collective: the all-reduce after o_proj / down_proj absorbs the residual add
+        # and the RMSNorm that follow it (csrc/comm.hip), 2 launches fewer per half layer
+        ar = self.custom_ar
+        fuse = self.use_coll and ar is not None and self.fuse_ar_norm and ar.fits_rows(T, self.h)
+        eps, res, xf = cfg.rms_norm_eps, self.buf_res, self.buf_xf
+        L = cfg.num_layers
+        for li in range(L):
+            self.launch_qkv(li, T, positions, meta.slot_mapping, pre_normed=fuse and li > 0)
             H.attn_paged(self.buf_q, self.kv_cache[li, 0], self.kv_cache[li, 1], meta.block_tables, self.max_blocks,
                          meta.context_lens, meta.B, T, meta.max_q, self.nh, self.nkv, self.hd, self.block_size, scale,
                          cu_q=meta.cu_q, q_per_seq=meta.q_per_seq, mode=meta.mode, tree_K=meta.tree_K, tree_mq=meta.tree_mq,
                          tree_step=meta.tree_step, tree_F=meta.tree_F, tree_jidx=meta.tree_jidx, splits=splits,
                          ws_o=self.ws_o, ws_ml=self.ws_ml, out_frag=self.buf_af, waves=attn_waves)
             self.launch_o(li, T)
-            self._allreduce(h[:T])
-            self.launch_gate_up(li, T)
+            if fuse:
+                ar.all_reduce_add_rmsnorm(h, res, res, w[f"model.layers.{li}.post_attention_layernorm.weight"], eps, T, self.h, out_frag=xf)
+            else:
+                self._allreduce(h[:T])
+            self.launch_gate_up(li, T, pre_normed=fuse)
             self.launch_down(li, T)
-            self._allreduce(h[:T])
+            if fuse and li + 1 < L:
+                ar.all_reduce_add_rmsnorm(h, res, res, w[f"model.layers.{li + 1}.input_layernorm.weight"], eps, T, self.h, out_frag=xf)
+            else:
+                self._allreduce(h[:T])
 
     def compute_logits(self, T: int, gather: torch.Tensor | None = None, rows: int | None = None) -> int:
         """Final add+RMSNorm (optionally only the `gather` rows: prefill last-token, embed_head.py:81-84) and the

@@ -82,6 +82,21 @@ class OneShotAllReduce:
         if rc != 0:
             raise RuntimeError(f"ssd_allreduce_bf16 failed with code {rc}")
 
+    def fits_rows(self, T: int, H: int) -> bool:
+        return T * H <= SLOT_ELEMS and H % 32 == 0 and H <= 16384
+
+    def all_reduce_add_rmsnorm(self, x: torch.Tensor, res_in: torch.Tensor, res_out: torch.Tensor, weight: torch.Tensor,
+                               eps: float, T: int, H: int, out_rows=None, out_frag=None) -> None:
+        """res_out = bf16(sum_over_ranks(x[:T]) + res_in); out = RMSNorm(that) * weight (csrc/comm.hip): the all-reduce
+        after o_proj / down_proj and the add + RMSNorm that follows it, in one launch."""
+        rc = self.lib.ssd_allreduce_add_rmsnorm_bf16(x.data_ptr(), res_in.data_ptr(), res_out.data_ptr(), weight.data_ptr(), eps,
+                                                     0 if out_rows is None else out_rows.data_ptr(),
+                                                     0 if out_frag is None else out_frag.data_ptr(), T, H, self.rank, self.world,
+                                                     self.slots, self.flags, SLOT_ELEMS, self.counters.data_ptr(),
+                                                     self.err.data_ptr(), SPIN_BUDGET, torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"ssd_allreduce_add_rmsnorm_bf16 failed with code {rc}")
+
     def all_gather_words(self, src: torch.Tensor, dst: torch.Tensor, n8: int) -> None:
         """dst [world][n8] 8-byte words <- every rank's src[:n8] (device buffers, 8-byte aligned)."""
         rc = self.lib.ssd_allgather_u64(src.data_ptr(), dst.data_ptr(), n8, self.rank, self.world, self.slots, self.flags,
@@ -149,6 +164,30 @@ def _selftest_main() -> int:
             torch.cuda.synchronize()
             if ar.failed() or not torch.equal(buf.cpu().view(torch.int16), want.view(torch.int16)):
                 print(f"[custom_ar selftest] rank {rank}: graph replay mismatch it={it} failed={ar.failed()}", flush=True)
+                ok = False
+                break
+    # the fused all-reduce + residual add + RMSNorm must equal the unfused pair bit for bit (interleaved with plain calls)
+    if ok:
+        from ssd_amd.hip import ops as H
+        for T, Hd in ((1, 2048), (7, 8192), (8, 5120), (20, 1024)):
+            xs = [torch.randn(T, Hd, generator=g).to(torch.bfloat16) for _ in range(world)]
+            res = torch.randn(T, Hd, generator=g).to(torch.bfloat16).to(dev)
+            w = (1 + 0.1 * torch.randn(Hd, generator=g)).to(torch.bfloat16).to(dev)
+            x = xs[rank].to(dev)
+            ref_h = x.clone()
+            ar.all_reduce(ref_h)
+            ref_res = torch.zeros_like(res)
+            ref_rows = torch.zeros(T, Hd, dtype=torch.bfloat16, device=dev)
+            ref_frag = torch.zeros(H.frag_numel(T, Hd), dtype=torch.bfloat16, device=dev)
+            H.rmsnorm(ref_h, w, 1e-5, T, Hd, res_in=res, res_out=ref_res, out_rows=ref_rows, out_frag=ref_frag)
+            got_res = res.clone()
+            rows = torch.zeros_like(ref_rows)
+            frag = torch.zeros_like(ref_frag)
+            ar.all_reduce_add_rmsnorm(x, got_res, got_res, w, 1e-5, T, Hd, out_rows=rows, out_frag=frag)
+            torch.cuda.synchronize()
+            same = all(torch.equal(a.view(torch.int16), b.view(torch.int16)) for a, b in ((got_res, ref_res), (rows, ref_rows), (frag, ref_frag)))
+            if ar.failed() or not same:
+                print(f"[custom_ar selftest] rank {rank}: fused all-reduce+norm mismatch at T={T} H={Hd} failed={ar.failed()}", flush=True)
                 ok = False
                 break
     flag = torch.tensor([1 if ok else 0])
