@@ -141,17 +141,22 @@ int ssd_verify_greedy(const int64_t* preds, const int64_t* speculations, int B, 
  * argmax(softmax / Exp(1))).  ssd_row_lse: log-sum-exp of logits / T per row (softmax normaliser of verify.py:76-99).
  * ssd_verify_ratio: verify() with ratio acceptance and residual resampling -- ssd/utils/verify.py:50-167.  ratio_rows
  * int32[B]: 1 where the draft tokens were really drawn from q (cache hit or JIT), else greedy acceptance + recovery ~ p.
- * accept_prob (optional) float[B][K] receives min(1, p/q) per position. */
+ * accept_prob (optional) float[B][K] receives min(1, p/q) per position.
+ * sampler_x (apply_sampler_x_rescaling -- ssd/utils/async_helpers/async_spec_helpers.py:79-105; sampler.py:29-31;
+ * verify.py:101-105): boost_idx int32[rows][boost_k] = the F+1 most probable tokens of each row (ssd_topk_rows),
+ * boost_x = sampler_x; NULL disables it.  ssd_row_lse and ssd_verify_ratio must see the same boost rows for q. */
+int ssd_topk_rows(const void* logits_rows, long ld, int T, int V, int k, int32_t* out_idx, void* stream);
 int ssd_sample_rows(const void* logits_rows, long ld, int T, int V, const float* temps, int rows_per_temp,
-                    const void* rng_state, unsigned salt, int64_t* out, int64_t* out2, void* stream);
+                    const void* rng_state, unsigned salt, int64_t* out, int64_t* out2, const int32_t* boost_idx,
+                    int boost_k, float boost_x, void* stream);
 int ssd_rng_advance(void* rng_state, void* stream);
 int ssd_row_lse(const void* logits_rows, long ld, int T, int V, const float* temps, int rows_per_temp, float* lse,
-                void* stream);
+                const int32_t* boost_idx, int boost_k, float boost_x, void* stream);
 int ssd_verify_ratio(const void* logits_p, long ld_p, const void* logits_q, long ld_q, int V, int B, int K,
                      const int64_t* speculations, const int64_t* preds_p, const float* lse_p, const float* lse_q,
                      const float* temps_t, const float* temps_q, const int32_t* ratio_rows, const void* rng_state,
                      unsigned salt, int32_t* accept_len, int64_t* recovery, int64_t* packed, float* accept_prob,
-                     void* stream);
+                     const int32_t* boost_idx_q, int boost_k, float boost_x, void* stream);
 
 /* get_forked_recovery_tokens_from_logits -- ssd/utils/async_helpers/async_spec_helpers.py:26-78.
  * counts/offsets int32 [B][K+1]: fan-out and output offset of each glue position. */

@@ -247,19 +247,32 @@ def fork_topf(logits: torch.Tensor, returned_tokens: torch.Tensor, fan_out_lists
 # temperature > 0 (stochastic) -- same torch RNG call sequence as the reference, so with the same manual seed the
 # CPU results are identical to the reference's (pinned in tests/test_oracle_golden.py::test_verify_stochastic)
 # --------------------------------------------------------------------------------------------------
-def sample(logits: torch.Tensor, temperatures: torch.Tensor) -> torch.Tensor:
-    """Sampler.forward -- ssd/layers/sampler.py:15-36 (without sampler_x): greedy where T == 0, else
-    argmax(softmax(logits / T) / Exp(1))."""
+def sampler_x_rescale(probs: torch.Tensor, sampler_x: float, F: int) -> torch.Tensor:
+    """apply_sampler_x_rescaling -- ssd/utils/async_helpers/async_spec_helpers.py:79-105: the F+1 largest probabilities
+    are multiplied by sampler_x, then the row is renormalised."""
+    _, top = torch.topk(probs, F + 1, dim=-1)
+    mask = torch.zeros_like(probs, dtype=torch.bool)
+    mask.scatter_(dim=-1, index=top, value=True)
+    probs = torch.where(mask, probs * sampler_x, probs)
+    return probs / probs.sum(dim=-1, keepdim=True)
+
+
+def sample(logits: torch.Tensor, temperatures: torch.Tensor, sampler_x: float | None = None, F: int | None = None) -> torch.Tensor:
+    """Sampler.forward -- ssd/layers/sampler.py:15-36: greedy where T == 0, else argmax(softmax(logits / T) / Exp(1));
+    with sampler_x (tree decode only, is_tree=True) the distribution is rescaled first."""
     lg = logits.to(torch.float)
     greedy = lg.argmax(dim=-1)
     lg = lg / temperatures.unsqueeze(1)
     probs = torch.softmax(lg, dim=-1, dtype=torch.float)
+    if sampler_x is not None:
+        probs = sampler_x_rescale(probs, sampler_x, F)
     scores = probs.div_(torch.empty_like(probs).exponential_(1) + 1e-10)
     return torch.where(temperatures == 0, greedy, scores.argmax(dim=-1))
 
 
-def verify_full(logits_p, logits_q, speculations, temps_t, temps_q, cache_hits=None, jit_speculate=False):
-    """verify() -- ssd/utils/verify.py:5-181 (sampler_x = None).  Returns (suffixes, recovery, accept_probs or None)."""
+def verify_full(logits_p, logits_q, speculations, temps_t, temps_q, cache_hits=None, jit_speculate=False, sampler_x=None,
+                async_fan_out=None):
+    """verify() -- ssd/utils/verify.py:5-181.  Returns (suffixes, recovery, accept_probs or None)."""
     B, Kp1, V = logits_p.shape
     K = Kp1 - 1
     draft = speculations[:, 1:]
@@ -299,6 +312,8 @@ def verify_full(logits_p, logits_q, speculations, temps_t, temps_q, cache_hits=N
             ohq = torch.zeros_like(logits_q[~nzq], dtype=torch.float32)
             ohq.scatter_(2, logits_q[~nzq].argmax(dim=-1).unsqueeze(-1), 1.0)
             probs_q[~nzq] = ohq
+        if sampler_x is not None:           # verify.py:101-105
+            probs_q = sampler_x_rescale(probs_q, sampler_x, async_fan_out)
         gi = draft.unsqueeze(2)
         p_vals = probs_p[:, :K, :].gather(2, gi).squeeze(2)
         q_vals = probs_q.gather(2, gi).squeeze(2)

@@ -152,7 +152,7 @@ class OracleRunner:
         # verify() with explicit ratio rows == jit_speculate=True on the rows flagged, greedy fallback elsewhere
         sfx, rec, _ = O.verify_full(lg, logits_q if logits_q is not None else torch.zeros(B, K, lg.shape[-1], dtype=lg.dtype),
                                     speculations, self._temps(seqs), torch.tensor(temps_q), cache_hits=torch.tensor(ratio_rows),
-                                    jit_speculate=False)
+                                    jit_speculate=False, sampler_x=self.config.sampler_x, async_fan_out=self.config.async_fan_out)
         return sfx, rec
 
     # ---- draft-server operations of asynchronous speculation (explicit arrays, no Sequence objects) ----
@@ -232,7 +232,7 @@ class OracleRunner:
             ctx = Ctx("tree", slot_mapping=torch.tensor(slots, dtype=torch.int32), context_lens=torch.tensor(ctx_lens, dtype=torch.int32),
                       block_tables=bt, tree_step=d, tree_K=K, tree_jidx=jlists)
             lg = self._logits(self.model.forward(toks, torch.tensor(pos), ctx))
-            toks = O.argmax_rows(lg) if t is None else O.sample(lg, t)
+            toks = O.argmax_rows(lg) if t is None else O.sample(lg, t, self.config.sampler_x, self.config.async_fan_out)
             tl.append(lg)
             out[:, d] = toks
         self._tree_lq = torch.stack(tl, dim=1) if t is not None else None

@@ -95,5 +95,9 @@ class Config:
                     self.fan_out_list_miss = list(self.fan_out_list)
                 assert len(self.fan_out_list) == self.speculate_k + 1
                 assert sum(self.fan_out_list_miss) == sum(self.fan_out_list), "hit and miss fan-out lists must have the same sum"
+        if self.sampler_x is not None:
+            assert self.speculate and self.draft_async, "sampler_x requires draft_async (reference model_runner.py:262-263)"
+            assert self.sampler_x > 0 and self.async_fan_out + 1 <= 8
+        assert self.kvcache_block_size & (self.kvcache_block_size - 1) == 0, "KV block sizes are powers of two (csrc/attention.hip)"
         assert self.kvcache_block_size >= 2 * self.speculate_k + 2, "block size < 2K+2 unsupported (reference llm_engine.py:48-49)"
         assert self.max_num_batched_tokens >= self.max_model_len

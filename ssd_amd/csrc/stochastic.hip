@@ -60,13 +60,65 @@ __device__ float block_max(float v, float* sm) {
 }
 
 constexpr int ST_THREADS = 1024;
+constexpr int ST_MAXBOOST = 8;      // sampler_x rescales the F+1 largest probabilities; F+1 <= 8
+
+// sampler_x (reference apply_sampler_x_rescaling, async_spec_helpers.py:79-105): the F+1 most probable tokens of a row
+// get their probability multiplied by x before renormalisation.  In log space that is "+ log x" on those logits: a Gumbel
+// draw and a log-sum-exp over the boosted logits are exactly the rescaled, renormalised distribution.
+struct Boost {
+  int idx[ST_MAXBOOST];
+  int k;
+  float log_x;
+  __device__ __forceinline__ float of(int i) const {
+    float b = 0.f;
+#pragma unroll
+    for (int j = 0; j < ST_MAXBOOST; ++j) b = (j < k && idx[j] == i) ? log_x : b;
+    return b;
+  }
+};
+__device__ __forceinline__ Boost load_boost(const int32_t* __restrict__ boost_idx, int row, int k, float log_x) {
+  Boost b;
+  b.k = boost_idx ? k : 0;
+  b.log_x = log_x;
+#pragma unroll
+  for (int j = 0; j < ST_MAXBOOST; ++j) b.idx[j] = (boost_idx && j < k) ? boost_idx[(size_t)row * k + j] : -1;
+  return b;
+}
+
+// out[row][0..k) = indices of the k largest logits of the row, largest first, lowest index on ties
+__global__ void __launch_bounds__(ST_THREADS)
+topk_rows_kernel(const bf16_t* __restrict__ logits, long ld, int V, int k, int32_t* __restrict__ out) {
+  __shared__ Best sm[ST_THREADS / 64];
+  __shared__ int chosen[ST_MAXBOOST];
+  const int row = blockIdx.x;
+  const bf16_t* x = logits + (size_t)row * ld;
+  for (int r = 0; r < k; ++r) {
+    Best best = {-INFINITY, 0x7fffffff};
+    for (int i = threadIdx.x; i < V; i += ST_THREADS) {
+      bool taken = false;
+      for (int j = 0; j < r; ++j) taken = taken || chosen[j] == i;
+      if (!taken) best = bmax(best, Best{bf2f(x[i]), i});
+    }
+    best = block_best<ST_THREADS>(best, sm);
+    if (threadIdx.x == 0) { chosen[r] = best.i; out[(size_t)row * k + r] = best.i; }
+    __syncthreads();
+  }
+}
+
+extern "C" int ssd_topk_rows(const void* logits, long ld, int T, int V, int k, int32_t* out, void* stream) {
+  if (T <= 0 || V <= 0 || k < 1 || k > ST_MAXBOOST || k > V) return SSD_ERR_SHAPE;
+  hipLaunchKernelGGL(topk_rows_kernel, dim3(T), dim3(ST_THREADS), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, V, k, out);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
 
 __global__ void __launch_bounds__(ST_THREADS)
 sample_rows_kernel(const bf16_t* __restrict__ logits, long ld, int V, const float* __restrict__ temps, int rows_per_temp,
-                   const uint64_t* __restrict__ rng, uint32_t salt, int64_t* __restrict__ out, int64_t* __restrict__ out2) {
+                   const uint64_t* __restrict__ rng, uint32_t salt, int64_t* __restrict__ out, int64_t* __restrict__ out2,
+                   const int32_t* __restrict__ boost_idx, int boost_k, float log_x) {
   __shared__ Best sm[ST_THREADS / 64];
   const int row = blockIdx.x;
   const float T = temps[row / rows_per_temp];
+  const Boost bo = load_boost(boost_idx, row, boost_k, log_x);
   const bf16_t* x = logits + (size_t)row * ld;
   const uint64_t seed = *rng;
   Best best = {-INFINITY, 0x7fffffff};
@@ -75,17 +127,20 @@ sample_rows_kernel(const bf16_t* __restrict__ logits, long ld, int V, const floa
   } else {
     const float inv = 1.0f / fmaxf(T, 1e-8f);
     for (int i = threadIdx.x; i < V; i += ST_THREADS)
-      best = bmax(best, Best{bf2f(x[i]) * inv + gumbel(u01(seed, salt, row, i)), i});
+      best = bmax(best, Best{bf2f(x[i]) * inv + bo.of(i) + gumbel(u01(seed, salt, row, i)), i});
   }
   best = block_best<ST_THREADS>(best, sm);
   if (threadIdx.x == 0) { out[row] = best.i; if (out2) out2[row] = best.i; }
 }
 
 extern "C" int ssd_sample_rows(const void* logits, long ld, int T, int V, const float* temps, int rows_per_temp,
-                               const void* rng_state, unsigned salt, int64_t* out, int64_t* out2, void* stream) {
+                               const void* rng_state, unsigned salt, int64_t* out, int64_t* out2, const int32_t* boost_idx,
+                               int boost_k, float boost_x, void* stream) {
   if (T <= 0 || V <= 0 || rows_per_temp <= 0) return SSD_ERR_SHAPE;
+  if (boost_idx && (boost_k < 1 || boost_k > ST_MAXBOOST || !(boost_x > 0.f))) return SSD_ERR_ARG;
   hipLaunchKernelGGL(sample_rows_kernel, dim3(T), dim3(ST_THREADS), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, V,
-                     temps, rows_per_temp, (const uint64_t*)rng_state, salt, out, out2);
+                     temps, rows_per_temp, (const uint64_t*)rng_state, salt, out, out2, boost_idx, boost_k,
+                     boost_idx ? logf(boost_x) : 0.f);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
@@ -98,27 +153,29 @@ extern "C" int ssd_rng_advance(void* rng_state, void* stream) {
 // lse[row] = log(sum_v exp(logit_v / T - m)) + m with m = max_v logit_v / T  (rows with T == 0 get lse = +inf marker 0)
 __global__ void __launch_bounds__(ST_THREADS)
 row_lse_kernel(const bf16_t* __restrict__ logits, long ld, int V, const float* __restrict__ temps, int rows_per_temp,
-               float* __restrict__ lse) {
+               float* __restrict__ lse, const int32_t* __restrict__ boost_idx, int boost_k, float log_x) {
   __shared__ float sm[ST_THREADS / 64];
   const int row = blockIdx.x;
   const float T = temps[row / rows_per_temp];
   if (T == 0.f) { if (threadIdx.x == 0) lse[row] = 0.f; return; }
   const float inv = 1.0f / fmaxf(T, 1e-8f);
   const bf16_t* x = logits + (size_t)row * ld;
+  const Boost bo = load_boost(boost_idx, row, boost_k, log_x);
   float m = -INFINITY;
-  for (int i = threadIdx.x; i < V; i += ST_THREADS) m = fmaxf(m, bf2f(x[i]) * inv);
+  for (int i = threadIdx.x; i < V; i += ST_THREADS) m = fmaxf(m, bf2f(x[i]) * inv + bo.of(i));
   m = block_max<ST_THREADS>(m, sm);
   float s = 0.f;
-  for (int i = threadIdx.x; i < V; i += ST_THREADS) s += __expf(bf2f(x[i]) * inv - m);
+  for (int i = threadIdx.x; i < V; i += ST_THREADS) s += __expf(bf2f(x[i]) * inv + bo.of(i) - m);
   s = block_sum<ST_THREADS>(s, sm);
   if (threadIdx.x == 0) lse[row] = __logf(s) + m;
 }
 
 extern "C" int ssd_row_lse(const void* logits, long ld, int T, int V, const float* temps, int rows_per_temp, float* lse,
-                           void* stream) {
+                           const int32_t* boost_idx, int boost_k, float boost_x, void* stream) {
   if (T <= 0 || V <= 0 || rows_per_temp <= 0) return SSD_ERR_SHAPE;
+  if (boost_idx && (boost_k < 1 || boost_k > ST_MAXBOOST || !(boost_x > 0.f))) return SSD_ERR_ARG;
   hipLaunchKernelGGL(row_lse_kernel, dim3(T), dim3(ST_THREADS), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, V, temps,
-                     rows_per_temp, lse);
+                     rows_per_temp, lse, boost_idx, boost_k, boost_idx ? logf(boost_x) : 0.f);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
@@ -133,7 +190,7 @@ verify_ratio_kernel(const bf16_t* __restrict__ lp, long ld_p, const bf16_t* __re
                     const float* __restrict__ lse_q, const float* __restrict__ temps_t, const float* __restrict__ temps_q,
                     const int32_t* __restrict__ ratio_rows, const uint64_t* __restrict__ rng, uint32_t salt,
                     int32_t* __restrict__ accept_len, int64_t* __restrict__ recovery, int64_t* __restrict__ packed,
-                    float* __restrict__ accept_prob) {
+                    float* __restrict__ accept_prob, const int32_t* __restrict__ boost_idx_q, int boost_k, float log_x) {
   __shared__ Best smb[ST_THREADS / 64];
   __shared__ float smf[ST_THREADS / 64];
   __shared__ int s_n;
@@ -155,7 +212,10 @@ verify_ratio_kernel(const bf16_t* __restrict__ lp, long ld_p, const bf16_t* __re
         const float pv = Tt > 0.f ? __expf(bf2f(lp[((size_t)b * (K + 1) + i) * ld_p + x]) * inv_t - lse_p[b * (K + 1) + i])
                                   : (pr[i] == x ? 1.f : 0.f);
         float qv;
-        if (Tq > 0.f) qv = __expf(bf2f(lq[((size_t)b * K + i) * ld_q + x]) * inv_q - lse_q[b * K + i]);
+        if (Tq > 0.f) {   // lse_q already carries the sampler_x boost (ssd_row_lse with the same boost rows)
+          const Boost bo = load_boost(boost_idx_q, b * K + i, boost_k, log_x);
+          qv = __expf(bf2f(lq[((size_t)b * K + i) * ld_q + x]) * inv_q + bo.of(x) - lse_q[b * K + i]);
+        }
         else qv = 1.f;   // a greedy draft proposed its own argmax: q is one-hot at x
         const float a = fminf(pv / (qv + 1e-10f), 1.0f);
         if (accept_prob) accept_prob[b * K + i] = a;
@@ -185,10 +245,11 @@ verify_ratio_kernel(const bf16_t* __restrict__ lp, long ld_p, const bf16_t* __re
       const bf16_t* qrow = lq + ((size_t)b * K + n) * ld_q;
       const float lseq = lse_q[b * K + n];
       const int xq = (int)sp[n + 1];
+      const Boost bo = load_boost(boost_idx_q, b * K + n, boost_k, log_x);
       float tot = 0.f;
       for (int v = threadIdx.x; v < V; v += ST_THREADS) {
         const float pv = __expf(bf2f(prow[v]) * inv_t - lsep);
-        const float qv = Tq > 0.f ? __expf(bf2f(qrow[v]) * inv_q - lseq) : (v == xq ? 1.f : 0.f);
+        const float qv = Tq > 0.f ? __expf(bf2f(qrow[v]) * inv_q + bo.of(v) - lseq) : (v == xq ? 1.f : 0.f);
         const float r = fmaxf(pv - qv, 0.f);
         tot += r;
         if (r > 0.f) best = bmax(best, Best{__logf(r) + gumbel(u01(seed, salt, b, 5000 + v)), v});
@@ -219,10 +280,12 @@ extern "C" int ssd_verify_ratio(const void* logits_p, long ld_p, const void* log
                                 const int64_t* spec, const int64_t* preds_p, const float* lse_p, const float* lse_q,
                                 const float* temps_t, const float* temps_q, const int32_t* ratio_rows, const void* rng_state,
                                 unsigned salt, int32_t* accept_len, int64_t* recovery, int64_t* packed, float* accept_prob,
-                                void* stream) {
+                                const int32_t* boost_idx_q, int boost_k, float boost_x, void* stream) {
   if (B <= 0 || K < 1 || K > 62 || V <= 0) return SSD_ERR_SHAPE;
+  if (boost_idx_q && (boost_k < 1 || boost_k > ST_MAXBOOST || !(boost_x > 0.f))) return SSD_ERR_ARG;
   hipLaunchKernelGGL(verify_ratio_kernel, dim3(B), dim3(ST_THREADS), 0, (hipStream_t)stream, (const bf16_t*)logits_p, ld_p,
                      (const bf16_t*)logits_q, ld_q, V, K, spec, preds_p, lse_p, lse_q, temps_t, temps_q, ratio_rows,
-                     (const uint64_t*)rng_state, salt, accept_len, recovery, packed, accept_prob);
+                     (const uint64_t*)rng_state, salt, accept_len, recovery, packed, accept_prob, boost_idx_q, boost_k,
+                     boost_idx_q ? logf(boost_x) : 0.f);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }

@@ -83,8 +83,6 @@ class DraftServer:
         keys, num_tokens, tables, temps = P.unpack_speculate(payload, B, self.max_blocks)
         want_logits = bool(flags & P.FLAG_WANT_LOGITS)
         sample = any(t > 0 for t in temps)
-        if self.config.sampler_x is not None and sample:
-            raise NotImplementedError("sampler_x rescaling of the draft distribution is not implemented")
         self._mirror_keys()
         idx = [self.cache_keys.get(tuple(k), -1) for k in keys]
         hits = [1 if i >= 0 else 0 for i in idx]

@@ -141,6 +141,12 @@ class ModelRunner:
         self.d_lse_q = torch.zeros(B * K, dtype=torch.float32, **dev)
         if self.is_draft:
             self.d_logits_q = torch.zeros(B, K, V, dtype=torch.bfloat16, **dev)
+        # sampler_x (config.py): the F+1 most probable draft tokens of a row are re-weighted (async_spec_helpers.py:79-105)
+        self.sx = self.config.sampler_x
+        self.sx_k = (self.config.async_fan_out + 1) if self.sx is not None else 0
+        if self.sx is not None:
+            rows = max(B * K, self.max_bs * getattr(self.config, "MQ_LEN", 1))
+            self.d_boost = torch.zeros(rows, self.sx_k, dtype=torch.int32, **dev)
 
     def _check_collectives(self) -> None:
         ar = self.model.custom_ar
@@ -291,9 +297,14 @@ class ModelRunner:
             lg = self.model.full_logits(T)
             self.model.argmax(T, self.d_next)
             H.row_lse(lg, V, T, V, self.d_temps, K + 1, self.d_lse_p)
-            H.row_lse(logits_q, V, B * K, V, self.d_temps_q, K, self.d_lse_q)
+            boost = {}
+            if self.sx is not None:          # verify.py:101-105: q is the sampler_x-rescaled draft distribution
+                H.topk_rows(logits_q, V, B * K, V, self.sx_k, self.d_boost)
+                boost = dict(boost_k=self.sx_k, boost_x=self.sx)
+            H.row_lse(logits_q, V, B * K, V, self.d_temps_q, K, self.d_lse_q, boost_idx=self.d_boost if boost else None, **boost)
             H.verify_ratio(lg, V, logits_q, V, V, B, K, self.d_ids, self.d_next, self.d_lse_p, self.d_lse_q, self.d_temps,
-                           self.d_temps_q, self.d_ratio, self.d_rng, 2, self.d_accept, self.d_recovery, self.d_packed)
+                           self.d_temps_q, self.d_ratio, self.d_rng, 2, self.d_accept, self.d_recovery, self.d_packed,
+                           boost_idx_q=self.d_boost if boost else None, **boost)
             H.rng_advance(self.d_rng)
             return
         if greedy_tail:
@@ -611,7 +622,12 @@ class ModelRunner:
             V = self.cfg.vocab_size
             lg = self.model.full_logits(T)
             H.store_step_rows(lg, V, self.d_tree_logits, T, V, self.K, self.d_steps_const[d:])
-            H.sample_rows(lg, V, T, V, self.d_temps, self.mq, self.d_rng, 4, self.d_next)
+            if self.sx is not None:          # Sampler(is_tree=True) with sampler_x (sampler.py:29-31)
+                H.topk_rows(lg, V, T, V, self.sx_k, self.d_boost)
+                H.sample_rows(lg, V, T, V, self.d_temps, self.mq, self.d_rng, 4, self.d_next, boost_idx=self.d_boost,
+                              boost_k=self.sx_k, boost_x=self.sx)
+            else:
+                H.sample_rows(lg, V, T, V, self.d_temps, self.mq, self.d_rng, 4, self.d_next)
             H.rng_advance(self.d_rng)
         else:
             self.model.argmax(T, self.d_next)

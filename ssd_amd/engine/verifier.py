@@ -28,8 +28,6 @@ class Verifier(VerifierBase):
         temps_q = [float(s.draft_temperature) if s.draft_temperature is not None else float(s.temperature) for s in seqs]
         t0 = perf_counter()
         if any(t > 0 for t in temps_t + temps_q):
-            if self.sampler_x is not None:
-                raise NotImplementedError("sampler_x rescaling of the draft distribution is not implemented")
             # rows whose draft tokens really came from q: JIT speculation, or a speculation-cache hit (verify.py:57-62)
             hits = speculate_result.cache_hits
             hl = None if hits is None else (hits if isinstance(hits, list) else hits.tolist())

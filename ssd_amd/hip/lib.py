@@ -53,11 +53,14 @@ SIGNATURES = {
                           c_void_p, c_void_p, c_long, c_void_p],
     "ssd_allreduce_add_rmsnorm_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                        C.POINTER(c_void_p), C.POINTER(c_void_p), c_long, c_void_p, c_void_p, c_long, c_void_p],
-    "ssd_sample_rows": [c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p, C.c_uint, c_void_p, c_void_p, c_void_p],
+    "ssd_topk_rows": [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p],
+    "ssd_sample_rows": [c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p, C.c_uint, c_void_p, c_void_p, c_void_p, c_int,
+                        c_float, c_void_p],
     "ssd_rng_advance": [c_void_p, c_void_p],
-    "ssd_row_lse": [c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p],
+    "ssd_row_lse": [c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p],
     "ssd_verify_ratio": [c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                         c_void_p, c_void_p, c_void_p, c_void_p, C.c_uint, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+                         c_void_p, c_void_p, c_void_p, c_void_p, C.c_uint, c_void_p, c_void_p, c_void_p, c_void_p,
+                         c_void_p, c_int, c_float, c_void_p],
     "ssd_store_step_rows": [c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "ssd_draft_advance": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
                           c_void_p, c_int, c_void_p],

@@ -144,25 +144,32 @@ def draft_advance(next_ids, input_ids, positions, slots, context_lens, block_tab
            "ssd_draft_advance")
 
 
-def sample_rows(logits, ld: int, T: int, V: int, temps, rows_per_temp: int, rng_state, salt: int, out, out2=None):
+def topk_rows(logits, ld: int, T: int, V: int, k: int, out_idx):
+    _check(load_library().ssd_topk_rows(_p(logits), ld, T, V, k, _p(out_idx), _stream()), "ssd_topk_rows")
+
+
+def sample_rows(logits, ld: int, T: int, V: int, temps, rows_per_temp: int, rng_state, salt: int, out, out2=None,
+                boost_idx=None, boost_k: int = 0, boost_x: float = 1.0):
     _check(load_library().ssd_sample_rows(_p(logits), ld, T, V, _p(temps), rows_per_temp, _p(rng_state), salt, _p(out), _p(out2),
-                                          _stream()), "ssd_sample_rows")
+                                          _p(boost_idx), boost_k, boost_x, _stream()), "ssd_sample_rows")
 
 
 def rng_advance(rng_state):
     _check(load_library().ssd_rng_advance(_p(rng_state), _stream()), "ssd_rng_advance")
 
 
-def row_lse(logits, ld: int, T: int, V: int, temps, rows_per_temp: int, lse):
-    _check(load_library().ssd_row_lse(_p(logits), ld, T, V, _p(temps), rows_per_temp, _p(lse), _stream()), "ssd_row_lse")
+def row_lse(logits, ld: int, T: int, V: int, temps, rows_per_temp: int, lse, boost_idx=None, boost_k: int = 0, boost_x: float = 1.0):
+    _check(load_library().ssd_row_lse(_p(logits), ld, T, V, _p(temps), rows_per_temp, _p(lse), _p(boost_idx), boost_k, boost_x,
+                                      _stream()), "ssd_row_lse")
 
 
 def verify_ratio(logits_p, ld_p: int, logits_q, ld_q: int, V: int, B: int, K: int, spec, preds_p, lse_p, lse_q, temps_t, temps_q,
-                 ratio_rows, rng_state, salt: int, accept_len, recovery, packed=None, accept_prob=None):
+                 ratio_rows, rng_state, salt: int, accept_len, recovery, packed=None, accept_prob=None, boost_idx_q=None,
+                 boost_k: int = 0, boost_x: float = 1.0):
     _check(load_library().ssd_verify_ratio(_p(logits_p), ld_p, _p(logits_q), ld_q, V, B, K, _p(spec), _p(preds_p), _p(lse_p),
                                            _p(lse_q), _p(temps_t), _p(temps_q), _p(ratio_rows), _p(rng_state), salt,
-                                           _p(accept_len), _p(recovery), _p(packed), _p(accept_prob), _stream()),
-           "ssd_verify_ratio")
+                                           _p(accept_len), _p(recovery), _p(packed), _p(accept_prob), _p(boost_idx_q), boost_k,
+                                           boost_x, _stream()), "ssd_verify_ratio")
 
 
 def store_step_rows(src, src_ld: int, dst, B: int, V: int, K: int, step):

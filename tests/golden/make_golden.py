@@ -514,6 +514,15 @@ def gen_stochastic():
         out[f"sfx{jit}"], out[f"rec{jit}"] = flat, torch.tensor(rec)
     torch.manual_seed(5)
     out["sample"] = Sampler()(lp[:, 0].clone(), tt)
+    # sampler_x: rescaled draft distribution in verify() and in the tree sampler (is_tree=True)
+    torch.manual_seed(321)
+    sfx, rec = verify(lp, lq, spec, tt, tq, cache_hits=hits, jit_speculate=True, sampler_x=0.6, async_fan_out=3)
+    flat = torch.full((B, K + 1), -1, dtype=torch.int64)
+    for b, s_ in enumerate(sfx):
+        flat[b, :len(s_)] = torch.tensor(s_)
+    out["sfx_x"], out["rec_x"] = flat, torch.tensor(rec)
+    torch.manual_seed(6)
+    out["sample_x"] = Sampler(sampler_x=0.6, async_fan_out=3)(lp[:, 1].clone(), tt, is_tree=True)
     save_npz(os.path.join(HERE, "stochastic_golden.npz"), out)
     print("stochastic_golden.npz written")
 

@@ -94,6 +94,16 @@ def test_async_temperature_greedy_draft_and_mixed_batch():
     assert all(1 <= n <= 4 for n in m["accepted_suffix_lens_with_recovery"])
 
 
+def test_async_temperature_sampler_x_runs_end_to_end():
+    """sampler_x (reference Sampler(is_tree=True) + verify(sampler_x=...)): the tree sampler and the verifier's q are
+    rescaled on their top F+1 entries; bit-level semantics are pinned against the reference in test_oracle_golden."""
+    torch.manual_seed(2)
+    out, m, stats = run("async", same=True, temperature=0.9, sampler_x=0.5)
+    assert all(len(t) == 14 for t in out)
+    assert all(1 <= n <= 4 for n in m["accepted_suffix_lens_with_recovery"])
+    assert stats["rounds"] >= 3
+
+
 def _worker(rank, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

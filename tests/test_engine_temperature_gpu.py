@@ -143,3 +143,18 @@ def test_async_speculative_sampling_matches_autoregressive_distribution(gpu):
     assert 1.3 < sum(lens) / len(lens) < 3.9
     for pos in range(1, n_new):
         two_sample_ok(a[:, pos], s[:, pos], t.vocab_size, f"async: marginal of generated position {pos}")
+
+
+def test_async_sampler_x_runs_on_the_hip_path(gpu):
+    """sampler_x end to end on the GPU: top-(F+1) boost rows for the tree sampler and for q in the ratio test."""
+    from ssd_amd.engine.llm_engine import LLMEngine
+    from ssd_amd.sampling_params import SamplingParams
+    t, factory = perturbed_pair(0.03)
+    kw = dict(KW, num_draft_kvcache_blocks=256)
+    sd = LLMEngine("t", hf_config=t, draft="d", draft_hf_config=t, speculate=True, speculate_k=3, max_num_seqs=4,
+                   draft_async=True, async_fan_out=3, jit_speculate=True, sampler_x=0.5, inprocess_draft=True,
+                   runner_factory=factory, **kw)
+    out, m = sd.generate([PROMPT] * 4, SamplingParams(temperature=0.8, max_new_tokens=16, ignore_eos=True), use_tqdm=False)
+    assert all(len(o["token_ids"]) == 16 for o in out)
+    assert all(1 <= n <= 4 for n in m["accepted_suffix_lens_with_recovery"])
+    assert sd.draft_server.stats["hits"] > 0

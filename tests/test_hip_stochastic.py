@@ -168,3 +168,47 @@ def test_verify_ratio_distributions(H):
     g_acc, _ = O.verify_greedy(lp1.argmax(-1).unsqueeze(0), spec1.unsqueeze(0))
     assert (acc2 == int(g_acc[0])).all()
     chi2_ok(torch.bincount(rec2, minlength=V), p[int(g_acc[0])], "recovery of a non-ratio row ~ p")
+
+
+def test_sampler_x_boost_kernels(H, golden):
+    """sampler_x: ssd_topk_rows picks the F+1 most probable tokens, ssd_sample_rows draws from the rescaled distribution
+    (chi-square against the oracle's apply_sampler_x_rescaling), ssd_row_lse / ssd_verify_ratio use the rescaled q
+    (acceptance probabilities against the oracle's verify(sampler_x=...))."""
+    torch.manual_seed(3)
+    V, N, F, X, T = 96, 40000, 3, 0.4, 0.8
+    logits = (torch.randn(V) * 1.5).to(BF)
+    rows = logits.unsqueeze(0).repeat(N, 1).contiguous()
+    d_rows = dev(rows)
+    top = torch.zeros(N, F + 1, dtype=torch.int32, device="cuda")
+    H.topk_rows(d_rows, V, N, V, F + 1, top)
+    want_top = torch.topk(logits.float(), F + 1).indices
+    assert top[0].cpu().tolist() == want_top.tolist() and torch.equal(top[0], top[N - 1])
+    out = torch.zeros(N, dtype=torch.int64, device="cuda")
+    H.sample_rows(d_rows, V, N, V, dev(torch.full((N,), T)), 1, rng(4), 9, out, boost_idx=top, boost_k=F + 1, boost_x=X)
+    probs = O.sampler_x_rescale(torch.softmax(logits.float() / T, -1).unsqueeze(0), X, F)[0]
+    chi2_ok(torch.bincount(out.cpu(), minlength=V), probs, "sample_rows with sampler_x")
+    # verify: accept probabilities with the rescaled q
+    g = golden("stochastic_golden")
+    lp, lq, spec, tt, tq, hits = g["lp"], g["lq"], g["spec"], g["tt"], g["tq"], g["hits"]
+    B, Kp1, Vg = lp.shape
+    K, V8 = Kp1 - 1, 56
+    lp8 = torch.full((B, Kp1, V8), float("-inf"), dtype=BF)
+    lq8 = torch.full((B, K, V8), float("-inf"), dtype=BF)
+    lp8[..., :Vg], lq8[..., :Vg] = lp, lq
+    d_lp, d_lq = dev(lp8.view(B * Kp1, V8)), dev(lq8.view(B * K, V8))
+    preds = torch.zeros(B * Kp1, dtype=torch.int64, device="cuda")
+    H.argmax_rows(d_lp, V8, B * Kp1, V8, preds)
+    bq = torch.zeros(B * K, 4, dtype=torch.int32, device="cuda")
+    H.topk_rows(d_lq, V8, B * K, V8, 4, bq)
+    lse_p = torch.zeros(B * Kp1, device="cuda")
+    lse_q = torch.zeros(B * K, device="cuda")
+    H.row_lse(d_lp, V8, B * Kp1, V8, dev(tt), Kp1, lse_p)
+    H.row_lse(d_lq, V8, B * K, V8, dev(tq), K, lse_q, boost_idx=bq, boost_k=4, boost_x=0.6)
+    acc = torch.zeros(B, dtype=torch.int32, device="cuda")
+    rec = torch.zeros(B, dtype=torch.int64, device="cuda")
+    ap = torch.zeros(B, K, device="cuda")
+    H.verify_ratio(d_lp, V8, d_lq, V8, V8, B, K, dev(spec), preds, lse_p, lse_q, dev(tt), dev(tq),
+                   dev(torch.ones(B, dtype=torch.int32)), rng(5), 2, acc, rec, None, ap, boost_idx_q=bq, boost_k=4, boost_x=0.6)
+    _, _, want_ap = O.verify_full(lp, lq, spec, tt, tq, cache_hits=hits, jit_speculate=True, sampler_x=0.6, async_fan_out=3)
+    rows_ = (tt > 0) | (tq > 0)
+    assert (ap.cpu()[rows_] - want_ap[rows_]).abs().max().item() < 2e-3

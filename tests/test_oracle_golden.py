@@ -183,3 +183,12 @@ def test_verify_stochastic_and_sampler(golden):
         assert rec == g[f"rec{jit}"].tolist()
     torch.manual_seed(5)
     assert torch.equal(O.sample(g["lp"][:, 0].clone(), g["tt"]), g["sample"])
+    # sampler_x rescaling of the draft distribution (verify.py:101-105, sampler.py:29-31)
+    torch.manual_seed(321)
+    sfx, rec, _ = O.verify_full(g["lp"], g["lq"], g["spec"], g["tt"], g["tq"], cache_hits=g["hits"], jit_speculate=True,
+                                sampler_x=0.6, async_fan_out=3)
+    for b, s in enumerate(sfx):
+        assert s == g["sfx_x"][b, :len(s)].tolist() and int((g["sfx_x"][b] >= 0).sum()) == len(s)
+    assert rec == g["rec_x"].tolist()
+    torch.manual_seed(6)
+    assert torch.equal(O.sample(g["lp"][:, 1].clone(), g["tt"], sampler_x=0.6, F=3), g["sample_x"])
