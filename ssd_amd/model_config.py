@@ -76,4 +76,10 @@ PRESETS = {
     "llama-3.1-70b": ModelConfig("llama", 8192, 80, 64, 8, 128, 28672, 128256, 1e-5, 5e5, 131072, False),
     "qwen3-32b": ModelConfig("qwen3", 5120, 64, 64, 8, 128, 25600, 151936, 1e-6, 1e6, 40960, False, True),
     "qwen3-0.6b": ModelConfig("qwen3", 1024, 28, 16, 8, 128, 3072, 151936, 1e-6, 1e6, 40960, True, True),
+    # the other sizes the reference's bench.py --size accepts (bench_helpers.py:96-120), public config.json shapes
+    "llama-3.2-3b": ModelConfig("llama", 3072, 28, 24, 8, 128, 8192, 128256, 1e-5, 5e5, 131072, True),
+    "qwen3-1.7b": ModelConfig("qwen3", 2048, 28, 16, 8, 128, 6144, 151936, 1e-6, 1e6, 40960, True, True),
+    "qwen3-4b": ModelConfig("qwen3", 2560, 36, 32, 8, 128, 9728, 151936, 1e-6, 1e6, 40960, True, True),
+    "qwen3-8b": ModelConfig("qwen3", 4096, 36, 32, 8, 128, 12288, 151936, 1e-6, 1e6, 40960, False, True),
+    "qwen3-14b": ModelConfig("qwen3", 5120, 40, 40, 8, 128, 17408, 151936, 1e-6, 1e6, 40960, False, True),
 }
