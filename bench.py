@@ -70,7 +70,7 @@ def workload_models(name):
 
 
 @torch.inference_mode()
-def gemm_roofline(engine, steps_k):
+def gemm_roofline(engine, steps_k, draft_fwd_per_step=None):
     """Time every skinny-GEMM launch shape of one speculation step with HIP events on the launch stream.
     For each (matrix kind, M) all L layers' matrices are launched back to back (L x tens of MB >> the 256 MiB
     Infinity Cache), so each launch streams its weights from HBM as in the real forward."""
@@ -78,7 +78,9 @@ def gemm_roofline(engine, steps_k):
     tot_bytes = tot_time = 0.0
     tot_launch = 0
     per_kind = {}
-    for runner, M, fwd_per_step in ((engine.model_runner, steps_k + 1, 1), (engine.draft_runner, 1, steps_k + 1)):
+    if draft_fwd_per_step is None:
+        draft_fwd_per_step = steps_k
+    for runner, M, fwd_per_step in ((engine.model_runner, steps_k + 1, 1), (engine.draft_runner, 1, draft_fwd_per_step)):
         if runner is None:
             continue
         m = runner.model
@@ -129,7 +131,7 @@ def gemm_roofline(engine, steps_k):
             "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
             "traffic_source": "separate rocprofv3 --pmc passes, profiles/r01_c2_pmc_traffic.csv (x1.0125 of algorithmic)",
-            "launches_per_step": tot_launch, "avg_launch_us": round(tot_time / tot_launch * 1e6, 2),
+            "launches_per_step": round(tot_launch, 1), "avg_launch_us": round(tot_time / tot_launch * 1e6, 2),
             "bytes_per_launch_avg": int(tot_bytes / tot_launch), "per_kind": per_kind}
 
 
@@ -227,7 +229,11 @@ def main():
 
     tb, db = engine.model_runner.model.weight_bytes(), engine.draft_runner.model.weight_bytes()
     kv_tok = lambda m: 2 * m.cfg.num_layers * m.nkv * m.hd * 2
-    step_bytes = tb + (K + 1) * db + ctx * (kv_tok(engine.model_runner.model) + (K + 1) * kv_tok(engine.draft_runner.model))
+    # draft forwards actually run per step: K chained ones + the deferred KV-deposit forward, which only follows a
+    # fully accepted round (engine/speculator_sync.py); the reference always runs K+1 (7 x 2.471 GB)
+    draft_fwd = K + sum(1 for n in lens if n == K + 1) / max(1, len(lens))
+    step_bytes = tb + draft_fwd * db + ctx * (kv_tok(engine.model_runner.model) + draft_fwd * kv_tok(engine.draft_runner.model))
+    full_accept_step_s = (dt / args.steps) * (1 + (K + 1 - draft_fwd) * db / step_bytes)
     out = {
         "metric": "output tokens/sec (sync SD, b=1, temp 0), with p50 TTFT and mean accepted length",
         "value": round(tokens / dt, 3), "unit": "tokens/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
@@ -235,17 +241,19 @@ def main():
         "dtype": "bf16", "data": "synthetic token ids (random.seed(0), randint(0,10000)) + synthetic seeded weights",
         "config": {"workload": f"{tname} target TP={args.gpus} + {dname} draft (replicated), sync speculative decoding "
                                f"k={K}, b=1, temp=0, input_len={args.input_len}, kv block 256",
-                   "steps_are": "one speculate(k+1 draft fwd)+verify(k+1-query target fwd)+accept round of the engine",
+                   "steps_are": "one speculate (k chained draft fwd; the reference's (k+1)-th, KV-deposit-only fwd runs only "
+                                "after a fully accepted round) + verify ((k+1)-query target fwd) + accept round of the engine",
                    "parallelism": f"tp{args.gpus}", "hipgraph": not args.eager},
         "mean_accepted_len": round(tokens / max(1, len(lens)), 4),
         "ttft_p50_ms": round(ttft_p50, 3),
+        "draft_forwards_per_step": round(draft_fwd, 3),
         "step_hbm_bytes_per_gpu": int(step_bytes),
         "step_roofline_frac": round(step_bytes / (dt / args.steps) / HBM_PEAK, 4),
-        "tokens_per_s_if_all_accepted": round((K + 1) / (dt / args.steps), 2),
+        "tokens_per_s_if_all_accepted": round((K + 1) / full_accept_step_s, 2),
     }
     if rank == 0 and args.gpus == 1:
         if not args.no_roofline:
-            out["roofline"] = gemm_roofline(engine, K)
+            out["roofline"] = gemm_roofline(engine, K, draft_fwd)
         if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(K)

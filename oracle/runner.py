@@ -121,24 +121,29 @@ class OracleRunner:
 
     @torch.inference_mode()
     def speculate_chain(self, seqs, recovery_tokens):
-        """K+1 sequential draft decodes from the recovery token (speculator_sync.py:47-66)."""
+        """K sequential draft decodes from the recovery token (speculator_sync.py:47-66); the (K+1)-th, KV-deposit-only
+        decode is deferred to deposit_pending, exactly like ssd_amd.engine.model_runner.ModelRunner."""
         B, K = len(seqs), self.K
         spec = torch.zeros(B, K + 1, dtype=torch.int64)
         spec[:, 0] = torch.tensor(recovery_tokens)
         cur = list(recovery_tokens)
         bt = self._bt(seqs)
         lq = []
-        for k in range(K + 1):
+        for k in range(K):
             pos = [len(s) - 1 + k for s in seqs]
             slots = [self._slot(self._table(s), p) for s, p in zip(seqs, pos)]
             lg = self._decode(cur, pos, slots, [p + 1 for p in pos], bt)
-            if k == K:
-                break
             lq.append(lg)
             cur = self._pick(lg, seqs)
             spec[:, k + 1] = torch.tensor(cur)
         self._lq = torch.stack(lq, dim=1)
         return spec
+
+    @torch.inference_mode()
+    def deposit_pending(self, seqs):
+        pos = [len(s) - 2 for s in seqs]
+        slots = [self._slot(self._table(s), p) for s, p in zip(seqs, pos)]
+        self._decode([s[p] for s, p in zip(seqs, pos)], pos, slots, [p + 1 for p in pos], self._bt(seqs))
 
     def logits_q(self, B):
         return self._lq[:B]

@@ -211,16 +211,18 @@ class ModelRunner:
         self._upload_block_tables(seqs)
         return T, max_q
 
-    def _prepare_decode(self, seqs) -> int:
-        """Single-token decode inputs (runner_helpers.py:59-75)."""
+    def _prepare_decode(self, seqs, back: int = 0) -> int:
+        """Single-token decode inputs (runner_helpers.py:59-75).  back = 1 feeds the token BEFORE the last one (the
+        deferred KV deposit of a fully accepted draft chain, see deposit_pending)."""
         ids, pos, slots, ctx = [], [], [], []
         for s in seqs:
             cached = s.num_draft_cached_tokens if self.is_draft else s.num_cached_tokens
             assert cached == len(s) - 1, "decode expects exactly one uncached token"
-            ids.append(s.last_token)
-            pos.append(len(s) - 1)
-            ctx.append(len(s))
-            slots.append(self._slot(self._table(s), len(s) - 1))
+            p = len(s) - 1 - back
+            ids.append(s.last_token if back == 0 else s[p])
+            pos.append(p)
+            ctx.append(p + 1)
+            slots.append(self._slot(self._table(s), p))
         self._note_ctx(max(ctx) + self.K + 1)
         self._upload(self.d_ids, ids, torch.int64)
         self._upload(self.d_pos, pos, torch.int64)
@@ -403,9 +405,10 @@ class ModelRunner:
     # ---- fast path of synchronous speculation: no host sync until the verify result ----
     @torch.inference_mode()
     def speculate_chain(self, seqs, recovery_tokens: list[int]) -> torch.Tensor:
-        """K+1 chained single-token draft forwards (SpeculatorSync.speculate, speculator_sync.py:47-66) starting
-        from the recovery token at position N = len(seq) - 1 (the caller has appended it).  Returns the device
-        tensor speculations [B, K+1] = (recovery, x_1..x_K); nothing is read back."""
+        """K chained single-token draft forwards (SpeculatorSync.speculate, speculator_sync.py:47-66) starting from the
+        recovery token at position N = len(seq) - 1 (the caller has appended it).  Returns the device tensor
+        speculations [B, K+1] = (recovery, x_1..x_K); nothing is read back.  The reference's (K+1)-th forward, which
+        only deposits x_K's KV, is deferred to `deposit_pending`: that KV is needed only if x_K gets accepted."""
         B, K = len(seqs), self.K
         temps = self._seq_temps(seqs)
         sample = any(t > 0 for t in temps)
@@ -432,10 +435,17 @@ class ModelRunner:
                 g.replay()
             else:
                 self._body_decode(B, True, sample=sample)
-        # the (K+1)-th forward only deposits x_K's KV: same inputs (already advanced on the device), no LM head
+        return self.d_spec[:B]
+
+    @torch.inference_mode()
+    def deposit_pending(self, seqs) -> None:
+        """The deferred (K+1)-th draft forward of the previous round (speculator_sync.py:55-56), for sequences whose K
+        draft tokens were all accepted: feed x_K (now the second-to-last token; the new recovery token has been
+        appended) at its position so that its KV exists before the next chain reads it.  No LM head, no sampling."""
+        B = len(seqs)
+        self._prepare_decode(seqs, back=1)
         if self._launch(("decode_deposit", B), lambda: self._body_decode(B, False, head=False)) == "captured":
             self.graphs[("decode_deposit", B, self._ctx_hint)].replay()     # idempotent: same token, same slot
-        return self.d_spec[:B]
 
     def logits_q(self, B: int) -> torch.Tensor:
         """[B, K, V] draft logits of the last sampled chain (temperature > 0 only)."""

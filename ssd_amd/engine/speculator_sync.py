@@ -5,10 +5,15 @@ the recovery token plus K lookahead positions to every sequence (rolled back by 
 ``num_draft_cached_tokens`` by K+1 and returns SpeculateResult(speculations [B,K+1], logits_q).
 
 What differs is where the loop runs: the reference does K+1 graph replays with a ``.tolist()`` host sync after
-each one; here ``draft_runner.speculate_chain`` enqueues all K+1 forwards back to back with the sampled token
+each one; here ``draft_runner.speculate_chain`` enqueues the forwards back to back with the sampled token
 fed forward on the device, so ``speculations`` comes back as a device tensor that nobody has read yet.  The K
 not-yet-known draft tokens are represented in ``seq.token_ids`` by the placeholder -1 until verification
 returns them (the state is restored before it could be observed).
+
+The reference's (K+1)-th forward only deposits the KV of x_K (speculator_sync.py:55-56), which a later step reads
+only if ALL K draft tokens were accepted.  It is therefore deferred: the chain runs K forwards, and the next
+``speculate`` first runs that deposit for exactly the sequences whose previous round accepted everything
+(``deposit_pending``).  Same KV values, same tokens; one seventh of the draft work gone whenever a rejection occurs.
 """
 from __future__ import annotations
 
@@ -34,6 +39,10 @@ class SpeculatorSync(SpeculatorBase):
                 raise ValueError(f"recovery_token_id is None for seq {i}")
             recovery.append(seq.recovery_token_id)
             seq.append_token(seq.recovery_token_id)
+        # suffix = [recovery] + accepted tokens: K+1 committed tokens <=> x_K was accepted and its KV is still missing
+        pending = [s for s in seqs if s.last_spec_step_accepted_len == K + 1]
+        if pending:
+            self.draft_model_runner.deposit_pending(pending)
         speculations = self.draft_model_runner.speculate_chain(seqs, recovery)
         sampled = any((s.draft_temperature if s.draft_temperature is not None else s.temperature) > 0 for s in seqs)
         for seq in seqs:

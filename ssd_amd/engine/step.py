@@ -53,6 +53,7 @@ class SpecDecodeStep(InferenceStep):
             assert seq.recovery_token_id is not None
             seq.num_cached_tokens = seq.num_prompt_tokens
             seq.num_draft_cached_tokens = seq.num_prompt_tokens
+            seq.last_spec_step_accepted_len = -1        # a (re)prefill leaves no deferred draft KV deposit behind
         return sum(len(s) for s in seqs)
 
     def decode(self, seqs) -> int:
