@@ -30,25 +30,41 @@ class OneShotAllReduce:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         torch.cuda.set_device(device)
-        self._own = []
-        slot = self._alloc(2 * SLOT_ELEMS * 2)
-        flags = self._alloc(FLAG_BYTES)
+        self._own, self._opened = [], []
+        # Every rank takes part in every collective of this constructor even if a local step failed, and the outcome is
+        # agreed on at the end: either all ranks hold a working object or all of them raise -- never a rank left
+        # waiting in a collective for a peer that bailed out.
+        mine = None
+        try:
+            slot = self._alloc(2 * SLOT_ELEMS * 2)
+            flags = self._alloc(FLAG_BYTES)
+            mine = (self._export(slot), self._export(flags))
+        except Exception:
+            mine = None
         handles = [None] * self.world
-        dist.all_gather_object(handles, (self._export(slot), self._export(flags)), group=group)
-        self._opened = []
-        slots, flgs = [], []
-        for r, (hs, hf) in enumerate(handles):
-            if r == self.rank:
-                slots.append(slot)
-                flgs.append(flags)
-            else:
-                slots.append(self._open(hs))
-                flgs.append(self._open(hf))
-        self.slots = (C.c_void_p * self.world)(*slots)
-        self.flags = (C.c_void_p * self.world)(*flgs)
-        self.counters = torch.zeros(8, dtype=torch.int32, device=device)
-        self.err = torch.zeros(1, dtype=torch.int32, device=device)
-        dist.barrier(group=group)
+        dist.all_gather_object(handles, mine, group=group)
+        ok = all(h is not None for h in handles)
+        if ok:
+            try:
+                slots, flgs = [], []
+                for r, (hs, hf) in enumerate(handles):
+                    if r == self.rank:
+                        slots.append(slot)
+                        flgs.append(flags)
+                    else:
+                        slots.append(self._open(hs))
+                        flgs.append(self._open(hf))
+                self.slots = (C.c_void_p * self.world)(*slots)
+                self.flags = (C.c_void_p * self.world)(*flgs)
+                self.counters = torch.zeros(8, dtype=torch.int32, device=device)
+                self.err = torch.zeros(1, dtype=torch.int32, device=device)
+            except Exception:
+                ok = False
+        verdict = [None] * self.world
+        dist.all_gather_object(verdict, bool(ok), group=group)      # doubles as the barrier after the IPC opens
+        if not all(verdict):
+            self.close()
+            raise RuntimeError("one-shot all-reduce setup failed on at least one rank")
 
     def _alloc(self, nbytes: int) -> int:
         p = C.c_void_p()
