@@ -142,7 +142,10 @@ class LoopbackTransport:
         return v
 
     def send_tensor(self, t):
-        self.to_peer.append(t.clone())
+        t = t.clone()
+        if t.is_cuda:       # the endpoints may issue work on different streams: hand over finished data only
+            torch.cuda.current_stream(t.device).synchronize()
+        self.to_peer.append(t)
 
     def recv_tensor(self, shape, dtype):
         if not self.from_peer and self.pump is not None:

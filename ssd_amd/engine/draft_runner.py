@@ -29,8 +29,14 @@ def branch_positions(fan_out: list[int]) -> list[int]:
 
 
 class DraftServer:
-    def __init__(self, config, runner, transport):
+    def __init__(self, config, runner, transport, stream=None, deferred: bool = False):
+        """stream / deferred: co-located mode (the server shares the target's process and GPU).  All draft work is
+        issued on `stream` so that it overlaps the target's verify on the device, and the work that follows the reply
+        (glue + fork + tree decode) is parked until the target has launched its verify (`run_deferred`, called from
+        ModelRunner.verify_chain just before it blocks), instead of delaying that launch."""
         self.config, self.runner, self.tx = config, runner, transport
+        self.stream, self.deferred = stream, deferred
+        self._parked = None
         self.K = config.speculate_k
         self.mq = config.MQ_LEN
         self.max_blocks = config.max_blocks
@@ -44,7 +50,22 @@ class DraftServer:
         self.stats = {"requests": 0, "hits": 0, "rounds": 0}
 
     # ---- one command ----
+    def run_deferred(self) -> None:
+        work, self._parked = self._parked, None
+        if work is not None:
+            self._on_stream(work)
+
+    def _on_stream(self, fn):
+        if self.stream is None:
+            return fn()
+        with torch.cuda.stream(self.stream):
+            return fn()
+
     def handle_one(self) -> bool:
+        self.run_deferred()          # nothing may overtake a parked round
+        return self._on_stream(self._handle_one)
+
+    def _handle_one(self) -> bool:
         cmd, B, n, flags = self.tx.recv_ints(P.HEADER_LEN)
         if cmd == P.CMD_EXIT:
             return False
@@ -113,13 +134,19 @@ class DraftServer:
                 logits_q = torch.zeros(B, K, self.runner.cfg.vocab_size, dtype=torch.bfloat16, device=tokens.device)
             self.tx.send_tensor(logits_q)
         # ---- from here on the target is verifying; pre-compute the next round's cache ----
-        fan = [self.config.fan_out_list if h else self.config.fan_out_list_miss for h in hits]
-        jl = [self.j_hit if h else self.j_miss for h in hits]
-        glue_ids = torch.cat([torch.tensor(rec, dtype=torch.int64, device=tokens.device).unsqueeze(1), tokens], dim=1)
-        forks = self.runner.draft_glue_fork(glue_ids, num_tokens, tables, fan)          # [B, MQ]
-        self.cache_tokens = self.runner.draft_tree(forks, num_tokens, tables, jl, temps)  # [B*MQ, K]
-        self.cache_logits = self.runner.tree_logits(B * self.mq) if sample else None
-        self.pending_forks = forks
-        self.pending_meta = ([k[0] for k in keys], jl)
+        def next_round():
+            fan = [self.config.fan_out_list if h else self.config.fan_out_list_miss for h in hits]
+            jl = [self.j_hit if h else self.j_miss for h in hits]
+            glue_ids = torch.cat([torch.tensor(rec, dtype=torch.int64, device=tokens.device).unsqueeze(1), tokens], dim=1)
+            forks = self.runner.draft_glue_fork(glue_ids, num_tokens, tables, fan)          # [B, MQ]
+            self.cache_tokens = self.runner.draft_tree(forks, num_tokens, tables, jl, temps)  # [B*MQ, K]
+            self.cache_logits = self.runner.tree_logits(B * self.mq) if sample else None
+            self.pending_forks = forks
+            self.pending_meta = ([k[0] for k in keys], jl)
+            self.stats["rounds"] += 1
         self.cache_keys = {}
-        self.stats["rounds"] += 1
+        self.cache_tokens = None
+        if self.deferred:
+            self._parked = next_round
+        else:
+            next_round()

@@ -114,7 +114,12 @@ class LLMEngine:
                 transport, server_end = LoopbackTransport.pair()
                 self.draft_runner = factory(config, config.draft_hf_config, is_draft=True, topo=self.topo,
                                             memory_utilization=0.75, num_kvcache_blocks=config.num_draft_kvcache_blocks)
-                self.draft_server = DraftServer(config, self.draft_runner, server_end)
+                # co-located draft: its own stream, next-round work parked until the target's verify is in flight
+                on_gpu = self.topo.device.type == "cuda"
+                side = torch.cuda.Stream(self.topo.device) if on_gpu and os.environ.get("SSD_COLOCATED_OVERLAP", "1") != "0" else None
+                self.draft_server = DraftServer(config, self.draft_runner, server_end, stream=side, deferred=side is not None)
+                if side is not None:
+                    self.model_runner.overlap_hook = self.draft_server.run_deferred
 
                 def pump(server=self.draft_server, end=server_end):
                     while end.from_peer:

@@ -483,6 +483,11 @@ class ModelRunner:
             stage()
             self.graphs[(*key, self._ctx_hint)].replay()
         self.h_packed[:B].copy_(self.d_packed[:B], non_blocking=True)
+        # the verify is in flight and the host is about to block on it: the moment for a co-located draft server to
+        # enqueue its next round on its own stream (engine/draft_runner.py run_deferred)
+        hook = getattr(self, "overlap_hook", None)
+        if hook is not None:
+            hook()
         torch.cuda.current_stream().synchronize()
         self._check_collectives()
         rows = self.h_packed[:B].tolist()
