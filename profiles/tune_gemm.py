@@ -19,6 +19,9 @@ SHAPES = {
     "70b_tp8": [(1280, 8192), (8192, 1024), (7168, 8192), (8192, 3584), (16032, 8192)],
 }
 MS = {"1b": [1, 24], "8b": [7], "70b_tp1": [7], "70b_tp4": [7], "70b_tp8": [7]}
+TPWS = (1, 2, 3, 4, 7, 8)      # consecutive tiles per workgroup (persistent variant), encoded in bits 8.. of `waves`
+if len(sys.argv) > 1:
+    SHAPES = {k: v for k, v in SHAPES.items() if k in sys.argv[1:]}
 
 
 @torch.inference_mode()
@@ -67,18 +70,24 @@ def main():
                     if nt == 4 and M > 32:
                         continue
                     for waves in (4, 8, 16):
-                        t = time_cfg(ws, x, y, M, N, K, epi, (nt, waves))
-                        if t is None:
-                            continue
-                        rows.append((nt, waves, t))
-                        if best is None or t < best[2]:
-                            best = (nt, waves, t)
+                        for tpw in TPWS:
+                            if tpw > 1 and (N // 16 // nt) // tpw < 128:
+                                continue
+                            t = time_cfg(ws, x, y, M, N, K, epi, (nt, waves | (tpw << 8)))
+                            if t is None:
+                                continue
+                            rows.append((nt, waves, tpw, t))
+                            if best is None or t < best[-1]:
+                                best = (nt, waves, tpw, t)
                 tdef = time_cfg(ws, x, y, M, N, K, epi, None)
                 key = f"{M},{N},{K}"
-                out[key] = {"best": [best[0], best[1]], "best_us": round(best[2] * 1e6, 2), "default_us": round(tdef * 1e6, 2),
-                            "GBps_best": round(bytes_ / best[2] / 1e9), "MB": round(bytes_ / 1e6, 1)}
-                print(f"{fam:8s} M={M:3d} N={N:6d} K={K:5d} {bytes_ / 1e6:7.1f}MB default {tdef * 1e6:7.2f}us  best {best[0]},{best[1]:2d} {best[2] * 1e6:7.2f}us "
-                      f"({bytes_ / best[2] / 1e9:5.0f} GB/s)  all: " + " ".join(f"{a},{b}:{c * 1e6:.1f}" for a, b, c in rows), file=sys.stderr)
+                out[key] = {"best": list(best[:3]), "best_us": round(best[3] * 1e6, 2), "default_us": round(tdef * 1e6, 2),
+                            "GBps_best": round(bytes_ / best[3] / 1e9), "MB": round(bytes_ / 1e6, 1)}
+                top = sorted(rows, key=lambda r: r[3])[:6]
+                print(f"{fam:8s} M={M:3d} N={N:6d} K={K:5d} {bytes_ / 1e6:7.1f}MB default {tdef * 1e6:7.2f}us  best nt{best[0]},w{best[1]},t{best[2]} "
+                      f"{best[3] * 1e6:7.2f}us ({bytes_ / best[3] / 1e9:5.0f} GB/s)  top: "
+                      + " ".join(f"{a},{b},{c}:{d * 1e6:.1f}" for a, b, c, d in top)
+                      + "  tpw=1 best: " + f"{min(r[3] for r in rows if r[2] == 1) * 1e6:.1f}", file=sys.stderr)
             del ws
             torch.cuda.empty_cache()
     print(json.dumps(out))

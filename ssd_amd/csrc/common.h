@@ -56,3 +56,27 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// Default decomposition of the skinny (M <= 16 token rows) weight-streaming GEMMs, from the MI355X sweep in
+// profiles/r01_gemm_tune_sweep.txt (python profiles/tune_gemm.py): groups = N / 16 row groups, KT = K / 32 k-tiles.
+//   nt    row groups per workgroup (x operand amortised over nt weight tiles; fewer, fatter workgroups)
+//   waves K-split inside the workgroup
+//   tpw   consecutive tiles per workgroup (gemm.hip only)
+static inline void ssd_pick_skinny_cfg(int groups, int KT, bool silu_pairs, int* nt, int* waves, int* tpw) {
+  int n = 1, w = 8, t = 1;
+  if (silu_pairs) {                       // gate_up: row groups come in (gate, up) pairs -> nt even
+    n = (groups >= 1792 && groups % 4 == 0) ? 4 : 2;
+    if (n == 4 && KT <= 128) { w = 16; t = 2; }
+  } else if (groups >= 4096) {            // LM heads
+    n = (groups % 2 == 0) ? 2 : 1;
+    if (KT >= 128) { w = 16; t = 8; }
+  } else if (groups >= 1000 && KT >= 256 && groups % 2 == 0) {   // vocabulary shards
+    n = 2; w = 16; t = 2;
+  } else if (groups >= 640 && KT >= 256 && groups % 4 == 0) {    // 70B-class qkv
+    n = 4;
+  } else if (groups >= 512 && KT >= 512 && groups % 2 == 0) {    // 70B-class down_proj: few row groups, very long K
+    n = 2; w = 16;
+  }
+  while (w > 1 && KT / w < 2) w >>= 1;    // every wave needs a couple of k-tiles
+  *nt = n; *waves = w; *tpw = t;
+}

@@ -24,30 +24,26 @@ struct Stage {
 template <int MT, int NT, int EPI>
 __global__ void __launch_bounds__(1024)
 gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
-               const bf16_t* __restrict__ bias, void* __restrict__ Yv, int M, int N, int K, int ldy) {
+               const bf16_t* __restrict__ bias, void* __restrict__ Yv, int M, int N, int K, int ldy, int tpw) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nw = blockDim.x >> 6;
   const int KT = K >> 5;
-  const int tile0 = blockIdx.x * NT;
   const int kt0 = (int)(((long)KT * wave) / nw);
   const int kt1 = (int)(((long)KT * (wave + 1)) / nw);
-
-  f32x4_t acc[NT][MT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  const u32x4_t* wp = Wf + ((size_t)tile0 * KT << 6) + lane;
+  // A workgroup owns `tpw` CONSECUTIVE tiles of NT row groups = one contiguous slab of W (long sequential DRAM runs, no
+  // tail of half-empty workgroup rounds), and the first loads of the next tile are issued before the cross-wave
+  // combine + epilogue of the current one, so the memory pipe never drains inside a workgroup.
+  const int ntiles = (N / 16) / NT;
+  const int t_begin = blockIdx.x * tpw, t_end = min(ntiles, t_begin + tpw);
   const u32x4_t* xp = Xf + lane;
   const size_t wstride = (size_t)KT << 6;  // chunks between adjacent row groups
   const size_t xstride = (size_t)KT << 6;
-
   constexpr int U = (MT + NT <= 3) ? 4 : ((MT + NT <= 6) ? 2 : 1);
   Stage<MT, NT> cur[U], nxt[U];
-
+  const int kmain = kt0 + ((kt1 - kt0) / U) * U;
+  const u32x4_t* wp = Wf + ((size_t)t_begin * NT * KT << 6) + lane;
   auto load = [&](Stage<MT, NT>(&s)[U], int kt) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -58,6 +54,16 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
       for (int mt = 0; mt < MT; ++mt) s[u].b[mt] = xp[mt * xstride + ((size_t)(kt + u) << 6)];
     }
   };
+  if (t_begin < t_end && kt0 < kmain) load(cur, kt0);
+
+  for (int tile = t_begin; tile < t_end; ++tile) {
+  const int tile0 = tile * NT;
+  f32x4_t acc[NT][MT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
   auto compute = [&](Stage<MT, NT>(&s)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -68,9 +74,7 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
   };
 
   int kt = kt0;
-  const int kmain = kt0 + ((kt1 - kt0) / U) * U;
   if (kt < kmain) {
-    load(cur, kt);
     for (; kt + U < kmain; kt += U) {
       load(nxt, kt + U);
       compute(cur);
@@ -88,6 +92,10 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
       for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mfma16(a, xp[mt * xstride + ((size_t)kt << 6)], acc[nt][mt]);
     }
   }
+
+  // next tile: advance the weight pointer and put its first loads in flight before the combine
+  wp += (size_t)NT * wstride;
+  if (tile + 1 < t_end && kt0 < kmain) load(cur, kt0);
 
   // ---- cross-wave split-K combine through LDS, fixed order ----
   f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);  // [nw][NT*MT][64]
@@ -151,6 +159,8 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
       }
     }
   }
+  __syncthreads();   // the combine area is reused by the next tile
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -159,8 +169,10 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
 // ---------------------------------------------------------------------------------------------
 template <int MT, int NT, int EPI>
 static int launch_t(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int ldy,
-                    int waves, hipStream_t st) {
-  const int blocks = (N / 16) / NT;
+                    int waves, int tpw, hipStream_t st) {
+  const int ntiles = (N / 16) / NT;
+  if (tpw < 1) tpw = 1;
+  const int blocks = (ntiles + tpw - 1) / tpw;
   const size_t lds = (size_t)waves * NT * MT * 64 * sizeof(f32x4_t);
   auto kern = gemm_wf_kernel<MT, NT, EPI>;
   if (lds > 64 * 1024) {
@@ -168,28 +180,32 @@ static int launch_t(const void* x, const void* w, const void* bias, void* y, int
       return SSD_ERR_LAUNCH;
   }
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, st, (const u32x4_t*)w, (const u32x4_t*)x,
-                     (const bf16_t*)bias, y, M, N, K, ldy);
+                     (const bf16_t*)bias, y, M, N, K, ldy, tpw);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
 template <int MT, int EPI>
 static int launch_nt(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int ldy,
-                     int nt, int waves, hipStream_t st) {
+                     int nt, int waves, int tpw, hipStream_t st) {
   if (nt == 1) {
     if constexpr (EPI == EPI_SILU_FRAG) return SSD_ERR_ARG;
-    else return launch_t<MT, 1, EPI>(x, w, bias, y, M, N, K, ldy, waves, st);
+    else return launch_t<MT, 1, EPI>(x, w, bias, y, M, N, K, ldy, waves, tpw, st);
   }
-  if (nt == 2) return launch_t<MT, 2, EPI>(x, w, bias, y, M, N, K, ldy, waves, st);
+  if (nt == 2) return launch_t<MT, 2, EPI>(x, w, bias, y, M, N, K, ldy, waves, tpw, st);
   if (nt == 4) {
     if constexpr (MT > 2) return SSD_ERR_ARG;
-    else return launch_t<MT, 4, EPI>(x, w, bias, y, M, N, K, ldy, waves, st);
+    else return launch_t<MT, 4, EPI>(x, w, bias, y, M, N, K, ldy, waves, tpw, st);
   }
   return SSD_ERR_ARG;
 }
 
+// `waves` may carry the tiles-per-workgroup count in bits 8..15 (0 = 1): a workgroup then streams that many consecutive
+// tiles of nt row groups.
 extern "C" int ssd_gemm_wf_cfg(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N,
                                int K, int ldy, int epilogue, int nt, int waves, void* stream) {
   if (M <= 0 || M > 128 || (N & 15) || (K & 31) || N <= 0 || K <= 0) return SSD_ERR_SHAPE;
+  const int tpw = (waves >> 8) & 0xff;
+  waves &= 0xff;
   if (waves < 1 || waves > 16) return SSD_ERR_ARG;
   if (((N / 16) % nt) != 0) return SSD_ERR_ARG;
   if (epilogue == EPI_SILU_FRAG && (nt & 1)) return SSD_ERR_ARG;
@@ -197,9 +213,9 @@ extern "C" int ssd_gemm_wf_cfg(const void* x_frag, const void* w_frag, const voi
   const int mt = (M + 15) / 16;
 #define DISPATCH_MT(MTV)                                                                                         \
   switch (epilogue) {                                                                                            \
-    case EPI_ROWS: return launch_nt<MTV, EPI_ROWS>(x_frag, w_frag, bias, y, M, N, K, ldy, nt, waves, st);         \
-    case EPI_SILU_FRAG: return launch_nt<MTV, EPI_SILU_FRAG>(x_frag, w_frag, bias, y, M, N, K, ldy, nt, waves, st); \
-    case EPI_ROWS_F32: return launch_nt<MTV, EPI_ROWS_F32>(x_frag, w_frag, bias, y, M, N, K, ldy, nt, waves, st); \
+    case EPI_ROWS: return launch_nt<MTV, EPI_ROWS>(x_frag, w_frag, bias, y, M, N, K, ldy, nt, waves, tpw, st);         \
+    case EPI_SILU_FRAG: return launch_nt<MTV, EPI_SILU_FRAG>(x_frag, w_frag, bias, y, M, N, K, ldy, nt, waves, tpw, st); \
+    case EPI_ROWS_F32: return launch_nt<MTV, EPI_ROWS_F32>(x_frag, w_frag, bias, y, M, N, K, ldy, nt, waves, tpw, st); \
     default: return SSD_ERR_ARG;                                                                                 \
   }
   if (mt == 1) { DISPATCH_MT(1) }
@@ -214,6 +230,11 @@ extern "C" int ssd_gemm_wf(const void* x_frag, const void* w_frag, const void* b
                            int K, int ldy, int epilogue, void* stream) {
   if ((N & 15) || (K & 31) || N <= 0 || K <= 0) return SSD_ERR_SHAPE;
   const int groups = N / 16, KT = K / 32, mt = (M + 15) / 16;
+  if (mt == 1) {       // decode / verify rows: the tuned table
+    int nt1, waves1, tpw1;
+    ssd_pick_skinny_cfg(groups, KT, epilogue == EPI_SILU_FRAG, &nt1, &waves1, &tpw1);
+    return ssd_gemm_wf_cfg(x_frag, w_frag, bias, y, M, N, K, ldy, epilogue, nt1, waves1 | (tpw1 << 8), stream);
+  }
   int nt = 1;
   if (epilogue == EPI_SILU_FRAG) nt = 2;
   else if (mt >= 4 && groups % 2 == 0) nt = 2;          // amortise the larger x operand

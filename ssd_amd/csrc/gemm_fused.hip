@@ -355,14 +355,11 @@ extern "C" int ssd_gemm_fused(const void* x_frag, const void* h_rows, const void
   if (h_rows && !norm_w) return SSD_ERR_ARG;
   if (res_out && res_out == res_in) return SSD_ERR_ARG;                   // in-place residual would race
   const int groups = N / 16;
-  if (nt <= 0) {
-    nt = (epilogue == FEPI_SILU_FRAG) ? 2 : 1;
-    if (groups >= 2048 && groups % 2 == 0) nt = 2;
-  }
-  if (waves <= 0) {
-    waves = 16;
-    while (waves > 1 && (K / 32) / waves < 4) waves >>= 1;
-    if (groups / nt >= 1024 && waves > 8) waves = 8;
+  if (nt <= 0 || waves <= 0) {
+    int nt1, waves1, tpw1;
+    ssd_pick_skinny_cfg(groups, K / 32, epilogue == FEPI_SILU_FRAG, &nt1, &waves1, &tpw1);
+    if (nt <= 0) nt = nt1;
+    if (waves <= 0) waves = waves1;
   }
   if (waves > 16 || groups % nt) return SSD_ERR_ARG;
   if (epilogue == FEPI_SILU_FRAG && (nt & 1)) return SSD_ERR_ARG;
