@@ -274,7 +274,7 @@ class HipDecoder:
         if norm_fuse:
             H.gemm_fused(w[p + "mlp.gate_up_proj.weight"], T, 2 * self.I, self.h, H.FEPI_SILU_FRAG, h_rows=self.buf_h,
                          res_in=self.buf_res2, res_out=self.buf_res, norm_w=w[p + "post_attention_layernorm.weight"],
-                         eps=cfg.rms_norm_eps, y=self.buf_actf, waves=16)
+                         eps=cfg.rms_norm_eps, y=self.buf_actf, waves=8)     # profiles/micro/fused_probe.py: 13.2 us vs 16.4 (16 waves)
         else:
             if not gemm_only and not pre_normed:
                 H.rmsnorm(self.buf_h, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps, T, self.h,
