@@ -423,18 +423,14 @@ class ModelRunner:
             if sample:
                 self._upload(self.d_temps, temps, torch.float32)
 
-        stage()
-        first = 0
-        if self._launch(key, lambda: self._body_decode(B, True, sample=sample)) == "captured":
-            stage()                      # the warm-up + capture runs disturbed the chained state
-        else:
-            first = 1
-        g = self.graphs.get((*key, self._ctx_hint))
-        for _ in range(first, K):
-            if g is not None:
-                g.replay()
-            else:
+        def chain():                     # all K forwards in ONE hipGraph: no host gap between them
+            for _ in range(K):
                 self._body_decode(B, True, sample=sample)
+
+        stage()
+        if self._launch(key, chain) == "captured":
+            stage()                      # the warm-up + capture runs disturbed the chained state
+            self.graphs[(*key, self._ctx_hint)].replay()
         return self.d_spec[:B]
 
     @torch.inference_mode()
@@ -558,18 +554,14 @@ class ModelRunner:
             if sample:
                 self._upload(self.d_temps, list(temps), torch.float32)
 
-        stage()
-        first = 0
-        if self._launch(key, lambda: self._body_decode(B, True, sample=sample)) == "captured":
-            stage()
-        else:
-            first = 1
-        g = self.graphs.get((*key, self._ctx_hint))
-        for _ in range(first, K):
-            if g is not None:
-                g.replay()
-            else:
+        def chain():
+            for _ in range(K):
                 self._body_decode(B, True, sample=sample)
+
+        stage()
+        if self._launch(key, chain) == "captured":
+            stage()
+            self.graphs[(*key, self._ctx_hint)].replay()
         return self.d_spec[:B, 1:].clone()
 
     def _body_glue_fork(self, B: int) -> None:
@@ -685,16 +677,15 @@ class ModelRunner:
             if sample:
                 self._upload(self.d_temps, list(temps), torch.float32)
 
+        def all_steps():                 # the K tree steps in ONE hipGraph (each step has its own static metadata rows)
+            for d in range(K):
+                self._body_tree(B, d, sample)
+
         stage()
-        for d in range(K):
-            key = ("tree_s" if sample else "tree", B, d)
-            if self._launch(key, lambda d=d: self._body_tree(B, d, sample)) == "captured":
-                # the eager warm-up already advanced the chain by one step; restore this step's inputs and replay
-                if d == 0:
-                    self.d_ids[:T].copy_(forks.reshape(-1))
-                else:
-                    self.d_ids[:T].copy_(self.d_tree_tokens[:T, d - 1])
-                self.graphs[(*key, self._ctx_hint)].replay()
+        key = ("tree_s" if sample else "tree", B)
+        if self._launch(key, all_steps) == "captured":
+            self.d_ids[:T].copy_(forks.reshape(-1))      # the eager warm-up consumed the inputs
+            self.graphs[(*key, self._ctx_hint)].replay()
         return self.d_tree_tokens[:T].clone()
 
     def tree_logits(self, T: int) -> torch.Tensor:
