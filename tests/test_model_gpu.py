@@ -333,3 +333,51 @@ def test_prefill_gemm_kernel_in_engine(gpu, monkeypatch):
         n = common_prefix(a["token_ids"], b["token_ids"])
         print("prefill-gemm engine: identical tokens", n, "of", len(b["token_ids"]))
         assert n >= 6
+
+
+def test_llm_from_model_directory_safetensors(gpu, tmp_path):
+    """The real-weight path end to end: `LLM(<dir>)` with a HF-style config.json + model.safetensors (q/k/v and gate/up
+    stored separately, as HF does; loader.py:186-218 packs them) for target AND draft must produce exactly the tokens of
+    the same engine fed the same tensors directly."""
+    import json
+    from safetensors.torch import save_file
+    from ssd_amd import weights as W
+    from ssd_amd.llm import LLM
+    from ssd_amd.model_config import ModelConfig
+    from ssd_amd.sampling_params import SamplingParams
+
+    def write_dir(path, cfg, seed):
+        path.mkdir()
+        full = W.synthetic_state_dict(cfg, seed, 0.1)
+        hf = {}
+        hd, nh, nkv, I = cfg.head_dim, cfg.num_heads, cfg.num_kv_heads, cfg.intermediate_size
+        for name, w in full.items():
+            if "qkv_proj" in name:
+                for s, x in zip(("q_proj", "k_proj", "v_proj"), w.split([nh * hd, nkv * hd, nkv * hd], 0)):
+                    hf[name.replace("qkv_proj", s)] = x.contiguous()
+            elif "gate_up_proj" in name:
+                for s, x in zip(("gate_proj", "up_proj"), w.split([I, I], 0)):
+                    hf[name.replace("gate_up_proj", s)] = x.contiguous()
+            else:
+                hf[name] = w
+        save_file(hf, str(path / "model.safetensors"))
+        (path / "config.json").write_text(json.dumps({
+            "model_type": "llama", "architectures": ["LlamaForCausalLM"], "hidden_size": cfg.hidden_size,
+            "num_hidden_layers": cfg.num_layers, "num_attention_heads": nh, "num_key_value_heads": nkv, "head_dim": hd,
+            "intermediate_size": I, "vocab_size": cfg.vocab_size, "rms_norm_eps": cfg.rms_norm_eps, "rope_theta": cfg.rope_theta,
+            "max_position_embeddings": cfg.max_position_embeddings, "tie_word_embeddings": cfg.tie_word_embeddings,
+            "torch_dtype": "bfloat16"}))
+        return full
+
+    t = ModelConfig("llama", 256, 2, 4, 2, 64, 512, 512, 1e-5, 5e5, 1024, False)
+    d = ModelConfig("llama", 128, 1, 2, 1, 64, 256, 512, 1e-5, 5e5, 1024, True)
+    wt = write_dir(tmp_path / "target", t, 11)
+    wd = write_dir(tmp_path / "draft", d, 12)
+    kw = dict(speculate=True, speculate_k=3, max_num_seqs=2, max_model_len=256, max_num_batched_tokens=256, kvcache_block_size=16,
+              num_kvcache_blocks=32, num_draft_kvcache_blocks=32)
+    prompts = [[(9 * j + 2) % 512 for j in range(20)], [(5 * j + 1) % 512 for j in range(33)]]
+    sp = SamplingParams(temperature=0, max_new_tokens=12, ignore_eos=True)
+    from_dir, _ = LLM(str(tmp_path / "target"), draft=str(tmp_path / "draft"), **kw).generate(prompts, sp, use_tqdm=False)
+    direct, _ = LLM("t", hf_config=t, draft="d", draft_hf_config=d, runner_factory=hip_factory(wt, wd), **kw).generate(prompts, sp, use_tqdm=False)
+    assert [o["token_ids"] for o in from_dir] == [o["token_ids"] for o in direct]
+    assert all(o["text"] == "" for o in from_dir)          # no tokenizer files in the directory
