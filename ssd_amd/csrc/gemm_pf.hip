@@ -21,12 +21,12 @@ enum { PF_EPI_ROWS = 0, PF_EPI_SILU_FRAG = 1 };
 constexpr int PF_WAVES = 4;
 constexpr int PF_U = 4;      // k-steps of W in flight per wave; every K split is a multiple of this many k-steps
 
-template <int MT, int NT>
+template <int MT, int NT, int UU>
 __global__ void __launch_bounds__(256, 2)
 gemm_pf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, float* __restrict__ ws,
                int M, int N, int K, int kt_per_split, int mt_valid) {
   __shared__ u32x4_t xs[2][MT][64];                      // ring of two k-steps, MT fragment tiles each
-  constexpr int U = PF_U;                                 // W k-steps in flight per wave
+  constexpr int U = UU;                                   // W k-steps in flight per wave (nk is a multiple of it)
   constexpr int FPW = (MT + PF_WAVES - 1) / PF_WAVES;     // x fragment tiles each wave fetches per k-step
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -85,7 +85,7 @@ gemm_pf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, f
   for (int u = 0; u < U; ++u) load_w(a[u], u);
   load_x(xr[1], 1);
   stage_x(xr[0], 0);
-  load_x(xr[0], 2);          // nk >= U = 4 > 2
+  load_x(xr[0], 2);          // nk >= U >= 4 > 2
   __syncthreads();
   const int klast = nk - 1;
   for (int kt = 0; kt < nk; kt += U) {
@@ -165,8 +165,14 @@ template <int MT, int NT>
 static int pf_launch(const void* x, const void* w, float* ws, int M, int N, int K, int splits, hipStream_t st) {
   const int KT = K >> 5;
   dim3 grid(N / (16 * NT * PF_WAVES), splits);
-  hipLaunchKernelGGL((gemm_pf_kernel<MT, NT>), grid, dim3(64 * PF_WAVES), 0, st, (const u32x4_t*)w, (const u32x4_t*)x, ws,
-                     M, N, K, KT / splits, (M + 15) / 16);
+  const int nk = KT / splits;
+  // the narrow tile (NT = 2) has the registers to keep 8 k-steps of W in flight per wave
+  if (NT == 2 && nk % 8 == 0)
+    hipLaunchKernelGGL((gemm_pf_kernel<MT, NT, (NT == 2 ? 8 : PF_U)>), grid, dim3(64 * PF_WAVES), 0, st, (const u32x4_t*)w,
+                       (const u32x4_t*)x, ws, M, N, K, nk, (M + 15) / 16);
+  else
+    hipLaunchKernelGGL((gemm_pf_kernel<MT, NT, PF_U>), grid, dim3(64 * PF_WAVES), 0, st, (const u32x4_t*)w, (const u32x4_t*)x, ws,
+                       M, N, K, nk, (M + 15) / 16);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
