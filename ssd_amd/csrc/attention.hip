@@ -38,12 +38,6 @@ struct AttnParams {
   float scale_log2e;
 };
 
-template <int HD>
-__device__ __forceinline__ const bf16_t* kv_row(const bf16_t* base, const int32_t* bt, int key, int h, int nkv, int bs) {
-  const int page = bt[key / bs];
-  return base + (((size_t)page * nkv + h) * bs + (key % bs)) * HD;
-}
-
 // LDS per wave: the V tile (32 keys x HD bf16) during the scan, then the wave's partial (O fp32 [RT*16][HD],
 // m/l [RT*16][2]) for the in-block merge.
 template <int HD, int RT>

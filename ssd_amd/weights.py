@@ -95,8 +95,6 @@ def synthetic_state_dict(cfg: ModelConfig, seed: int, std: float, norm_jitter: f
 # --------------------------------------------------------------------------------------------------
 # HF safetensors (reference ssd/utils/loader.py:186-218): q/k/v and gate/up are packed by concatenation
 # --------------------------------------------------------------------------------------------------
-_PACK = {"q_proj": ("qkv_proj", 0), "k_proj": ("qkv_proj", 1), "v_proj": ("qkv_proj", 2),
-         "gate_proj": ("gate_up_proj", 0), "up_proj": ("gate_up_proj", 1)}
 
 
 def has_safetensors(model_dir: str) -> bool:
@@ -117,8 +115,6 @@ def load_safetensors(cfg: ModelConfig, model_dir: str, rank: int = 0, tp: int = 
             return sf.get_tensor(name).to(BF16)
 
     def packed_sources(name: str) -> list[str] | None:
-        for src, (dst, _) in _PACK.items():
-            pass
         if "qkv_proj" in name:
             return [name.replace("qkv_proj", s) for s in ("q_proj", "k_proj", "v_proj")]
         if "gate_up_proj" in name:
