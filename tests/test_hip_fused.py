@@ -1,5 +1,7 @@
 """GPU parity of the fused decode-layer GEMMs (csrc/gemm_fused.hip) and of the rotation-paired QKV layout against
 the oracle chain  add+RMSNorm -> linear -> RoPE -> KV store  /  add+RMSNorm -> linear -> SiLU*mul."""
+import math
+
 import pytest
 import torch
 
@@ -92,6 +94,20 @@ def test_fused_qkv_rope(H, M, nh, nkv, hd, K, with_res, xnorm):
     assert_close_bf16(q_out, q, what="fused q", **tol)
     assert_close_bf16(LY.kv_hnd_to_nhd(kc.cpu()), kref, what="fused k cache", **tol)
     assert_close_bf16(LY.kv_hnd_to_nhd(vc.cpu()), vref, what="fused v cache", **tol)
+    # every decomposition of the RoPE-epilogue kernel (the tuned default picks nt = 4 for 70B-class shapes)
+    # (a 1-ulp flip of a pre-RoPE value moves x*cos - y*sin by up to that ulp, however small the rotated result is:
+    # other accumulation orders are compared with an absolute floor of one ulp of the largest pre-RoPE magnitude)
+    tol_v = dict(tol, abs_floor=float(2.0 ** (math.floor(math.log2(max(q.abs().max().item(), 1e-3))) - 7)))
+    if not xnorm:
+        for nt, waves in ((1, 4), (2, 8), (4, 8), (4, 16), (2, 2)):
+            if (N // 16) % nt:
+                continue
+            q3, kc3, vc3 = torch.zeros_like(q_out), torch.zeros_like(kc), torch.zeros_like(vc)
+            H.gemm_fused(wf, M, N, K, H.FEPI_QKV_ROPE, x_frag=dev(LY.rows_to_frag_ref(x)), nt=nt, waves=waves,
+                         **dict(common, q_out=q3, k_cache=kc3, v_cache=vc3))
+            assert_close_bf16(q3, q, what=f"fused q nt{nt} w{waves}", **tol_v)
+            assert_close_bf16(LY.kv_hnd_to_nhd(kc3.cpu()), kref, what=f"fused k nt{nt} w{waves}", **tol_v)
+            assert_close_bf16(LY.kv_hnd_to_nhd(vc3.cpu()), vref, what=f"fused v nt{nt} w{waves}", **tol_v)
     # the unfused pair (generic GEMM on the same weights, then rope_store with qkv_perm=1) must agree too
     y = torch.zeros(M, N, dtype=BF, device="cuda")
     H.gemm(dev(LY.rows_to_frag_ref(x)), wf, y, M, N, K, N, bias=bias_p)
