@@ -381,3 +381,34 @@ def test_llm_from_model_directory_safetensors(gpu, tmp_path):
     direct, _ = LLM("t", hf_config=t, draft="d", draft_hf_config=d, runner_factory=hip_factory(wt, wd), **kw).generate(prompts, sp, use_tqdm=False)
     assert [o["token_ids"] for o in from_dir] == [o["token_ids"] for o in direct]
     assert all(o["text"] == "" for o in from_dir)          # no tokenizer files in the directory
+
+
+def test_full_size_1b_speculation_is_exact(gpu):
+    """Size-independent property at a BASELINE.json model size (Llama-3.2-1B shapes, block size 256, hipGraphs): with
+    draft == target, speculative decoding -- synchronous and asynchronous -- must reproduce plain autoregressive
+    decoding and accept (almost) every draft token; the only admissible deviations are near-ties between the M=1
+    decode and the M=K+1 verify launches of the same matrices."""
+    from ssd_amd.engine.llm_engine import LLMEngine
+    from ssd_amd.model_config import PRESETS
+    from ssd_amd.sampling_params import SamplingParams
+    cfg = PRESETS["llama-3.2-1b"]
+    kw = dict(hf_config=cfg, max_num_seqs=1, max_model_len=1024, max_num_batched_tokens=1024, kvcache_block_size=256,
+              num_kvcache_blocks=6, weights_std=0.05)
+    import random
+    random.seed(0)
+    prompt = [random.randint(0, 10000) for _ in range(128)]
+    sp = SamplingParams(temperature=0, max_new_tokens=36, ignore_eos=True)
+    ar, _ = LLMEngine("llama-3.2-1b", **kw).generate([prompt], sp, use_tqdm=False)
+    K = 6
+    sd_kw = dict(kw, draft="llama-3.2-1b", draft_hf_config=cfg, speculate=True, speculate_k=K, draft_weights_seed=0,
+                 num_draft_kvcache_blocks=6)
+    sync, m1 = LLMEngine("llama-3.2-1b", **sd_kw).generate([prompt], sp, use_tqdm=False)
+    lens1 = list(m1["accepted_suffix_lens_with_recovery"])
+    asy, m2 = LLMEngine("llama-3.2-1b", draft_async=True, async_fan_out=3, jit_speculate=True, inprocess_draft=True,
+                        **dict(sd_kw, speculate_k=7)).generate([prompt], sp, use_tqdm=False)
+    lens2 = list(m2["accepted_suffix_lens_with_recovery"])
+    a, s, y = ar[0]["token_ids"], sync[0]["token_ids"], asy[0]["token_ids"]
+    print("1B exactness: common prefix sync", common_prefix(a, s), "async", common_prefix(a, y), "of", len(a),
+          "| accepted", lens1, lens2)
+    assert common_prefix(a, s) >= 12 and common_prefix(a, y) >= 12
+    assert sum(lens1[:-1]) / max(1, len(lens1) - 1) >= K and sum(lens2[:-1]) / max(1, len(lens2) - 1) >= K
