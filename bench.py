@@ -148,18 +148,26 @@ def cpu_baseline(k_spec):
     cores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     cfg = PRESETS["llama-3.2-1b"]
-    eng = LLMEngine("llama-3.2-1b", hf_config=cfg, runner_factory=oracle_runner_factory(), max_model_len=256,
-                    max_num_batched_tokens=256, kvcache_block_size=256, num_kvcache_blocks=2)
+    eng = LLMEngine("llama-3.2-1b", hf_config=cfg, runner_factory=oracle_runner_factory(), max_model_len=1024,
+                    max_num_batched_tokens=1024, kvcache_block_size=256, num_kvcache_blocks=4)
     random.seed(0)
     prompt = [random.randint(0, 10000) for _ in range(32)]
-    n = 8
+    # time-bounded sample: decode steps until ~12 s of CPU work have been spent (at least 4, at most 512 tokens), so a
+    # slow or oversubscribed host cannot stall the benchmark
+    eng.add_request(prompt, SamplingParams(temperature=0, ignore_eos=True, max_new_tokens=512))
+    step = eng.create_inference_step(eng.config)
     t0 = time.perf_counter()
-    out, m = eng.generate([prompt], SamplingParams(temperature=0, ignore_eos=True, max_new_tokens=n), use_tqdm=False)
+    eng.step(step)                                  # prefill
+    t1 = time.perf_counter()
+    n = 0
+    while not eng.is_finished() and (n < 4 or time.perf_counter() - t1 < 12.0):
+        eng.step(step)
+        n += 1
     wall = time.perf_counter() - t0
-    dec = m["decode_total_tokens"] / m["decode_total_time"] if m["decode_total_time"] else 0.0
+    dec = n / (time.perf_counter() - t1)
     return {"value": round(dec, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
             "sample": f"oracle engine (CPU restatement of the reference), Llama-3.2-1B shapes (the workload's draft model; "
-                      f"BASELINE configs[0]), greedy AR b=1, 32-token prompt, {n} output tokens, bf16 weights; "
+                      f"BASELINE configs[0]), greedy AR b=1, 32-token prompt, {n} output tokens (time-bounded sample, ~12 s), bf16 weights; "
                       f"end-to-end wall {wall:.1f}s incl. prefill; decode-only rate reported"}
 
 
