@@ -21,10 +21,13 @@ enum { PF_EPI_ROWS = 0, PF_EPI_SILU_FRAG = 1 };
 constexpr int PF_WAVES = 4;
 constexpr int PF_U = 4;      // k-steps of W in flight per wave; every K split is a multiple of this many k-steps
 
-template <int MT, int NT, int UU>
+// direct: 0 = write fp32 partials for the epilogue kernel; 1 / 2 = the K range is not split, finish in place
+// (1: rows bf16 + bias, 2: SiLU(gate) * up -> fragment-major) and skip the workspace round trip.
+template <int MT, int NT, int UU, int DIRECT>
 __global__ void __launch_bounds__(256, 2)
 gemm_pf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, float* __restrict__ ws,
-               int M, int N, int K, int kt_per_split, int mt_valid) {
+               int M, int N, int K, int kt_per_split, int mt_valid, const bf16_t* __restrict__ bias,
+               void* __restrict__ Yv, int ldy) {
   __shared__ u32x4_t xs[2][MT][64];                      // ring of two k-steps, MT fragment tiles each
   constexpr int U = UU;                                   // W k-steps in flight per wave (nk is a multiple of it)
   constexpr int FPW = (MT + PF_WAVES - 1) / PF_WAVES;     // x fragment tiles each wave fetches per k-step
@@ -102,9 +105,55 @@ gemm_pf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, f
     }
   }
 
+  const int mcol = lane & 15, nrow = (lane >> 4) * 4;
+  if constexpr (DIRECT == 1) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = (g0 + nt) * 16 + nrow;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 16 + mcol;
+        f32x4_t s = acc[nt][mt];
+        if (bias) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[r] += bf2f(bias[n + r]);
+        }
+        if (m < M) {
+          const u32x2_t v = {pack_bf2(s[0], s[1]), pack_bf2(s[2], s[3])};
+          *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(Yv) + (size_t)m * ldy + n) = v;
+        }
+      }
+    }
+    return;
+  }
+  if constexpr (DIRECT == 2) {
+    const int KT2 = (N >> 1) >> 5;
+    u32x2_t* out2 = reinterpret_cast<u32x2_t*>(Yv);
+#pragma unroll
+    for (int pr = 0; pr < NT / 2; ++pr) {
+      const int f = ((g0 >> 1) + pr) * 16 + nrow;             // feature index in [0, N/2)
+      const int ng = (g0 + 2 * pr) * 16 + nrow, nu = ng + 16;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 16 + mcol;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float gb = acc[2 * pr][mt][r], ub = acc[2 * pr + 1][mt][r];
+          if (bias) { gb += bf2f(bias[ng + r]); ub += bf2f(bias[nu + r]); }
+          gb = round_bf(gb); ub = round_bf(ub);
+          o[r] = (gb / (1.0f + __expf(-gb))) * ub;
+        }
+        if (m < M) {
+          const u32x2_t v = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+          out2[frag_chunk(m, f >> 3, KT2) * 2 + ((f >> 2) & 1)] = v;
+        }
+      }
+    }
+    return;
+  }
   // fp32 partial tile of this split: ws[z][m][n]
   float* out = ws + (size_t)blockIdx.y * M * N;
-  const int mcol = lane & 15, nrow = (lane >> 4) * 4;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = (g0 + nt) * 16 + nrow;
@@ -161,19 +210,28 @@ gemm_pf_epilogue_kernel(const float* __restrict__ ws, const bf16_t* __restrict__
   }
 }
 
-template <int MT, int NT>
-static int pf_launch(const void* x, const void* w, float* ws, int M, int N, int K, int splits, hipStream_t st) {
+template <int MT, int NT, int DIRECT>
+static int pf_launch_d(const void* x, const void* w, float* ws, int M, int N, int K, int splits, const void* bias, void* y,
+                       int ldy, hipStream_t st) {
   const int KT = K >> 5;
   dim3 grid(N / (16 * NT * PF_WAVES), splits);
   const int nk = KT / splits;
   // the narrow tile (NT = 2) has the registers to keep 8 k-steps of W in flight per wave
   if (NT == 2 && nk % 8 == 0)
-    hipLaunchKernelGGL((gemm_pf_kernel<MT, NT, (NT == 2 ? 8 : PF_U)>), grid, dim3(64 * PF_WAVES), 0, st, (const u32x4_t*)w,
-                       (const u32x4_t*)x, ws, M, N, K, nk, (M + 15) / 16);
+    hipLaunchKernelGGL((gemm_pf_kernel<MT, NT, (NT == 2 ? 8 : PF_U), DIRECT>), grid, dim3(64 * PF_WAVES), 0, st,
+                       (const u32x4_t*)w, (const u32x4_t*)x, ws, M, N, K, nk, (M + 15) / 16, (const bf16_t*)bias, y, ldy);
   else
-    hipLaunchKernelGGL((gemm_pf_kernel<MT, NT, PF_U>), grid, dim3(64 * PF_WAVES), 0, st, (const u32x4_t*)w, (const u32x4_t*)x, ws,
-                       M, N, K, nk, (M + 15) / 16);
+    hipLaunchKernelGGL((gemm_pf_kernel<MT, NT, PF_U, DIRECT>), grid, dim3(64 * PF_WAVES), 0, st, (const u32x4_t*)w,
+                       (const u32x4_t*)x, ws, M, N, K, nk, (M + 15) / 16, (const bf16_t*)bias, y, ldy);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
+template <int MT, int NT>
+static int pf_launch(const void* x, const void* w, float* ws, int M, int N, int K, int splits, int direct, const void* bias,
+                     void* y, int ldy, hipStream_t st) {
+  if (direct == 1) return pf_launch_d<MT, NT, 1>(x, w, ws, M, N, K, splits, bias, y, ldy, st);
+  if (direct == 2) return pf_launch_d<MT, NT, 2>(x, w, ws, M, N, K, splits, bias, y, ldy, st);
+  return pf_launch_d<MT, NT, 0>(x, w, ws, M, N, K, splits, bias, y, ldy, st);
 }
 
 // Default decomposition (measured on MI355X, profiles/micro/prefill_gemm_probe.py): about 160-256 workgroups fill the
@@ -190,7 +248,10 @@ static void pf_pick(int N, int K, int* nt_out, int* splits_out) {
     return s;
   };
   const int s4 = fit(4), s2 = fit(2);
-  if (s4 > 0 && (s4 <= 8 || s2 == 0)) { *nt_out = 4; *splits_out = s4; }
+  // an unsplit K finishes inside the GEMM kernel (no partial tiles, no epilogue launch): take it when the narrow tile
+  // alone fills the chip (8B gate_up: nt2 s1 58.7 us vs nt4 s2 62.1)
+  if (s2 == 1 && s4 > 1) { *nt_out = 2; *splits_out = 1; }
+  else if (s4 > 0 && (s4 <= 8 || s2 == 0)) { *nt_out = 4; *splits_out = s4; }
   else { *nt_out = 2; *splits_out = s2; }
 }
 
@@ -212,14 +273,17 @@ extern "C" int ssd_gemm_pf_cfg(const void* x_frag, const void* w_frag, const voi
   const int KT = K >> 5;
   if (splits <= 0) { int nt_d; pf_pick(N, K, &nt_d, &splits); if (nt_d != nt) splits = 1; }
   if (KT % (splits * PF_U) != 0) return SSD_ERR_ARG;
-  if (!workspace || workspace_bytes < (int64_t)splits * M * N * 4) return SSD_ERR_ARG;
+  const int direct = splits == 1 ? (epilogue == PF_EPI_ROWS ? 1 : 2) : 0;     // unsplit K: finish inside the GEMM kernel
+  if (!direct && (!workspace || workspace_bytes < (int64_t)splits * M * N * 4)) return SSD_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)workspace;
   const int mt = (M + 15) / 16;
   int rc;
-  if (mt <= 4) rc = nt == 4 ? pf_launch<4, 4>(x_frag, w_frag, ws, M, N, K, splits, st) : pf_launch<4, 2>(x_frag, w_frag, ws, M, N, K, splits, st);
-  else rc = nt == 4 ? pf_launch<8, 4>(x_frag, w_frag, ws, M, N, K, splits, st) : pf_launch<8, 2>(x_frag, w_frag, ws, M, N, K, splits, st);
-  if (rc != SSD_OK) return rc;
+#define PF_ARGS x_frag, w_frag, ws, M, N, K, splits, direct, bias, y, ldy, st
+  if (mt <= 4) rc = nt == 4 ? pf_launch<4, 4>(PF_ARGS) : pf_launch<4, 2>(PF_ARGS);
+  else rc = nt == 4 ? pf_launch<8, 4>(PF_ARGS) : pf_launch<8, 2>(PF_ARGS);
+#undef PF_ARGS
+  if (rc != SSD_OK || direct) return rc;
   if (epilogue == PF_EPI_ROWS) {
     const size_t items = (size_t)M * N / 4;
     hipLaunchKernelGGL((gemm_pf_epilogue_kernel<PF_EPI_ROWS>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, ws,

@@ -95,6 +95,7 @@ def test_gemm_configs_and_bias(H):
 
 
 @pytest.mark.parametrize("M,N,K,splits", [(128, 512, 4096, 0), (100, 1024, 512, 0), (17, 256, 1024, 2), (64, 256, 128, 1),
+                                          (128, 512, 1024, 1), (90, 128, 2048, 1),
                                           (33, 2048, 2048, 0), (128, 128, 8192, 16), (65, 384, 256, 0)])
 def test_gemm_prefill_vs_oracle(H, M, N, K, splits):
     """csrc/gemm_pf.hip: x tile shared through LDS, K split across workgroups, fp32 partials summed in order."""
@@ -115,8 +116,8 @@ def test_gemm_prefill_vs_oracle(H, M, N, K, splits):
     assert torch.equal(y2.view(torch.int16), y.view(torch.int16))          # deterministic
 
 
-@pytest.mark.parametrize("M", [40, 128])
-def test_gemm_prefill_silu_epilogue(H, M):
+@pytest.mark.parametrize("M,splits", [(40, 0), (128, 0), (100, 1), (128, 1)])
+def test_gemm_prefill_silu_epilogue(H, M, splits):
     torch.manual_seed(M)
     I, K = 512, 1024
     x = torch.randn(M, K).to(BF)
@@ -126,7 +127,7 @@ def test_gemm_prefill_silu_epilogue(H, M):
     H.rows_to_frag(dev(w), wf, 2 * I, K, mode=1)
     act_f = torch.zeros(H.frag_numel(M, I), dtype=BF, device="cuda")
     ws = torch.zeros(H.gemm_pf_workspace_bytes(M, 2 * I, K) // 4, dtype=torch.float32, device="cuda")
-    H.gemm_pf(to_frag_dev(x), wf, act_f, M, 2 * I, K, 0, ws, epilogue=H.EPI_SILU_FRAG)
+    H.gemm_pf(to_frag_dev(x), wf, act_f, M, 2 * I, K, 0, ws, epilogue=H.EPI_SILU_FRAG, splits=splits)   # splits=1: in-kernel epilogue
     act = LY.frag_to_rows_ref(act_f.cpu(), M, I)
     assert_close_bf16(act, ref, max_ulp=1, max_frac=0.03, rel_floor=2 ** -7, what="prefill gemm+silu")
 
