@@ -66,7 +66,7 @@ static inline void ssd_pick_skinny_cfg(int groups, int KT, bool silu_pairs, int*
   int n = 1, w = 8, t = 1;
   if (silu_pairs) {                       // gate_up: row groups come in (gate, up) pairs -> nt even
     n = (groups >= 1792 && groups % 4 == 0) ? 4 : 2;
-    if (n == 4 && KT <= 128) { w = 16; t = 2; }
+    if (n == 4) t = KT <= 128 ? 1 : 4;
   } else if (groups >= 4096) {            // LM heads
     n = (groups % 2 == 0) ? 2 : 1;
     if (KT >= 128) { w = 16; t = 8; }
@@ -75,7 +75,9 @@ static inline void ssd_pick_skinny_cfg(int groups, int KT, bool silu_pairs, int*
   } else if (groups >= 640 && KT >= 256 && groups % 4 == 0) {    // 70B-class qkv
     n = 4;
   } else if (groups >= 512 && KT >= 512 && groups % 2 == 0) {    // 70B-class down_proj: few row groups, very long K
-    n = 2; w = 16;
+    n = 2; w = 8;
+  } else if (groups >= 512 && KT >= 256 && groups % 2 == 0) {    // 70B-class o_proj
+    n = 2; w = 8;
   }
   while (w > 1 && KT / w < 2) w >>= 1;    // every wave needs a couple of k-tiles
   *nt = n; *waves = w; *tpw = t;

@@ -30,8 +30,6 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nw = blockDim.x >> 6;
   const int KT = K >> 5;
-  const int kt0 = (int)(((long)KT * wave) / nw);
-  const int kt1 = (int)(((long)KT * (wave + 1)) / nw);
   // A workgroup owns `tpw` CONSECUTIVE tiles of NT row groups = one contiguous slab of W (long sequential DRAM runs, no
   // tail of half-empty workgroup rounds), and the first loads of the next tile are issued before the cross-wave
   // combine + epilogue of the current one, so the memory pipe never drains inside a workgroup.
@@ -42,7 +40,13 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
   const size_t xstride = (size_t)KT << 6;
   constexpr int U = (MT + NT <= 3) ? 4 : ((MT + NT <= 6) ? 2 : 1);
   Stage<MT, NT> cur[U], nxt[U];
-  const int kmain = kt0 + ((kt1 - kt0) / U) * U;
+  // K is dealt to the waves in groups of U k-tiles, round-robin: wave w takes groups w, w + nw, ...  The workgroup as a
+  // whole therefore walks each row group's K run linearly (DRAM-friendly: measured 6.4-6.9 TB/s for this pattern against
+  // 4.7-6.1 when every wave streams its own distant K slice, profiles/micro/readpat.hip).  The < U left-over k-tiles go
+  // to the last wave.
+  const int kstep = nw * U;
+  const int kt0 = wave * U;
+  const int kmain = (KT / U) * U;                         // first k-tile of the left-over
   const u32x4_t* wp = Wf + ((size_t)t_begin * NT * KT << 6) + lane;
   auto load = [&](Stage<MT, NT>(&s)[U], int kt) {
 #pragma unroll
@@ -75,16 +79,15 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
 
   int kt = kt0;
   if (kt < kmain) {
-    for (; kt + U < kmain; kt += U) {
-      load(nxt, kt + U);
+    for (; kt + kstep < kmain; kt += kstep) {
+      load(nxt, kt + kstep);
       compute(cur);
 #pragma unroll
       for (int u = 0; u < U; ++u) cur[u] = nxt[u];
     }
     compute(cur);
-    kt += U;
   }
-  for (; kt < kt1; ++kt) {  // K-range remainder (< U tiles)
+  for (kt = (wave == nw - 1) ? kmain : KT; kt < KT; ++kt) {  // K remainder (< U tiles): last wave
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       u32x4_t a = __builtin_nontemporal_load(wp + nt * wstride + ((size_t)kt << 6));

@@ -55,8 +55,6 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
   const int M = p.M, K = p.K;
   const int KT = K >> 5, K8 = K >> 3;
   const int tile0 = blockIdx.x * NT;
-  const int kt0 = (int)(((long)KT * wave) / nw);
-  const int kt1 = (int)(((long)KT * (wave + 1)) / nw);
   const int mcol = lane & 15, q4 = lane >> 4;
   // LDS: [combine / prologue scratch: nw*NT KiB (>= M*K8*4 B)] [x^ image: M*K*2 B, chunk (k8, m) at (k8*M + m)*16 B]
   u32x4_t* xlds = reinterpret_cast<u32x4_t*>(smem + p.scratch_bytes);
@@ -79,7 +77,12 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
       if (!XNORM) xg[buf][u] = p.Xf[((size_t)(kt + u) << 6) + lane];
     }
   };
-  const int nmain = (kt1 - kt0) / U;
+  // K is dealt to the waves in groups of U k-tiles, round-robin (wave w: groups w, w + nw, ...): the workgroup walks each
+  // row group's K run linearly (see gemm.hip / profiles/micro/readpat.hip); the < U left-over k-tiles go to the last wave
+  const int kstep = nw * U;
+  const int kt0 = wave * U;
+  const int ngroups = KT / U;
+  const int nmain = ngroups > wave ? (ngroups - wave + nw - 1) / nw : 0;   // groups of this wave
   if (nmain > 0) loadw(0, kt0);   // the first weight tiles fly while the norm prologue runs
 
   if (XNORM) {
@@ -196,20 +199,20 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
   int kt = kt0;
   auto stage = [&](auto curc, int it) {          // curc: compile-time buffer index (runtime-indexed register
     constexpr int cur = decltype(curc)::value;   // arrays would go to scratch)
-    if (it + 1 < nmain) loadw(cur ^ 1, kt + U);
+    if (it + 1 < nmain) loadw(cur ^ 1, kt + kstep);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const u32x4_t xb = xfrag(cur, u, kt + u);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(wa[cur][u][nt], xb, acc[nt]);
     }
-    kt += U;
+    kt += kstep;
   };
   for (int it = 0; it < nmain; it += 2) {
     stage(std::integral_constant<int, 0>{}, it);
     if (it + 1 < nmain) stage(std::integral_constant<int, 1>{}, it + 1);
   }
-  for (; kt < kt1; ++kt) {
+  for (kt = (wave == nw - 1) ? ngroups * U : KT; kt < KT; ++kt) {
     u32x4_t xb;
     if (!XNORM) xb = p.Xf[((size_t)kt << 6) + lane];
     else { xb = u32x4_t{0u, 0u, 0u, 0u}; if (mcol < M) xb = xlds[(kt * 4 + q4) * M + mcol]; }
