@@ -55,7 +55,15 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
       for (int nt = 0; nt < NT; ++nt)
         s[u].a[nt] = __builtin_nontemporal_load(wp + nt * wstride + ((size_t)(kt + u) << 6));
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) s[u].b[mt] = xp[mt * xstride + ((size_t)(kt + u) << 6)];
+      for (int mt = 0; mt < MT; ++mt) {
+        // token rows >= M of the last 16-row tile are padding: their lanes do not load (x traffic is per 16-byte lane;
+        // at M = 7 this more than halves the L2 -> CU bytes of the B operand, at M = 1 it is 1/16)
+        // (only where x is not amortised over several weight tiles: the predication costs the wider kernels more than
+        // the saved bytes are worth)
+        u32x4_t b = {0u, 0u, 0u, 0u};
+        if (NT > 1 || mt * 16 + (lane & 15) < M) b = xp[mt * xstride + ((size_t)(kt + u) << 6)];
+        s[u].b[mt] = b;
+      }
     }
   };
   if (t_begin < t_end && kt0 < kmain) load(cur, kt0);
@@ -92,7 +100,11 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
     for (int nt = 0; nt < NT; ++nt) {
       u32x4_t a = __builtin_nontemporal_load(wp + nt * wstride + ((size_t)kt << 6));
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mfma16(a, xp[mt * xstride + ((size_t)kt << 6)], acc[nt][mt]);
+      for (int mt = 0; mt < MT; ++mt) {
+        u32x4_t b = {0u, 0u, 0u, 0u};
+        if (mt * 16 + (lane & 15) < M) b = xp[mt * xstride + ((size_t)kt << 6)];
+        acc[nt][mt] = mfma16(a, b, acc[nt][mt]);
+      }
     }
   }
 

@@ -74,7 +74,11 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         wa[buf][u][nt] = __builtin_nontemporal_load(wp + nt * wstride + ((size_t)(kt + u) << 6));
-      if (!XNORM) xg[buf][u] = p.Xf[((size_t)(kt + u) << 6) + lane];
+      if (!XNORM) {     // padding token rows (>= M) are not loaded: halves the B-operand bytes at M = 7
+        u32x4_t b = {0u, 0u, 0u, 0u};
+        if (mcol < M) b = p.Xf[((size_t)(kt + u) << 6) + lane];
+        xg[buf][u] = b;
+      }
     }
   };
   // K is dealt to the waves in groups of U k-tiles, round-robin (wave w: groups w, w + nw, ...): the workgroup walks each
@@ -84,7 +88,6 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
   const int ngroups = KT / U;
   const int nmain = ngroups > wave ? (ngroups - wave + nw - 1) / nw : 0;   // groups of this wave
   if (nmain > 0) loadw(0, kt0);   // the first weight tiles fly while the norm prologue runs
-
   if (XNORM) {
     // ---- prologue: x32 = h + res kept in registers; per-chunk sums of squares -> per-row rs (fixed order) ->
     //      x^ = bf16(x32 * rs * w) into the LDS image; residual slice written to res_out ----
@@ -214,7 +217,7 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
   }
   for (kt = (wave == nw - 1) ? ngroups * U : KT; kt < KT; ++kt) {
     u32x4_t xb;
-    if (!XNORM) xb = p.Xf[((size_t)kt << 6) + lane];
+    if (!XNORM) { xb = u32x4_t{0u, 0u, 0u, 0u}; if (mcol < M) xb = p.Xf[((size_t)kt << 6) + lane]; }
     else { xb = u32x4_t{0u, 0u, 0u, 0u}; if (mcol < M) xb = xlds[(kt * 4 + q4) * M + mcol]; }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
