@@ -130,7 +130,7 @@ def gemm_roofline(engine, steps_k, draft_fwd_per_step=None):
     return {"bound": "hbm", "kernel": "gemm_wf_kernel + gemm_fused_kernel (skinny weight-streaming GEMM family)",
             "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
-            "traffic_source": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_c2_pmc_traffic.csv (read bytes = x1.019 of algorithmic over the GEMM family)",
+            "traffic_source": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_c2_pmc_traffic.csv (read bytes = x1.012 of algorithmic over the GEMM family)",
             "launches_per_step": round(tot_launch, 1), "avg_launch_us": round(tot_time / tot_launch * 1e6, 2),
             "bytes_per_launch_avg": int(tot_bytes / tot_launch), "per_kind": per_kind}
 
