@@ -91,10 +91,12 @@ int main() {
   const size_t bytes = (size_t)4 << 30;
   u32x4* buf; unsigned* out;
   CK(hipMalloc(&buf, bytes)); CK(hipMalloc(&out, 4)); CK(hipMemset(buf, 1, bytes));
-  struct { int N, K; } shapes[] = {{57344, 8192}, {8192, 28672}, {8192, 8192}, {10240, 8192}, {28672, 4096}};
+  struct { int N, K; } shapes[] = {{57344, 8192}, {8192, 28672}, {8192, 8192}, {10240, 8192}, {28672, 4096},
+                                   {2048, 8192}, {16384, 2048}, {3072, 2048}, {2048, 2048}, {1280, 8192}, {7168, 8192}, {8192, 3584}};
   for (auto s : shapes) {
     const size_t mat16 = (size_t)s.N * s.K * 2 / 16;
-    const int copies = (int)(bytes / 16 / mat16);
+    int copies = (int)(bytes / 16 / mat16);
+    if (copies > 64) copies = 64;
     run<4, false>(buf, s.N, s.K, 8, out, copies, mat16);
     run<4, true>(buf, s.N, s.K, 8, out, copies, mat16);
     run<2, false>(buf, s.N, s.K, 16, out, copies, mat16);

@@ -66,7 +66,10 @@ static inline void ssd_pick_skinny_cfg(int groups, int KT, bool silu_pairs, int*
   int n = 1, w = 8, t = 1;
   if (silu_pairs) {                       // gate_up: row groups come in (gate, up) pairs -> nt even
     n = (groups >= 1792 && groups % 4 == 0) ? 4 : 2;
-    if (n == 4) t = KT <= 128 ? 1 : 4;
+    if (n == 4 && KT > 128) {             // consecutive tiles per workgroup, but never fewer than ~224 workgroups
+      t = (groups / 4) / 224;
+      t = t < 1 ? 1 : (t > 4 ? 4 : t);
+    }
   } else if (groups >= 4096) {            // LM heads
     n = (groups % 2 == 0) ? 2 : 1;
     if (KT >= 128) { w = 16; t = 8; }
