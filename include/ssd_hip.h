@@ -71,6 +71,12 @@ int ssd_gemm_wf(const void* x_frag, const void* w_frag, const void* bias, void* 
 int ssd_gemm_wf_cfg(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K, int ldy,
                     int epilogue, int nt, int waves, void* stream);
 
+/* The same F.linear for matrices with too few 16-row groups to fill the chip (csrc/gemm_sk.hip; the 1B draft's o_proj /
+ * down_proj): K is split across `splits` workgroups per row group, the last one to arrive reduces the fp32 partials in a
+ * fixed order.  workspace >= (N/16)*splits KiB; counters >= N/16 uint32, zeroed once.  M <= 16, bf16 rows. */
+int ssd_gemm_splitk(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K, int ldy,
+                    int splits, int waves, void* workspace, void* counters, void* stream);
+
 /* Prefill-chunk GEMM, 16 < M <= 128 (csrc/gemm_pf.hip): the reference's eager prefill F.linear calls
  * (ssd/engine/model_runner.py:602 -> ssd/layers/linear.py:65,98,196).  Same operands and epilogues (SSD_EPI_ROWS,
  * SSD_EPI_SILU_FRAG) as ssd_gemm_wf; the x tile of a k-step is shared by a workgroup through LDS and K is split

@@ -15,6 +15,9 @@
 
 enum { EPI_ROWS = 0, EPI_SILU_FRAG = 1, EPI_ROWS_F32 = 2 };
 
+extern "C" int ssd_gemm_splitk(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K, int ldy,
+                               int splits, int waves, void* workspace, void* counters, void* stream);
+
 template <int MT, int NT>
 struct Stage {
   u32x4_t a[NT];
@@ -248,6 +251,10 @@ extern "C" int ssd_gemm_wf(const void* x_frag, const void* w_frag, const void* b
   if (mt == 1) {       // decode / verify rows: the tuned table
     int nt1, waves1, tpw1;
     ssd_pick_skinny_cfg(groups, KT, epilogue == EPI_SILU_FRAG, &nt1, &waves1, &tpw1);
+    // one row group per workgroup, bf16 rows: the single-buffered kernel of gemm_sk.hip (fewer registers -> more resident
+    // workgroups) measured 5-17 % faster than the register double buffer below (profiles/micro/splitk_probe.py)
+    if (nt1 == 1 && tpw1 == 1 && epilogue == EPI_ROWS)
+      return ssd_gemm_splitk(x_frag, w_frag, bias, y, M, N, K, ldy, 1, waves1, nullptr, nullptr, stream);
     return ssd_gemm_wf_cfg(x_frag, w_frag, bias, y, M, N, K, ldy, epilogue, nt1, waves1 | (tpw1 << 8), stream);
   }
   int nt = 1;

@@ -1,0 +1,105 @@
+// Skinny GEMM with the K range split ACROSS workgroups, for matrices with too few 16-row groups to fill the chip
+// (the 1B draft's o_proj / down_proj: N = 2048 -> 128 row groups on 256 CUs; a pure read of such a matrix by 128
+// workgroups tops out at ~3 TB/s, profiles/micro/readpat.hip).  y[M,N] = x[M,K] . W[N,K]^T (+ bias), M <= 16, bf16 rows.
+//
+// grid = (row groups, S).  Workgroup (g, z) streams the z-th K range of row group g exactly like gemm_wf_kernel
+// (waves deal k-tiles round-robin, fixed-order LDS combine), publishes its fp32 partial tile (1 KiB) with agent-scope
+// stores and bumps the group's arrival counter; the LAST workgroup to arrive sums the S partials in z order -- so the
+// result does not depend on the arrival order -- applies the epilogue and resets the counter (hipGraph-replay safe).
+// No atomics on data, no second launch.
+#include "common.h"
+
+__device__ __forceinline__ void st_agent64(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_agent64(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void __launch_bounds__(1024)
+gemm_sk_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, const bf16_t* __restrict__ bias,
+               bf16_t* __restrict__ Y, int M, int N, int K, int ldy, unsigned long long* __restrict__ ws,
+               unsigned int* __restrict__ counters) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ unsigned int s_prev;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nw = blockDim.x >> 6;
+  const int KT = K >> 5;
+  const int g = blockIdx.x, z = blockIdx.y, S = gridDim.y;
+  const int kz0 = (int)(((long)KT * z) / S), kz1 = (int)(((long)KT * (z + 1)) / S);
+  constexpr int U = 4;
+  const u32x4_t* wp = Wf + ((size_t)g * KT << 6) + lane;
+  const u32x4_t* xp = Xf + lane;
+  const bool xrow = (lane & 15) < M;           // padding token rows are not loaded
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  u32x4_t a[U], b[U];
+  const int ngroups = (kz1 - kz0) / U;
+  for (int grp = wave; grp < ngroups; grp += nw) {
+    const int kt = kz0 + grp * U;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      a[u] = __builtin_nontemporal_load(wp + ((size_t)(kt + u) << 6));
+      b[u] = u32x4_t{0u, 0u, 0u, 0u};
+      if (xrow) b[u] = xp[(size_t)(kt + u) << 6];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc = mfma16(a[u], b[u], acc);
+  }
+  if (wave == nw - 1)
+    for (int kt = kz0 + ngroups * U; kt < kz1; ++kt) {
+      u32x4_t bb = {0u, 0u, 0u, 0u};
+      if (xrow) bb = xp[(size_t)kt << 6];
+      acc = mfma16(__builtin_nontemporal_load(wp + ((size_t)kt << 6)), bb, acc);
+    }
+  // in-workgroup combine, wave order
+  f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);
+  red[wave * 64 + lane] = acc;
+  __syncthreads();
+  if (wave != 0) return;
+  f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+  for (int w = 0; w < nw; ++w) s += red[w * 64 + lane];
+  if (S > 1) {
+    unsigned long long* mine = ws + ((size_t)(g * S + z) * 64 + lane) * 2;
+    st_agent64(mine, (unsigned long long)__float_as_uint(s[0]) | ((unsigned long long)__float_as_uint(s[1]) << 32));
+    st_agent64(mine + 1, (unsigned long long)__float_as_uint(s[2]) | ((unsigned long long)__float_as_uint(s[3]) << 32));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) s_prev = __hip_atomic_fetch_add(counters + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const unsigned int prev = *(volatile unsigned int*)&s_prev;
+    if (prev != (unsigned)(S - 1)) return;                  // not the last one: done
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    s = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int zz = 0; zz < S; ++zz) {                         // fixed order, whoever arrived last
+      const unsigned long long* pp = ws + ((size_t)(g * S + zz) * 64 + lane) * 2;
+      const unsigned long long v0 = ld_agent64(pp), v1 = ld_agent64(pp + 1);
+      s[0] += __uint_as_float((unsigned)v0); s[1] += __uint_as_float((unsigned)(v0 >> 32));
+      s[2] += __uint_as_float((unsigned)v1); s[3] += __uint_as_float((unsigned)(v1 >> 32));
+    }
+    if (lane == 0) __hip_atomic_store(counters + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const int m = lane & 15, n = g * 16 + (lane >> 4) * 4;
+  if (bias) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] += bf2f(bias[n + r]);
+  }
+  if (m < M) {
+    const u32x2_t v = {pack_bf2(s[0], s[1]), pack_bf2(s[2], s[3])};
+    *reinterpret_cast<u32x2_t*>(Y + (size_t)m * ldy + n) = v;
+  }
+}
+
+// workspace: >= (N/16) * splits KiB of device memory; counters: >= N/16 uint32, zero-initialised once (the kernel leaves
+// them at zero).  splits in 1..8; waves in 1..16.
+extern "C" int ssd_gemm_splitk(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K, int ldy,
+                               int splits, int waves, void* workspace, void* counters, void* stream) {
+  if (M <= 0 || M > 16 || (N & 15) || (K & 31) || N <= 0 || K <= 0) return SSD_ERR_SHAPE;
+  if (splits < 1 || splits > 8 || waves < 1 || waves > 16) return SSD_ERR_ARG;
+  if (splits > 1 && (!workspace || !counters)) return SSD_ERR_ARG;
+  if ((K >> 5) / splits < 1) return SSD_ERR_ARG;
+  hipLaunchKernelGGL(gemm_sk_kernel, dim3(N / 16, splits), dim3(64 * waves), (size_t)waves * 64 * sizeof(f32x4_t),
+                     (hipStream_t)stream, (const u32x4_t*)w_frag, (const u32x4_t*)x_frag, (const bf16_t*)bias, (bf16_t*)y, M, N,
+                     K, ldy, (unsigned long long*)workspace, (unsigned int*)counters);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}

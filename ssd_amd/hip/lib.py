@@ -29,6 +29,7 @@ SIGNATURES = {
     "ssd_rmsnorm": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "ssd_gemm_wf": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "ssd_gemm_wf_cfg": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "ssd_gemm_splitk": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "ssd_gemm_pf_workspace_bytes": [c_int, c_int, c_int, c_void_p],
     "ssd_gemm_pf": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int, c_void_p],
     "ssd_gemm_pf_cfg": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int, c_int, c_void_p],

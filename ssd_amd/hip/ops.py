@@ -61,6 +61,12 @@ def gemm(x_frag, w_frag, y, M: int, N: int, K: int, ldy: int, epilogue: int = EP
     _check(rc, "ssd_gemm_wf")
 
 
+def gemm_splitk(x_frag, w_frag, y, M: int, N: int, K: int, ldy: int, splits: int, waves: int, workspace, counters, bias=None):
+    """Skinny GEMM with K split across workgroups (csrc/gemm_sk.hip); workspace: >= (N/16)*splits KiB, counters: zeroed uint32[N/16]."""
+    _check(load_library().ssd_gemm_splitk(_p(x_frag), _p(w_frag), _p(bias), _p(y), M, N, K, ldy, splits, waves, _p(workspace),
+                                          _p(counters), _stream()), "ssd_gemm_splitk")
+
+
 def gemm_pf_workspace_bytes(M: int, N: int, K: int) -> int:
     import ctypes
     out = ctypes.c_int64(0)

@@ -94,6 +94,32 @@ def test_gemm_configs_and_bias(H):
     assert torch.equal(y2.view(torch.int16), outs[-1].view(torch.int16))
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 256, 2048), (7, 128, 8192), (16, 2048, 2048), (3, 80, 96), (1, 2048, 8192)])
+def test_gemm_splitk_vs_oracle(H, M, N, K):
+    """csrc/gemm_sk.hip: K split across workgroups, last arriver reduces in z order; counters must return to zero and
+    the result must not depend on the run (deterministic order)."""
+    torch.manual_seed(M + N + K)
+    x = torch.randn(M, K).to(BF)
+    w = (torch.randn(N, K) * 0.05).to(BF)
+    b = torch.randn(N).to(BF)
+    ref = O.linear(x, w, b)
+    xf, wf = to_frag_dev(x), to_frag_dev(w)
+    counters = torch.zeros(N // 16, dtype=torch.int32, device="cuda")
+    for splits in (1, 2, 3, 4, 8):
+        if (K // 32) < splits:
+            continue
+        ws = torch.zeros((N // 16) * splits * 256, dtype=torch.float32, device="cuda")
+        outs = []
+        for waves in (1, 4, 8, 16):
+            for _ in range(2):
+                y = torch.full((M, N), float("nan"), dtype=BF, device="cuda")
+                H.gemm_splitk(xf, wf, y, M, N, K, N, splits, waves, ws, counters, bias=dev(b))
+                outs.append(y)
+            assert torch.equal(outs[-1].view(torch.int16), outs[-2].view(torch.int16))
+            assert_close_bf16(outs[-1], ref, max_ulp=1, max_frac=0.03, rel_floor=2 ** -7, what=f"split-K gemm S{splits} w{waves}")
+        assert int(counters.abs().sum()) == 0
+
+
 @pytest.mark.parametrize("M,N,K,splits", [(128, 512, 4096, 0), (100, 1024, 512, 0), (17, 256, 1024, 2), (64, 256, 128, 1),
                                           (128, 512, 1024, 1), (90, 128, 2048, 1),
                                           (33, 2048, 2048, 0), (128, 128, 8192, 16), (65, 384, 256, 0)])
