@@ -127,7 +127,7 @@ def gemm_roofline(engine, steps_k, draft_fwd_per_step=None):
             traffic = int(tot_bytes / tot_launch * json.load(f)["gemm_traffic_over_algorithmic"])
     except Exception:
         pass
-    return {"bound": "hbm", "kernel": "gemm_wf_kernel + gemm_fused_kernel (skinny weight-streaming GEMM family)",
+    return {"bound": "hbm", "kernel": "gemm_wf_kernel + gemm_sk_kernel + gemm_fused_kernel (skinny weight-streaming GEMM family)",
             "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
             "traffic_source": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_c2_pmc_traffic.csv (read bytes = x1.012 of algorithmic over the GEMM family)",
