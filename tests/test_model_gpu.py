@@ -412,3 +412,29 @@ def test_full_size_1b_speculation_is_exact(gpu):
           "| accepted", lens1, lens2)
     assert common_prefix(a, s) >= 12 and common_prefix(a, y) >= 12
     assert sum(lens1[:-1]) / max(1, len(lens1) - 1) >= K and sum(lens2[:-1]) / max(1, len(lens2) - 1) >= K
+
+
+def test_long_generation_crosses_context_buckets(gpu):
+    """2,300 generated tokens with KV block size 256: the context passes the 1024 / 2048 attention buckets, so the engine
+    re-captures its hipGraphs with grid key-splits + the merge kernel on the way.  With draft == target the speculative
+    stream must keep reproducing the autoregressive one and keep accepting (near-ties aside)."""
+    from ssd_amd.engine.llm_engine import LLMEngine
+    from ssd_amd.model_config import ModelConfig
+    from ssd_amd.sampling_params import SamplingParams
+    t = ModelConfig("llama", 256, 2, 4, 2, 64, 512, 512, 1e-5, 5e5, 8192, False)
+    kw = dict(hf_config=t, max_num_seqs=1, max_model_len=4096, max_num_batched_tokens=4096, kvcache_block_size=256,
+              num_kvcache_blocks=20, weights_std=0.1)
+    prompt = [(11 * j + 3) % 512 for j in range(300)]
+    n = 2300
+    sp = SamplingParams(temperature=0, max_new_tokens=n, ignore_eos=True)
+    ar, _ = LLMEngine("t", **kw).generate([prompt], sp, use_tqdm=False)
+    K = 4
+    sd, m = LLMEngine("t", draft="d", draft_hf_config=t, speculate=True, speculate_k=K, draft_weights_seed=0,
+                      num_draft_kvcache_blocks=20, **kw).generate([prompt], sp, use_tqdm=False)
+    a, s = ar[0]["token_ids"], sd[0]["token_ids"]
+    lens = m["accepted_suffix_lens_with_recovery"]
+    cp = common_prefix(a, s)
+    print("long generation: common prefix", cp, "of", n, "| mean accepted", sum(lens) / len(lens), "steps", len(lens))
+    assert len(a) == len(s) == n
+    assert sum(lens) / len(lens) > K                     # of K+1: the draft keeps being accepted at every context length
+    assert cp >= 600                                      # identical well past the first bucket boundary
