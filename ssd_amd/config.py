@@ -94,6 +94,10 @@ class Config:
                 if self.fan_out_list_miss is None:
                     self.fan_out_list_miss = list(self.fan_out_list)
                 assert len(self.fan_out_list) == self.speculate_k + 1
+                assert len(self.fan_out_list_miss) == self.speculate_k + 1
+                # csrc/sample.hip fork_topf_kernel keeps the draft's own token + the picks so far in a 17-entry LDS list
+                assert 0 <= min(self.fan_out_list + self.fan_out_list_miss) and max(self.fan_out_list + self.fan_out_list_miss) <= 15, \
+                    "fan-out per position must be in 0..15"
                 assert sum(self.fan_out_list_miss) == sum(self.fan_out_list), "hit and miss fan-out lists must have the same sum"
         if self.sampler_x is not None:
             assert self.speculate and self.draft_async, "sampler_x requires draft_async (reference model_runner.py:262-263)"

@@ -6,13 +6,19 @@
 // locally -- one hop, no serialized ring steps, and a fixed rank order makes the result bitwise identical on every
 // rank and run.
 //
-// Mechanism (per call, `epoch` = per-workgroup call counter kept on the device, so hipGraph replays stay in step):
+// Mechanism (per call, `epoch` = call counter kept on the device, so hipGraph replays stay in step).  EVERY collective
+// of this file -- plain all-reduce, fused all-reduce + norm, all-gather -- launches exactly AR_BLOCKS workgroups and
+// every workgroup takes part in the flag exchange of every call, whether or not the call's partition gives it data:
+// the AR_BLOCKS per-workgroup counters therefore all equal the number of collectives issued so far (one global epoch),
+// however the message sizes and partitions of consecutive calls differ.
 //   1. copy my input slice into my staging slot (epoch & 1) with system-scope stores, system-scope release;
 //   2. write `epoch` into my entry of every peer's flag array (remote stores over xGMI);
 //   3. spin (bounded) until every peer's entry in MY flag array reaches `epoch`, acquire;
 //   4. read all ranks' slots (remote loads), sum in fp32 in rank order, write bf16 to the output.
 // Slots are double-buffered by epoch parity: a rank can only overwrite slot s at call e+2 after passing the flag
-// exchange of call e+1, which every peer enters only after finishing its reads of call e.
+// exchange of call e+1, which a peer's workgroup enters only after that peer's WHOLE kernel of call e has retired
+// (kernels of one stream do not overlap) -- so the argument does not depend on which workgroup owned which words in
+// call e, only on all workgroups agreeing on the epoch, which the fixed launch width guarantees.
 // Buffers are fine-grained device memory shared through hipIpc handles; nothing here allocates per call.
 // A spin that exceeds its budget sets an error word instead of hanging; the caller then falls back to RCCL.
 #include "common.h"
@@ -233,10 +239,7 @@ extern "C" int ssd_allreduce_bf16(const void* in, void* out, long n, int rank, i
     peers.flags[r] = (unsigned int*)(r < world ? flags[r] : nullptr);
   }
   const long n8 = n / 4;
-  int blocks = (int)((n8 + 2047) / 2048);
-  if (blocks < 1) blocks = 1;
-  if (blocks > AR_BLOCKS) blocks = AR_BLOCKS;
-  hipLaunchKernelGGL(allreduce_bf16_kernel, dim3(blocks), dim3(AR_THREADS), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(allreduce_bf16_kernel, dim3(AR_BLOCKS), dim3(AR_THREADS), 0, (hipStream_t)stream,
                      (const unsigned long long*)in, (unsigned long long*)out, n8, slot_elems / 4, peers, rank, world,
                      (unsigned int*)counters, (unsigned int*)err, spin_budget, 0);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
@@ -253,10 +256,7 @@ extern "C" int ssd_allgather_u64(const void* in, void* out, long n8, int rank, i
     peers.slot[r] = (unsigned long long*)(r < world ? slots[r] : nullptr);
     peers.flags[r] = (unsigned int*)(r < world ? flags[r] : nullptr);
   }
-  int blocks = (int)((n8 + 2047) / 2048);
-  if (blocks < 1) blocks = 1;
-  if (blocks > AR_BLOCKS) blocks = AR_BLOCKS;
-  hipLaunchKernelGGL(allreduce_bf16_kernel, dim3(blocks), dim3(AR_THREADS), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(allreduce_bf16_kernel, dim3(AR_BLOCKS), dim3(AR_THREADS), 0, (hipStream_t)stream,
                      (const unsigned long long*)in, (unsigned long long*)out, n8, slot_elems / 4, peers, rank, world,
                      (unsigned int*)counters, (unsigned int*)err, spin_budget, 1);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
@@ -279,8 +279,7 @@ extern "C" int ssd_allreduce_add_rmsnorm_bf16(const void* in, const void* res_in
     peers.slot[r] = (unsigned long long*)(r < world ? slots[r] : nullptr);
     peers.flags[r] = (unsigned int*)(r < world ? flags[r] : nullptr);
   }
-  const int blocks = T < AR_BLOCKS ? T : AR_BLOCKS;
-  hipLaunchKernelGGL(allreduce_add_rmsnorm_kernel, dim3(blocks), dim3(ARN_THREADS), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(allreduce_add_rmsnorm_kernel, dim3(AR_BLOCKS), dim3(ARN_THREADS), 0, (hipStream_t)stream,
                      (const unsigned long long*)in, (const u32x4_t*)res_in, (u32x4_t*)res_out, (const u32x4_t*)weight, eps,
                      (u32x4_t*)out_rows, (u32x4_t*)out_frag, T, H, slot_elems / 4, peers, rank, world,
                      (unsigned int*)counters, (unsigned int*)err, spin_budget);

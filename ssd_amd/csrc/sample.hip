@@ -50,6 +50,7 @@ __device__ ArgBest block_row_argmax(const bf16_t* __restrict__ row, int V, const
   __syncthreads();
   ArgBest r = sm[0];
   for (int w = 1; w < THREADS / 64; ++w) r = better(r, sm[w]);
+  if (r.i == 0x7fffffff) r.i = 0;   // nothing comparable in the row (all NaN / -inf / excluded): never emit the sentinel as a token id
   return r;
 }
 
@@ -149,7 +150,7 @@ fork_topf_kernel(const bf16_t* __restrict__ logits, long ld, int V, const int64_
   __shared__ ArgBest sm[FORK_THREADS / 64];
   __shared__ int excl[FORK_MAXF + 1];
   const int b = blockIdx.x / (K + 1), j = blockIdx.x % (K + 1);
-  const int cnt = counts[b * (K + 1) + j];
+  const int cnt = min(counts[b * (K + 1) + j], FORK_MAXF - 1);   // excl[] holds x_{j+1} + the picks so far (Config validates)
   int nex = 0;
   if (threadIdx.x == 0 && j < K) excl[0] = (int)returned[(size_t)b * (K + 1) + j + 1];
   if (j < K) nex = 1;

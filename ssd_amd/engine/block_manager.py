@@ -146,8 +146,14 @@ class BlockManager:
         """Hash a block that just became full (reference scheduler.py:234-241: the prefix is taken from the
         second-to-last table entry, the hash lands on the last one)."""
         toks = seq.block(block_index)
-        prefix = self.blocks[table[-2]].hash if len(table) > 1 else -1
+        if block_index == len(table) - 1:
+            prefix = self.blocks[table[-2]].hash if len(table) > 1 else -1
+            last = self.blocks[table[-1]]
+        else:
+            # a block whose hashing was postponed (deferred draft KV deposit, scheduler._commit_suffix) is no longer the
+            # last one: chain from ITS predecessor and label IT
+            prefix = self.blocks[table[block_index - 1]].hash if block_index > 0 else -1
+            last = self.blocks[table[block_index]]
         h = self.compute_hash(toks, prefix)
-        last = self.blocks[table[-1]]
         last.update(h, toks)
         self.hash_to_block_id[h] = last.block_id

@@ -105,6 +105,13 @@ class LLMEngine:
             self.draft_runner = factory(config, config.draft_hf_config, is_draft=True, topo=self.topo.single(),
                                         memory_utilization=0.75, num_kvcache_blocks=config.num_draft_kvcache_blocks)
             draft_blocks = self.draft_runner.num_kvcache_blocks
+            if self.topo.tp_size > 1:
+                # the replicated draft sized its KV cache from THIS rank's free memory; every rank runs its own
+                # Scheduler and must take identical admission / preemption decisions -> agree on the minimum
+                import torch.distributed as dist
+                t = torch.tensor([draft_blocks], dtype=torch.int64, device=self.topo.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.topo.tp_group)
+                draft_blocks = int(t.item())
         elif config.speculate:
             from ssd_amd.engine.speculator_async import AsyncLink
             transport = None

@@ -96,6 +96,7 @@ class ModelRunner:
         self.h_next = torch.zeros(max(self.max_decode_tokens, B), dtype=torch.int64).pin_memory()
         self._setup_custom_ar(custom_ar)
         self._stage: dict = {}
+        self._stage_set = 0
         self._ctx_hint = 4096
         self.graphs: dict = {}
         self.graph_pool = None
@@ -165,12 +166,15 @@ class ModelRunner:
 
     def _upload(self, dst: torch.Tensor, values, dtype) -> None:
         """Host list -> persistent pinned staging -> async H2D.  Every step ends in a stream sync before the
-        next one stages, so a staging buffer is never rewritten while its copy is in flight."""
+        next one stages, so a staging buffer is never rewritten while its copy is in flight -- except for work that
+        is queued WITHOUT a sync before the next staging (deposit_pending): such callers switch `_stage_set`, which
+        selects a second set of pinned buffers."""
         n = len(values)
         if n:
-            stage = self._stage.get(id(dst))
+            key = (id(dst), self._stage_set)
+            stage = self._stage.get(key)
             if stage is None:
-                stage = self._stage[id(dst)] = torch.zeros(dst.shape, dtype=dst.dtype).pin_memory()
+                stage = self._stage[key] = torch.zeros(dst.shape, dtype=dst.dtype).pin_memory()
             stage[:n] = torch.tensor(values, dtype=dtype)
             dst[:n].copy_(stage[:n], non_blocking=True)
 
@@ -439,7 +443,11 @@ class ModelRunner:
         draft tokens were all accepted: feed x_K (now the second-to-last token; the new recovery token has been
         appended) at its position so that its KV exists before the next chain reads it.  No LM head, no sampling."""
         B = len(seqs)
-        self._prepare_decode(seqs, back=1)
+        self._stage_set = 1         # no host sync follows: the chain's staging must not reuse these pinned buffers
+        try:
+            self._prepare_decode(seqs, back=1)
+        finally:
+            self._stage_set = 0
         if self._launch(("decode_deposit", B), lambda: self._body_decode(B, False, head=False)) == "captured":
             self.graphs[("decode_deposit", B, self._ctx_hint)].replay()     # idempotent: same token, same slot
 

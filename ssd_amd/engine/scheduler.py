@@ -166,11 +166,15 @@ class Scheduler:
         seq.last_spec_step_accepted_len = n
         seq.recovery_token_id = recovery
         assert seq.block_table and seq.draft_block_table
+        # synchronous speculation defers the draft's KV deposit of x_K (engine/speculator_sync.py): after a fully
+        # accepted round the draft KV row of position num_tokens-1 does not exist yet, so a draft block ending exactly
+        # there must not become a prefix-cache entry now (it is hashed by a later commit, once the row is written)
+        draft_valid = seq.num_tokens - (1 if (not self.draft_async and n == self.K + 1) else 0)
         for idx in range(len(seq.block_table)):
             if (idx + 1) * self.block_size <= seq.num_tokens:
                 if self.block_manager.blocks[seq.block_table[idx]].hash == -1:
                     self.block_manager.finalize_block(seq, seq.block_table, idx)
-                if self.draft_block_manager.blocks[seq.draft_block_table[idx]].hash == -1:
+                if (idx + 1) * self.block_size <= draft_valid and self.draft_block_manager.blocks[seq.draft_block_table[idx]].hash == -1:
                     self.draft_block_manager.finalize_block(seq, seq.draft_block_table, idx)
 
     def postprocess_speculate(self, seqs: list[Sequence], new_suffixes: list[list[int]], next_recovery_tokens: list[int],

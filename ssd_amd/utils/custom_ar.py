@@ -135,6 +135,14 @@ class OneShotAllReduce:
 # --------------------------------------------------------------------------------------------------
 # validation helper: run as its own process group (gloo rendezvous), one helper per rank
 # --------------------------------------------------------------------------------------------------
+def _rank_order_sum(xs) -> torch.Tensor:
+    """fp32 sum in rank order, one rounding to bf16 -- the kernel's arithmetic (torch.sum may use another order)."""
+    acc = xs[0].float()
+    for x in xs[1:]:
+        acc = acc + x.float()
+    return acc.to(torch.bfloat16)
+
+
 def _selftest_main() -> int:
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dev = torch.device("cuda", int(os.environ.get("SSD_AR_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
@@ -146,7 +154,7 @@ def _selftest_main() -> int:
     for n in (4, 4096, 7 * 8192, 24 * 2048, SLOT_ELEMS):
         for it in range(6):
             xs = [torch.randn(n, generator=g).to(torch.bfloat16) for _ in range(world)]      # same on every rank
-            want = torch.stack([x.float() for x in xs]).sum(0).to(torch.bfloat16)
+            want = _rank_order_sum(xs)
             t = xs[rank].to(dev)
             ar.all_reduce(t)
             torch.cuda.synchronize()
@@ -173,8 +181,8 @@ def _selftest_main() -> int:
             body()
         for it in range(20):
             xs = [torch.randn(n, generator=g).to(torch.bfloat16) for _ in range(world)]
-            once = torch.stack([x.float() for x in xs]).sum(0).to(torch.bfloat16)
-            want = (once.float() * world).to(torch.bfloat16)
+            once = _rank_order_sum(xs)
+            want = _rank_order_sum([once] * world)
             src.copy_(xs[rank].to(dev))
             graph.replay()
             torch.cuda.synchronize()
@@ -204,6 +212,46 @@ def _selftest_main() -> int:
             same = all(torch.equal(a.view(torch.int16), b.view(torch.int16)) for a, b in ((got_res, ref_res), (rows, ref_rows), (frag, ref_frag)))
             if ar.failed() or not same:
                 print(f"[custom_ar selftest] rank {rank}: fused all-reduce+norm mismatch at T={T} H={Hd} failed={ar.failed()}", flush=True)
+                ok = False
+                break
+    # mismatched shapes interleaved (plain: words dealt to the workgroups; fused: whole rows; gather: a handful of
+    # words) while one rank is delayed by a long device-side sleep: every workgroup must stay on one global epoch
+    if ok:
+        from ssd_amd.hip import ops as H
+        T, Hd, ng = 7, 4096, 12
+        res0 = torch.randn(T, Hd, generator=g).to(torch.bfloat16)
+        w = (1 + 0.1 * torch.randn(Hd, generator=g)).to(torch.bfloat16).to(dev)
+        for it in range(24):
+            xs = [torch.randn(T, Hd, generator=g).to(torch.bfloat16) for _ in range(world)]
+            ys = [torch.randn(4 * (it + 1), generator=g).to(torch.bfloat16) for _ in range(world)]
+            gs = [torch.randint(0, 1 << 40, (ng,), generator=g) for _ in range(world)]
+            if it % world == rank:
+                torch.cuda._sleep(20_000_000)           # ~10 ms: this rank enters the sequence late
+            y = ys[rank].to(dev)
+            ar.all_reduce(y)
+            x = xs[rank].to(dev)
+            res = res0.to(dev)
+            rows = torch.zeros(T, Hd, dtype=torch.bfloat16, device=dev)
+            ar.all_reduce_add_rmsnorm(x, res, res, w, 1e-5, T, Hd, out_rows=rows)
+            gout = torch.zeros(world, ng, dtype=torch.int64, device=dev)
+            ar.all_gather_words(gs[rank].to(dev), gout, ng)
+            x2 = xs[(rank + 1) % world].to(dev)
+            ar.all_reduce(x2.view(-1))
+            torch.cuda.synchronize()
+            want_y = _rank_order_sum(ys)
+            sum_x = _rank_order_sum(xs)
+            want_x2 = _rank_order_sum([xs[(r + 1) % world] for r in range(world)])
+            ref_res = torch.zeros(T, Hd, dtype=torch.bfloat16, device=dev)
+            ref_rows = torch.zeros(T, Hd, dtype=torch.bfloat16, device=dev)
+            H.rmsnorm(sum_x.to(dev), w, 1e-5, T, Hd, res_in=res0.to(dev), res_out=ref_res, out_rows=ref_rows)
+            torch.cuda.synchronize()
+            good = (torch.equal(y.cpu().view(torch.int16), want_y.view(torch.int16))
+                    and torch.equal(res.view(torch.int16), ref_res.view(torch.int16))
+                    and torch.equal(rows.view(torch.int16), ref_rows.view(torch.int16))
+                    and torch.equal(gout.cpu(), torch.stack(gs))
+                    and torch.equal(x2.cpu().view(torch.int16), want_x2.view(torch.int16)))
+            if ar.failed() or not good:
+                print(f"[custom_ar selftest] rank {rank}: interleaved mismatched-shape sequence broke at it={it} failed={ar.failed()}", flush=True)
                 ok = False
                 break
     flag = torch.tensor([1 if ok else 0])
