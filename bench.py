@@ -2,102 +2,126 @@
 """Headline benchmark: speculative decoding output tokens/s on MI355X, the reference's metric
 (bench/bench.py:351-361: output tokens / wall clock; decode-only variant llm_engine.py:215-223).
 
-Contract: ``python bench.py --gpus N --steps K --warmup W`` (one rank per GPU; under torchrun for N > 1) prints
-ONE JSON line on rank 0.  A *step* is one full speculation round of the real engine -- K_spec+1 chained draft
-forwards, the K_spec+1-query target verify forward, the on-device accept/reject, and the scheduler
-post-processing -- for one sequence (b = 1) of synthetic token ids, exactly the objects ``LLM.generate`` drives.
+Contract: ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line on rank 0.  One rank per GPU: under
+``python -m torch.distributed.run --nproc-per-node N`` the ranks are taken from the environment; started as a plain
+process with ``--gpus N > 1`` the script re-executes itself under torch.distributed.run on 127.0.0.1 (the reference's
+LLM(num_gpus=N) also spawns its own workers, ssd/engine/llm_engine.py:61-93).  A *step* is one full speculation round
+of the real engine for one sequence (b = 1) of synthetic token ids -- exactly the objects ``LLM.generate`` drives.
 
 Workload (``--workload``):
-  c3   (default) Llama-3.1-70B shapes as target, tensor-parallel over the N GPUs (TP = N; 139 GB of bf16
-       weights fit one 288 GB MI355X, so N = 1 is the same model), Llama-3.2-1B shapes as draft replicated on
-       every rank, synchronous SD k = 6, b = 1, temp 0, 128-token prompt (BASELINE.json configs[2] shape;
-       the metric's model).  Same total work at every N -> "strong" scaling.
-  c2   Llama-3.1-8B target + 1B draft, sync SD k = 6 on one GPU (BASELINE.json configs[1]).
+  c4   (default; the configuration BASELINE.json's metric is quoted on) Llama-3.1-70B shapes as target + Llama-3.2-1B
+       shapes as draft, ASYNCHRONOUS speculation ("SSD") k = 7, fan-out f = 3, b = 1, temp 0, 128-token prompt, KV block
+       256, max_model_len 8192, jit backup on a speculation-cache miss (reference README.md:96-97, bench/bench.py:34-51).
+       Placement: ``colocated`` (default) -- the target is tensor-parallel over all N GPUs (139 GB of bf16 weights fit
+       one 288 GB MI355X, so N = 1 is the same model) and the draft server shares TP rank 0's GPU on its own HIP stream,
+       pre-computing the next round's speculation tree while the verify runs; ``dedicated`` (``--placement dedicated``,
+       N - 1 a power of two) -- the draft has the last GPU to itself and talks to TP rank 0 over RCCL p2p (the
+       reference's 4 + 1 GPU layout is ``--gpus 5 --placement dedicated``).  Same total work at every N -> "strong".
+  c3   the same pair, SYNCHRONOUS speculation k = 6 (BASELINE.json configs[2]); draft replicated on every rank.
+  c2   Llama-3.1-8B target + 1B draft, sync k = 6 on one GPU (configs[1]).
+  c5t  Qwen3-32B target + Qwen3-0.6B draft, async k = 7 f = 3 (configs[4] without the draft data-parallelism).
   tiny 2-layer toy shapes (plumbing check).
-Weights are synthetic (seeded N(0, 0.02)); no checkpoints exist offline.  With unrelated random draft and target
-the acceptance is ~0, so ``value`` (tokens/s at the MEASURED acceptance) is essentially 1 / step latency; the
-line also carries ms_per_step, mean_accepted_len and the step's HBM roofline fraction, which are
-acceptance-independent because every shape is fixed.
+Weights are synthetic (no checkpoints exist offline).  ``--pair correlated`` (default) builds the two models with the
+"correlated pair" recipe of ssd_amd/weights.py: real shapes, every matrix streamed in full, values constructed so that
+draft and target agree on most greedy tokens -- acceptance, speculation-cache hits and the all-accepted path are
+exercised at rates comparable to a trained pair.  ``--pair random`` uses independent N(0, 0.02) weights (acceptance
+~0: value = 1 / step latency).  ms_per_step, bytes per step and the roofline fractions are shape-determined and do not
+depend on the pair.
 
-Extra objects on the line: ``roofline`` (dominant kernel = the skinny weight-streaming GEMM family
-gemm_wf_kernel, timed with HIP events on the launch stream while rotating through all layers' weights so
-nothing is cache-resident) and ``cpu_baseline`` (the oracle engine -- the reference's own modules restated --
-timed on the host cores on a bounded sample; baseline only).
+Extra objects on the line: ``roofline`` (dominant kernel family = the skinny weight-streaming GEMMs, timed with HIP
+events on the launch stream while rotating through all layers' weights so nothing is cache-resident; per-rank shard
+shapes at N > 1), ``collective`` (N > 1: which all-reduce carries the tensor-parallel sums and its measured latency)
+and ``cpu_baseline`` (the oracle engine -- the reference's own modules restated -- timed on the host cores on a
+bounded sample; baseline only).
 """
 from __future__ import annotations
 
 import argparse
+import dataclasses
 import json
 import os
 import random
+import socket
 import statistics
+import subprocess
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12   # B/s, MI355X spec (guide: 6.29e12 measured copy ceiling)
+ASYNC_WORKLOADS = ("c4", "c5t")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "tiny"])
-    ap.add_argument("--k", type=int, default=6)
+    ap.add_argument("--workload", default="c4", choices=["c4", "c3", "c2", "c5t", "tiny", "tiny-async"])
+    ap.add_argument("--k", type=int, default=None, help="speculation length (default: 7 async, 6 sync)")
+    ap.add_argument("--f", type=int, default=3, help="async fan-out")
+    ap.add_argument("--placement", default="colocated", choices=["colocated", "dedicated"])
+    ap.add_argument("--pair", default="correlated", choices=["correlated", "random"])
+    ap.add_argument("--pair-snr", type=float, default=8.0)
     ap.add_argument("--input-len", type=int, default=128)
+    ap.add_argument("--max-model-len", type=int, default=8192)
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--ttft-samples", type=int, default=3)
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def self_launch(args) -> int:
+    """``python bench.py --gpus N`` outside a distributed launch: become the launcher (one rank per GPU)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def workload_models(name):
     from ssd_amd.model_config import PRESETS, ModelConfig
-    if name == "c3":
+    if name in ("c3", "c4"):
         return "llama-3.1-70b", PRESETS["llama-3.1-70b"], "llama-3.2-1b", PRESETS["llama-3.2-1b"]
     if name == "c2":
         return "llama-3.1-8b", PRESETS["llama-3.1-8b"], "llama-3.2-1b", PRESETS["llama-3.2-1b"]
+    if name == "c5t":
+        return "qwen3-32b", PRESETS["qwen3-32b"], "qwen3-0.6b", PRESETS["qwen3-0.6b"]
     t = ModelConfig("llama", 512, 2, 8, 8, 64, 1024, 4096, 1e-5, 5e5, 8192, False)
     d = ModelConfig("llama", 256, 1, 8, 8, 32 * 2, 512, 4096, 1e-5, 5e5, 8192, False)
     return "tiny-target", t, "tiny-draft", d
 
 
-@torch.inference_mode()
-def gemm_roofline(engine, steps_k, draft_fwd_per_step=None):
+def gemm_roofline(legs):
     """Time every skinny-GEMM launch shape of one speculation step with HIP events on the launch stream.
-    For each (matrix kind, M) all L layers' matrices are launched back to back (L x tens of MB >> the 256 MiB
-    Infinity Cache), so each launch streams its weights from HBM as in the real forward."""
-    from ssd_amd.hip import ops as H
+    legs: (runner, M rows, forwards of that shape per step).  For each (matrix kind, M) all L layers' matrices are
+    launched back to back (L x tens of MB >> the 256 MiB Infinity Cache), so each launch streams its weights from HBM
+    as in the real forward; the L launches are captured in a hipGraph and the replay is timed (the real forward is a
+    graph replay too; eager launches through ctypes are host-bound for the small shapes)."""
+    import torch
     tot_bytes = tot_time = 0.0
     tot_launch = 0
     per_kind = {}
-    if draft_fwd_per_step is None:
-        draft_fwd_per_step = steps_k
-    for runner, M, fwd_per_step in ((engine.model_runner, steps_k + 1, 1), (engine.draft_runner, 1, draft_fwd_per_step)):
-        if runner is None:
+    for runner, M, fwd_per_step in legs:
+        if runner is None or fwd_per_step <= 0:
             continue
         m = runner.model
         L = m.cfg.num_layers
-        # the GEMM kernels are exactly the ones the forward issues for M tokens (HipDecoder.launch_*, fused norm /
-        # RoPE / SiLU variants included); separate add+RMSNorm / RoPE launches of the unfused variants are left out
         kinds = [("qkv", m.qkv_n * m.h * 2, lambda li: m.launch_qkv(li, M, runner.d_pos, runner.d_slots, gemm_only=True)),
                  ("o", m.h * m.qn * 2, lambda li: m.launch_o(li, M)),
                  ("gate_up", 2 * m.I * m.h * 2, lambda li: m.launch_gate_up(li, M, gemm_only=True)),
                  ("down", m.h * m.I * 2, lambda li: m.launch_down(li, M))]
-        runner.d_slots[:M].fill_(-1)          # timing only: do not touch the KV cache
+        runner.d_slots[:max(M, 1)].fill_(-1)          # timing only: do not touch the KV cache
         for kind, b, launch in kinds:
             for li in range(min(2, L)):
                 launch(li)
             reps = max(2, 128 // L)
-            # the L launches are captured in a hipGraph and the replay is timed: the real forward is a graph
-            # replay too, and eager launches through ctypes are host-bound (~8 us each) for the small shapes
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
@@ -112,33 +136,74 @@ def gemm_roofline(engine, steps_k, draft_fwd_per_step=None):
             e1.record()
             torch.cuda.synchronize()
             dt = e0.elapsed_time(e1) * 1e-3 / (reps * L)
-            tag = ("draft." if runner.is_draft else "target.") + kind
-            per_kind[tag] = {"us": round(dt * 1e6, 2), "GBps": round(b / dt / 1e9, 1), "MB": round(b / 1e6, 1)}
+            tag = ("draft." if runner.is_draft else "target.") + f"{kind}.M{M}"
+            per_kind[tag] = {"us": round(dt * 1e6, 2), "GBps": round(b / dt / 1e9, 1), "MB": round(b / 1e6, 1),
+                             "launches_per_step": round(L * fwd_per_step, 1)}
             tot_bytes += b * L * fwd_per_step
             tot_time += dt * L * fwd_per_step
             tot_launch += L * fwd_per_step
     achieved = tot_bytes / tot_time
+    out = {"bound": "hbm", "kernel": "skinny weight-streaming GEMM family (gemm_wf_kernel, gemm_sk_kernel, gemm_fused_kernel)",
+           "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4),
+           "traffic": None, "launches_per_step": round(tot_launch, 1), "avg_launch_us": round(tot_time / tot_launch * 1e6, 2),
+           "bytes_per_launch_avg": int(tot_bytes / tot_launch), "per_kind": per_kind}
     # HBM traffic per launch: PMC counters cannot be collected from inside this process; the committed separate
-    # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (profiles/r01_c2_pmc_traffic.csv, FETCH_SIZE doubled
-    # as the gfx950 guide prescribes) measured read+write bytes = ratio x algorithmic bytes for this kernel family
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic_r01.json")) as f:
-            traffic = int(tot_bytes / tot_launch * json.load(f)["gemm_traffic_over_algorithmic"])
-    except Exception:
-        pass
-    return {"bound": "hbm", "kernel": "gemm_wf_kernel + gemm_sk_kernel + gemm_fused_kernel (skinny weight-streaming GEMM family)",
-            "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
-            "traffic_source": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_c2_pmc_traffic.csv (read bytes = x1.012 of algorithmic over the GEMM family)",
-            "launches_per_step": round(tot_launch, 1), "avg_launch_us": round(tot_time / tot_launch * 1e6, 2),
-            "bytes_per_launch_avg": int(tot_bytes / tot_launch), "per_kind": per_kind}
+    # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (profiles/collect.sh; FETCH_SIZE doubled as the gfx950
+    # guide prescribes) give read+write bytes = ratio x algorithmic bytes for this kernel family
+    for fn in ("traffic_r02.json", "traffic_r01.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", fn)) as f:
+                t = json.load(f)
+            out["traffic"] = int(tot_bytes / tot_launch * t["gemm_traffic_over_algorithmic"])
+            out["traffic_source"] = t.get("source", fn)
+            if "mfma_util" in t:
+                out["mfma_util"] = t["mfma_util"]
+            break
+        except Exception:
+            continue
+    return out
 
 
-def cpu_baseline(k_spec):
+def collective_probe(engine, M):
+    """N > 1: which implementation carries the [M, hidden] bf16 tensor-parallel sums and what one costs (64 of them in
+    one hipGraph, every rank in lock step)."""
+    import torch
+    import torch.distributed as dist
+    m = engine.model_runner.model
+    if not m.use_coll:
+        return None
+    t = torch.zeros(M, m.h, dtype=torch.bfloat16, device=m.device)
+    n = 64
+
+    def body():
+        for _ in range(n):
+            m._allreduce(t)
+    body()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        body()
+    g.replay()
+    torch.cuda.synchronize()
+    dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (5 * n)
+    one_shot = m.custom_ar is not None
+    return {"all_reduce": "one-shot full-mesh over hipIpc (csrc/comm.hip)" if one_shot else "RCCL (torch.distributed nccl)",
+            "one_shot_validated": one_shot, "fused_add_rmsnorm": bool(one_shot and m.fuse_ar_norm),
+            "message_bytes": M * m.h * 2, "avg_us": round(us, 2), "backend": dist.get_backend(m.tp_group)}
+
+
+def cpu_baseline():
     """The oracle engine (reference modules restated on CPU) on a bounded sample of the workload:
-    (a) Llama-3.2-1B shapes, greedy AR decode, b=1 (BASELINE.json configs[0]) -> tokens/s measured end to end;
-    the 70B target does not fit host RAM, so no extrapolation is made -- this is a baseline, not a target."""
+    Llama-3.2-1B shapes (the workload's draft model; BASELINE.json configs[0]), greedy AR decode, b=1 -> tokens/s
+    measured end to end; the 70B target does not fit host RAM, so no extrapolation is made -- a baseline, not a target."""
+    import torch
     from oracle.runner import oracle_runner_factory
     from ssd_amd.engine.llm_engine import LLMEngine
     from ssd_amd.model_config import PRESETS
@@ -152,15 +217,15 @@ def cpu_baseline(k_spec):
                     max_num_batched_tokens=1024, kvcache_block_size=256, num_kvcache_blocks=4)
     random.seed(0)
     prompt = [random.randint(0, 10000) for _ in range(32)]
-    # time-bounded sample: decode steps until ~12 s of CPU work have been spent (at least 4, at most 512 tokens), so a
-    # slow or oversubscribed host cannot stall the benchmark
+    # time-bounded sample: decode steps until ~12 s of CPU work have been spent (at least 4, at most 512 tokens)
     eng.add_request(prompt, SamplingParams(temperature=0, ignore_eos=True, max_new_tokens=512))
     step = eng.create_inference_step(eng.config)
     t0 = time.perf_counter()
     eng.step(step)                                  # prefill
     t1 = time.perf_counter()
     n = 0
-    while not eng.is_finished() and (n < 4 or time.perf_counter() - t1 < 12.0):
+    budget = float(os.environ.get("SSD_BENCH_CPU_SECONDS", "12"))
+    while not eng.is_finished() and (n < 4 or time.perf_counter() - t1 < budget):
         eng.step(step)
         n += 1
     wall = time.perf_counter() - t0
@@ -173,28 +238,50 @@ def cpu_baseline(k_spec):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     from ssd_amd.engine.llm_engine import LLMEngine, METRICS
     from ssd_amd.sampling_params import SamplingParams
 
-    tname, tcfg, dname, dcfg = workload_models(args.workload)
-    K = args.k
-    max_len = 2048
-    blocks = (max_len // 256) + 2
-    engine = LLMEngine(tname, hf_config=tcfg, draft=dname, draft_hf_config=dcfg, speculate=True, speculate_k=K,
-                       num_gpus=args.gpus, max_num_seqs=1, max_model_len=max_len, max_num_batched_tokens=max_len,
-                       kvcache_block_size=256, num_kvcache_blocks=blocks, num_draft_kvcache_blocks=blocks,
-                       enforce_eager=args.eager)
+    tname, tcfg, dname, dcfg = workload_models(args.workload.split("-")[0] if args.workload.startswith("tiny") else args.workload)
+    is_async = args.workload in ASYNC_WORKLOADS or args.workload == "tiny-async"
+    K = args.k if args.k is not None else (7 if is_async else 6)
+    max_len = args.max_model_len
+    lookahead = (K + 1 + K * (K + 1) * args.f) if is_async else K + 1
+    blocks = -(-(max_len + lookahead) // 256) + 2
+    recipe = None
+    if args.pair == "correlated":
+        # a tied draft would predict "repeat the token" (E.E^T is diagonal-dominant): the pair recipe unties the head; the
+        # LM-head GEMM streams a [V, h] matrix either way, so bytes and kernels are unchanged
+        dcfg = dataclasses.replace(dcfg, tie_word_embeddings=False)
+        recipe = {"kind": "pair", "shared": min(dcfg.hidden_size, tcfg.hidden_size), "snr": args.pair_snr, "layer_gain": 0.005}
+    dedicated = is_async and args.placement == "dedicated" and world > 1
+    tp = world - 1 if dedicated else world
+    kw = dict(hf_config=tcfg, draft=dname, draft_hf_config=dcfg, speculate=True, speculate_k=K, num_gpus=args.gpus,
+              max_num_seqs=1, max_model_len=max_len, max_num_batched_tokens=max_len, kvcache_block_size=256,
+              num_kvcache_blocks=blocks, num_draft_kvcache_blocks=blocks, enforce_eager=args.eager, weights_recipe=recipe)
+    if is_async:
+        kw.update(draft_async=True, async_fan_out=args.f, jit_speculate=True, inprocess_draft=not dedicated)
+    engine = LLMEngine(tname, **kw)
+    if engine.is_draft_process:             # dedicated draft GPU: serve until the target says EXIT, then join the barrier
+        engine.serve()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     dev = engine.topo.device
     random.seed(0)
     prompt = [random.randint(0, 10000) for _ in range(args.input_len)]
+    tp_group = engine.topo.tp_group
 
     def sync_all():
         torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
+        if tp > 1:
+            dist.barrier(group=tp_group)
             torch.cuda.synchronize(dev)
 
     # ---- TTFT (chat.py:95-111 definition: generate() call -> first streamed token), p50 over a few runs ----
@@ -218,58 +305,80 @@ def main():
     for _ in range(args.warmup):
         engine.step(step)
     n0 = len(METRICS["accepted_suffix_lens_with_recovery"])
+    h0 = len(METRICS["cache_hits"])
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         engine.step(step)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
-    if world > 1:
+    if tp > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=tp_group)
         dt = float(t.item())
-        dist.barrier()
+        dist.barrier(group=tp_group)
     lens = METRICS["accepted_suffix_lens_with_recovery"][n0:]
+    hits = METRICS["cache_hits"][h0:]
     tokens = sum(lens)
     ms_step = dt / args.steps * 1e3
     seq = engine.scheduler.running[0] if engine.scheduler.running else None
     ctx = len(seq) if seq is not None else args.input_len
 
-    tb, db = engine.model_runner.model.weight_bytes(), engine.draft_runner.model.weight_bytes()
+    tm = engine.model_runner.model
+    dr = engine.draft_runner                # None on ranks that do not host the draft
+    tb = tm.weight_bytes()
     kv_tok = lambda m: 2 * m.cfg.num_layers * m.nkv * m.hd * 2
-    # draft forwards actually run per step: K chained ones + the deferred KV-deposit forward, which only follows a
-    # fully accepted round (engine/speculator_sync.py); the reference always runs K+1 (7 x 2.471 GB)
-    draft_fwd = K + sum(1 for n in lens if n == K + 1) / max(1, len(lens))
-    step_bytes = tb + draft_fwd * db + ctx * (kv_tok(engine.model_runner.model) + draft_fwd * kv_tok(engine.draft_runner.model))
-    full_accept_step_s = (dt / args.steps) * (1 + (K + 1 - draft_fwd) * db / step_bytes)
+    hit_rate = sum(hits) / len(hits) if hits else None
+    if is_async:
+        # per round the draft GPU runs: glue (K+1 rows) + K tree steps (MQ_LEN rows) -- off the critical path when the
+        # request hits the speculation cache -- plus, on a miss, the K-forward JIT chain on the critical path
+        miss = 1.0 - (hit_rate or 0.0)
+        draft_fwd = 1 + K + miss * K
+        legs = [(engine.model_runner, K + 1, 1), (dr, K + 1, 1), (dr, engine.config.MQ_LEN, K), (dr, 1, miss * K)]
+    else:
+        # K chained forwards + the deferred KV-deposit forward, which only follows a fully accepted round
+        draft_fwd = K + sum(1 for n in lens if n == K + 1) / max(1, len(lens))
+        legs = [(engine.model_runner, K + 1, 1), (dr, 1, draft_fwd)]
+    db = dr.model.weight_bytes() if dr is not None else 0
+    dkv = kv_tok(dr.model) if dr is not None else 0
+    colocated_bytes = 0 if (dedicated or dr is None) else draft_fwd * (db + ctx * dkv)
+    step_bytes = tb + ctx * kv_tok(tm) + colocated_bytes      # HBM bytes THIS GPU (TP rank 0) streams per step
+    mode = (f"async SSD k={K} f={args.f} ({'dedicated draft GPU, RCCL p2p' if dedicated else 'draft co-located on TP rank 0'}, jit backup)"
+            if is_async else f"sync speculative decoding k={K} (draft replicated)")
     out = {
-        "metric": "output tokens/sec (sync SD, b=1, temp 0), with p50 TTFT and mean accepted length",
+        "metric": ("output tokens/sec + p50 TTFT, Llama-3-70B SSD k=7 f=3; mean accepted len" if args.workload == "c4" and K == 7 and args.f == 3
+                   else "output tokens/sec (speculative decoding, b=1, temp 0), with p50 TTFT and mean accepted length"),
         "value": round(tokens / dt, 3), "unit": "tokens/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic token ids (random.seed(0), randint(0,10000)) + synthetic seeded weights",
-        "config": {"workload": f"{tname} target TP={args.gpus} + {dname} draft (replicated), sync speculative decoding "
-                               f"k={K}, b=1, temp=0, input_len={args.input_len}, kv block 256",
-                   "steps_are": "one speculate (k chained draft fwd; the reference's (k+1)-th, KV-deposit-only fwd runs only "
-                                "after a fully accepted round) + verify ((k+1)-query target fwd) + accept round of the engine",
-                   "parallelism": f"tp{args.gpus}", "hipgraph": not args.eager},
+        "dtype": "bf16",
+        "data": "synthetic token ids (random.seed(0), randint(0,10000)) + synthetic seeded weights "
+                + (f"(correlated-pair recipe, snr {args.pair_snr}: real shapes, values built so draft and target mostly agree)"
+                   if recipe else "(independent N(0,0.02): acceptance ~0)"),
+        "config": {"workload": f"{args.workload}: {tname} target TP={tp} + {dname} draft, {mode}, b=1, temp=0, "
+                               f"input_len={args.input_len}, kv block 256, max_model_len {max_len}",
+                   "parallelism": f"tp{tp}" + ("+draft1" if dedicated else ""), "hipgraph": not args.eager, "pair": args.pair},
         "mean_accepted_len": round(tokens / max(1, len(lens)), 4),
+        "cache_hit_rate": None if hit_rate is None else round(hit_rate, 4),
         "ttft_p50_ms": round(ttft_p50, 3),
         "draft_forwards_per_step": round(draft_fwd, 3),
         "step_hbm_bytes_per_gpu": int(step_bytes),
         "step_roofline_frac": round(step_bytes / (dt / args.steps) / HBM_PEAK, 4),
-        "tokens_per_s_if_all_accepted": round((K + 1) / full_accept_step_s, 2),
+        "tokens_per_s_at_accepted_len": {str(a): round(a / (dt / args.steps), 1) for a in (1, 2, 4, K + 1)},
     }
-    if rank == 0 and args.gpus == 1:
-        if not args.no_roofline:
-            out["roofline"] = gemm_roofline(engine, K, draft_fwd)
+    if not args.no_roofline:          # every rank launches the same sequence (shard shapes); rank 0 reports
+        roof = gemm_roofline(legs)
+        if tp > 1:
+            out["collective"] = collective_probe(engine, K + 1)
+        out["roofline"] = roof
+    if rank == 0:
         if not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(K)
+                out["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}
-    if rank == 0:
         print(json.dumps(out), flush=True)
+    engine.exit()                           # dedicated placement: tells the draft rank to leave its serve loop
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

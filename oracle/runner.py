@@ -27,11 +27,19 @@ class OracleRunner:
         tp_group = topo.tp_group if topo is not None else None
         if weights is None:
             seed = config.draft_weights_seed if is_draft else config.weights_seed
-            weights = W.synthetic_state_dict(model_cfg, seed, config.weights_std)
+            weights = W.synthetic_state_dict(model_cfg, seed, config.weights_std, recipe=getattr(config, "weights_recipe", None))
         self.num_kvcache_blocks = num_kvcache_blocks if num_kvcache_blocks > 0 else 64
         self.model = OracleModel(model_cfg, shard_weights(model_cfg, weights, tp_rank, tp_size), self.num_kvcache_blocks,
                                  self.block_size, tp_rank, tp_size, tp_group)
         self.tp_rank, self.tp_size, self.tp_group = tp_rank, tp_size, tp_group
+        # (seq_id, absolute position of the decided token) -> top-2 logit margin of that greedy decision; tests use it
+        # to tell a legitimate near-tie flip from a real divergence of the HIP engine
+        self.margin_log: dict[tuple[int, int], float] = {}
+
+    def _log_margins(self, lg, keys):
+        top = lg.float().topk(2, dim=-1).values
+        for (sid, pos), m in zip(keys, (top[:, 0] - top[:, 1]).tolist()):
+            self.margin_log[(sid, pos)] = m
 
     # ---- helpers ----
     def _table(self, s):
@@ -84,6 +92,7 @@ class OracleRunner:
                       block_tables=self._bt(seqs) if paged else None)
             h = self.model.forward(torch.tensor(ids), torch.tensor(pos), ctx)
             lg = self._logits(h[(cu_q_t[1:] - 1).long()])
+            self._log_margins(lg, [(s.seq_id, len(s)) for s in seqs])
             toks = self._pick(lg, seqs)
             return (toks, lg) if draft_return_logits else toks
         if not last_only:
@@ -96,6 +105,7 @@ class OracleRunner:
             slots.append(self._slot(self._table(s), len(s) - 1))
             ctx_lens.append(len(s))
         lg = self._decode(ids, pos, slots, ctx_lens, self._bt(seqs))
+        self._log_margins(lg, [(s.seq_id, len(s)) for s in seqs])
         toks = self._pick(lg, seqs)
         return (toks, lg) if draft_return_logits else toks
 
@@ -152,6 +162,8 @@ class OracleRunner:
     def verify_chain(self, seqs, speculations, logits_q=None, temps_q=None, ratio_rows=None):
         B, K = len(seqs), self.K
         lg = self._verify_logits(seqs, speculations).view(B, K + 1, -1)
+        # row j decides the token at position pos0 + j + 1 (rows past the first rejection are re-decided, and re-logged, later)
+        self._log_margins(lg.reshape(B * (K + 1), -1), [(s.seq_id, s.num_tokens - (K + 1) + j + 1) for s in seqs for j in range(K + 1)])
         if temps_q is None:
             return O.verify_suffixes(lg, speculations)
         # verify() with explicit ratio rows == jit_speculate=True on the rows flagged, greedy fallback elsewhere

@@ -67,6 +67,7 @@ class Config:
     weights_std: float = 0.02
     draft_weights_seed: int = 1
     num_draft_kvcache_blocks: int = -1      # -1: size from free memory like the reference (draft_runner.py:27)
+    weights_recipe: dict | None = None      # e.g. {"kind": "pair", "shared": 2048, "snr": 8}: see weights._pair_tensor
 
     @property
     def max_blocks(self) -> int:

@@ -94,22 +94,25 @@ class DistTransport:
 
     def __init__(self, group, peer: int, device: torch.device):
         self.group, self.peer, self.device = group, peer, device
+        # gloo moves host memory only: when two ranks share one GPU in tests (SSD_DIST_BACKEND=gloo) the messages are
+        # staged through the CPU; on the deployment path (nccl = RCCL) device tensors go over xGMI directly
+        self.wire = torch.device("cpu") if dist.get_backend(group) == "gloo" else device
 
     def send_ints(self, values: list[int]) -> None:
-        dist.send(torch.tensor(values, dtype=torch.int64).to(self.device), dst=self.peer, group=self.group)
+        dist.send(torch.tensor(values, dtype=torch.int64).to(self.wire), dst=self.peer, group=self.group)
 
     def recv_ints(self, n: int) -> list[int]:
-        t = torch.empty(n, dtype=torch.int64, device=self.device)
+        t = torch.empty(n, dtype=torch.int64, device=self.wire)
         dist.recv(t, src=self.peer, group=self.group)
         return t.tolist()
 
     def send_tensor(self, t: torch.Tensor) -> None:
-        dist.send(t.contiguous(), dst=self.peer, group=self.group)
+        dist.send(t.contiguous().to(self.wire), dst=self.peer, group=self.group)
 
     def recv_tensor(self, shape, dtype) -> torch.Tensor:
-        t = torch.empty(shape, dtype=dtype, device=self.device)
+        t = torch.empty(shape, dtype=dtype, device=self.wire)
         dist.recv(t, src=self.peer, group=self.group)
-        return t
+        return t.to(self.device)
 
 
 class LoopbackTransport:

@@ -82,8 +82,11 @@ class LLMEngine:
 
         from ssd_amd.utils.topology import resolve_topology, Topology
         if topology is None and inprocess_draft:
-            dev = torch.device("cuda", 0) if torch.cuda.is_available() else torch.device("cpu")
-            topology = Topology(0, 1, dev, "target", 0, 1)
+            if int(os.environ.get("WORLD_SIZE", "1")) > 1:      # tensor-parallel target, draft co-located on TP rank 0
+                topology = resolve_topology(config, colocated_draft=True)
+            else:
+                dev = torch.device("cuda", 0) if torch.cuda.is_available() else torch.device("cpu")
+                topology = Topology(0, 1, dev, "target", 0, 1)
         self.topo = topology or resolve_topology(config)
         factory = runner_factory or hip_runner_factory
 
@@ -115,11 +118,11 @@ class LLMEngine:
         elif config.speculate:
             from ssd_amd.engine.speculator_async import AsyncLink
             transport = None
-            if inprocess_draft:
+            if inprocess_draft and self.topo.tp_rank == 0:
                 from ssd_amd.engine.draft_runner import DraftServer
                 from ssd_amd.engine.async_proto import LoopbackTransport
                 transport, server_end = LoopbackTransport.pair()
-                self.draft_runner = factory(config, config.draft_hf_config, is_draft=True, topo=self.topo,
+                self.draft_runner = factory(config, config.draft_hf_config, is_draft=True, topo=self.topo.single(),
                                             memory_utilization=0.75, num_kvcache_blocks=config.num_draft_kvcache_blocks)
                 # co-located draft: its own stream, next-round work parked until the target's verify is in flight
                 on_gpu = self.topo.device.type == "cuda"

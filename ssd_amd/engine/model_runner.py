@@ -60,7 +60,7 @@ class ModelRunner:
         else:
             gd = gen_device or ("cuda" if model_cfg.hidden_size >= 1024 else "cpu")
             src = W.synthetic_weights(model_cfg, weights_seed, config.weights_std, tp_rank, tp_size, gen_device=gd,
-                                      out_device=str(device))
+                                      out_device=str(device), recipe=getattr(config, "weights_recipe", None))
         self.model.load_weights(src)
 
         # ---- KV cache: free * utilisation // block_bytes (reference model_runner.py:446-492) ----
@@ -99,6 +99,7 @@ class ModelRunner:
         self._stage_set = 0
         self._ctx_hint = 4096
         self.graphs: dict = {}
+        self.margin_log = None      # tests: set to {} to record (seq_id, position) -> top-2 margin of every greedy decision (TP = 1)
         self.graph_pool = None
         self.stream = torch.cuda.Stream(device)
 
@@ -361,6 +362,7 @@ class ModelRunner:
             T, max_q = self._prepare_prefill(seqs)
             self.model.forward(self.d_ids, self.d_pos, T, self._meta("prefill", B, max_q))
             self.model.compute_logits(T, gather=self.d_gather, rows=B)
+            self._log_margins(B, [(s.seq_id, len(s)) for s in seqs])
             self._sample_or_argmax(seqs, B)
             toks = self._read_tokens(B)
             return (toks, self.model.full_logits(B)) if draft_return_logits else toks
@@ -381,8 +383,17 @@ class ModelRunner:
         elif self._launch(("decode", B), lambda: self._body_decode(B, False)) == "captured":
             self._prepare_decode(seqs)
             self.graphs[("decode", B, self._ctx_hint)].replay()
+        self._log_margins(B, [(s.seq_id, len(s)) for s in seqs])
         toks = self._read_tokens(B)
         return (toks, self.model.full_logits(B)) if draft_return_logits else toks
+
+    def _log_margins(self, rows: int, keys) -> None:
+        """Debug aid of the parity tests (off unless margin_log is a dict): top-2 margin of logits[:rows]."""
+        if self.margin_log is None or self.model.use_coll:
+            return
+        top = self.model.logits[:rows].float().topk(2, dim=-1).values
+        for k, m in zip(keys, (top[:, 0] - top[:, 1]).tolist()):
+            self.margin_log[k] = m
 
     def _seq_temps(self, seqs) -> list[float]:
         """prepare_sample (model_runner.py:542-550): the draft uses draft_temperature when given."""
@@ -486,6 +497,7 @@ class ModelRunner:
         if self._launch(key, lambda: self._body_verify(B, True, logits_q=logits_q)) == "captured":
             stage()
             self.graphs[(*key, self._ctx_hint)].replay()
+        self._log_margins(B * (K + 1), [(s.seq_id, s.num_tokens - (K + 1) + j + 1) for s in seqs for j in range(K + 1)])
         self.h_packed[:B].copy_(self.d_packed[:B], non_blocking=True)
         # the verify is in flight and the host is about to block on it: the moment for a co-located draft server to
         # enqueue its next round on its own stream (engine/draft_runner.py run_deferred)

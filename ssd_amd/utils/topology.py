@@ -56,7 +56,9 @@ def _local_device(rank: int) -> int:
     return int(os.environ.get("LOCAL_RANK", str(rank)))
 
 
-def resolve_topology(config) -> Topology:
+def resolve_topology(config, colocated_draft: bool = False) -> Topology:
+    """colocated_draft: asynchronous speculation WITHOUT a dedicated draft GPU -- all ranks are tensor-parallel target
+    ranks and TP rank 0 additionally hosts the draft server on a side stream (LLMEngine(inprocess_draft=True))."""
     rank, world = init_process_group_if_needed()
     local = _local_device(rank)
     device = torch.device("cuda", local) if torch.cuda.is_available() else torch.device("cpu")
@@ -65,7 +67,7 @@ def resolve_topology(config) -> Topology:
                                       f"`python -m torch.distributed.run --nproc-per-node {config.num_gpus} ...`")
         return Topology(0, 1, device, "target", 0, 1)
     assert world == config.num_gpus, f"WORLD_SIZE={world} but num_gpus={config.num_gpus}"
-    if config.speculate and config.draft_async:
+    if config.speculate and config.draft_async and not colocated_draft:
         tp = world - 1
         tp_group = dist.new_group(list(range(tp)))
         async_group = dist.new_group([0, tp])

@@ -51,9 +51,50 @@ def _name_seed(seed: int, name: str) -> int:
     return int.from_bytes(hashlib.blake2b(f"{seed}:{name}".encode(), digest_size=7).digest(), "little")
 
 
-def synthetic_tensor(name: str, shape, seed: int, std: float, gen_device: str, norm_jitter: float = 0.0) -> torch.Tensor:
+def _pair_tensor(name: str, shape, seed: int, std: float, gen_device: str, recipe: dict) -> torch.Tensor | None:
+    """The "correlated pair" recipe: a target and a draft of DIFFERENT shapes that agree on most greedy tokens by
+    construction, so that speculation runs at a realistic acceptance rate without trained checkpoints.
+      * both models embed a token with the same base vectors E_b[V, ds] (ds = recipe["shared"], the draft's hidden
+        size) and read it out with the same base head H_b[V, ds]; a wider model fills its remaining hidden dims with
+        independent noise, down-weighted through the gain on the shared dims: logits_target = snr * signal + noise,
+        logits_draft = signal (recipe["snr"]; Monte Carlo at V = 128256: snr 4 -> 45 % top-1 agreement, 8 -> ~65 %);
+      * o_proj / down_proj are scaled by recipe["layer_gain"], so the decoder layers perturb the residual stream
+        (context-dependent, independent between the two models) instead of drowning the embedding.
+    Every matrix keeps its real shape and is streamed in full; only the VALUES differ from the plain N(0, std) recipe."""
+    ds, snr, lg = int(recipe["shared"]), float(recipe.get("snr", 8.0)), float(recipe.get("layer_gain", 0.005))
+    pseed = int(recipe.get("seed", 1234))
+
+    def randn(tag, shp):
+        g = torch.Generator(device=gen_device)
+        g.manual_seed(_name_seed(pseed, tag))
+        return torch.randn(shp, generator=g, device=gen_device, dtype=torch.float32)
+
+    if name in ("model.embed_tokens.weight", "lm_head.weight"):
+        V, h = shape
+        assert h >= ds
+        is_embed = name.startswith("model.embed")
+        base = randn("pair.embed" if is_embed else "pair.head", (V, ds))
+        if h == ds:
+            return (base * (1.0 if is_embed else std)).to(BF16)
+        gain = snr * ((h - ds) / ds) ** 0.5 if is_embed else 1.0       # logit SNR = gain * sqrt(ds / (h - ds))
+        rest = randn(f"pair.rest.{seed}.{name}", (V, h - ds))
+        out = torch.cat([base * gain, rest], dim=1)
+        return (out * (1.0 if is_embed else std)).to(BF16)
+    if name.endswith("o_proj.weight") or name.endswith("down_proj.weight"):
+        g = torch.Generator(device=gen_device)
+        g.manual_seed(_name_seed(seed, name))
+        return (std * lg * torch.randn(shape, generator=g, device=gen_device, dtype=torch.float32)).to(BF16)
+    return None
+
+
+def synthetic_tensor(name: str, shape, seed: int, std: float, gen_device: str, norm_jitter: float = 0.0,
+                     recipe: dict | None = None) -> torch.Tensor:
     """Full (unsharded) synthetic parameter.  gen_device="cpu" gives values reproducible on any machine (tests,
     oracle comparisons); "cuda" is for the multi-GB benchmark models."""
+    if recipe is not None and recipe.get("kind") == "pair":
+        t = _pair_tensor(name, shape, seed, std, gen_device, recipe)
+        if t is not None:
+            return t
     g = torch.Generator(device=gen_device)
     g.manual_seed(_name_seed(seed, name))
     if "norm" in name:
@@ -81,15 +122,16 @@ def shard_param(cfg: ModelConfig, name: str, w: torch.Tensor, rank: int, tp: int
 
 
 def synthetic_weights(cfg: ModelConfig, seed: int, std: float, rank: int = 0, tp: int = 1, gen_device: str = "cpu",
-                      out_device: str | None = None, norm_jitter: float = 0.0) -> Iterator[tuple[str, torch.Tensor]]:
+                      out_device: str | None = None, norm_jitter: float = 0.0,
+                      recipe: dict | None = None) -> Iterator[tuple[str, torch.Tensor]]:
     """Yields (name, this rank's shard) one tensor at a time (bounded transient memory for 70B)."""
     for name, shape in param_shapes(cfg):
-        w = shard_param(cfg, name, synthetic_tensor(name, shape, seed, std, gen_device, norm_jitter), rank, tp)
+        w = shard_param(cfg, name, synthetic_tensor(name, shape, seed, std, gen_device, norm_jitter, recipe), rank, tp)
         yield name, (w.to(out_device) if out_device is not None else w)
 
 
-def synthetic_state_dict(cfg: ModelConfig, seed: int, std: float, norm_jitter: float = 0.0) -> dict:
-    return dict(synthetic_weights(cfg, seed, std, gen_device="cpu", norm_jitter=norm_jitter))
+def synthetic_state_dict(cfg: ModelConfig, seed: int, std: float, norm_jitter: float = 0.0, recipe: dict | None = None) -> dict:
+    return dict(synthetic_weights(cfg, seed, std, gen_device="cpu", norm_jitter=norm_jitter, recipe=recipe))
 
 
 # --------------------------------------------------------------------------------------------------

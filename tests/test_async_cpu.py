@@ -133,3 +133,66 @@ def test_async_two_processes_gloo():
     assert got[0][0] == ar                 # target rank produced the exact stream
     assert got[1][0] == []                 # draft rank only served
     assert all(h == 1.0 for h in got[0][1][1:])
+
+
+def _worker_colocated(rank, port, q):
+    """TP = 2 target with the draft server co-located on TP rank 0 (bench.py's default placement at N > 1)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from oracle.runner import oracle_runner_factory
+    from ssd_amd.engine.llm_engine import LLMEngine
+    from ssd_amd.sampling_params import SamplingParams
+    t, d = cfgs()
+    eng = LLMEngine("t", hf_config=t, runner_factory=oracle_runner_factory(), inprocess_draft=True, num_gpus=2, draft="d",
+                    draft_hf_config=t, draft_weights_seed=0, speculate=True, speculate_k=3, draft_async=True, async_fan_out=2,
+                    jit_speculate=True, **KW)
+    assert eng.topo.tp_size == 2 and (eng.draft_server is not None) == (rank == 0)
+    out, m = eng.generate(PROMPTS[:1], SamplingParams(temperature=0, max_new_tokens=14, ignore_eos=True), use_tqdm=False)
+    q.put((rank, [o["token_ids"] for o in out], m["cache_hits"]))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_async_colocated_draft_under_tensor_parallelism_gloo():
+    ar, _, _ = run("ar")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + (os.getpid() % 90)
+    ps = [ctx.Process(target=_worker_colocated, args=(r, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r, toks, hits = q.get(timeout=300)
+        got[r] = (toks, hits)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][0] == ar and got[1][0] == ar          # SPMD: both TP ranks produce the exact stream
+    assert got[0][1] == got[1][1] and all(h == 1.0 for h in got[0][1][1:])   # hits are broadcast to the non-head rank
+
+
+def test_correlated_pair_recipe_gives_partial_acceptance():
+    """weights._pair_tensor: a target and a NARROWER draft that agree on most greedy tokens by construction -- what
+    bench.py uses so that acceptance, cache hits and the all-accepted path run at realistic rates without checkpoints.
+    Speculation stays exact whatever the acceptance."""
+    from oracle.runner import oracle_runner_factory
+    from ssd_amd.engine.llm_engine import LLMEngine
+    from ssd_amd.model_config import ModelConfig
+    from ssd_amd.sampling_params import SamplingParams
+    t = ModelConfig("llama", 128, 2, 4, 2, 32, 256, 2048, 1e-5, 5e5, 1024, False)
+    d = ModelConfig("llama", 64, 1, 2, 1, 32, 128, 2048, 1e-5, 5e5, 1024, False)
+    kw = dict(KW, hf_config=t, weights_recipe={"kind": "pair", "shared": 64, "snr": 8.0, "layer_gain": 0.05})
+    sp = SamplingParams(temperature=0, max_new_tokens=48, ignore_eos=True)
+    prompt = [[3, 1, 4, 1, 5, 9, 2, 6]]
+    ar, _ = LLMEngine("t", runner_factory=oracle_runner_factory(), **kw).generate(prompt, sp, use_tqdm=False)
+    sd, m = LLMEngine("t", runner_factory=oracle_runner_factory(), draft="d", draft_hf_config=d, speculate=True, speculate_k=4,
+                      **kw).generate(prompt, sp, use_tqdm=False)
+    asy, m2 = LLMEngine("t", runner_factory=oracle_runner_factory(), draft="d", draft_hf_config=d, speculate=True, speculate_k=4,
+                        draft_async=True, async_fan_out=2, jit_speculate=True, inprocess_draft=True, **kw).generate(prompt, sp, use_tqdm=False)
+    assert ar[0]["token_ids"] == sd[0]["token_ids"] == asy[0]["token_ids"]
+    lens = m["accepted_suffix_lens_with_recovery"]
+    assert 1.5 < sum(lens) / len(lens) < 5.0, lens                  # neither ~1.0 (random pair) nor always K+1 (draft == target)
+    assert 0.0 < sum(m2["cache_hits"]) / len(m2["cache_hits"]) <= 1.0

@@ -163,13 +163,7 @@ COMMON = dict(max_model_len=512, max_num_batched_tokens=512, kvcache_block_size=
               num_draft_kvcache_blocks=64)
 
 
-def common_prefix(a, b):
-    n = 0
-    for x, y in zip(a, b):
-        if x != y:
-            break
-        n += 1
-    return n
+from tests.util import common_prefix, assert_stream_matches, seq_margins  # noqa: E402
 
 
 @pytest.mark.parametrize("eager", [False, True])
@@ -186,7 +180,6 @@ def test_engine_autoregressive(gpu, golden, eager):
     margins = g["ar_margins"].tolist()
     assert n == len(want) or margins[n] < 0.0625, f"diverged at token {n} with margin {margins[n]}"
     print("AR identical tokens:", n, "of", len(want))
-    assert n >= 8
 
 
 @pytest.mark.parametrize("tag", ["same", "diff"])
@@ -277,7 +270,6 @@ def test_engine_async_ssd_loopback(gpu, golden, tag):
     margins = g["ar_margins"].tolist()
     print(f"SSD[{tag}] identical tokens: {n} of {len(want)}; hits {metrics['cache_hits']}; lens {metrics['accepted_suffix_lens_with_recovery']}")
     assert n == len(want) or margins[n] < 0.0625, f"diverged at token {n} (margin {margins[n]})"
-    assert n >= 8
     if tag == "same":
         assert metrics["cache_hits"][0] == 0.0 and metrics["cache_hits"][1] == 1.0
         assert metrics["accepted_suffix_lens_with_recovery"][0] == K + 1
@@ -299,11 +291,12 @@ def test_engine_batch_prefix_cache_and_preemption_gpu(gpu):
               max_num_batched_tokens=256, kvcache_block_size=16, num_kvcache_blocks=16, num_draft_kvcache_blocks=16, weights_std=0.1)
     sp = SamplingParams(temperature=0, max_new_tokens=14, ignore_eos=True)
     gpu_out, gm = LLMEngine("t", **kw).generate(prompts, sp, use_tqdm=False)
-    cpu_out, cm = LLMEngine("t", runner_factory=oracle_runner_factory(), **kw).generate(prompts, sp, use_tqdm=False)
-    for a, b in zip(gpu_out, cpu_out):
-        n = common_prefix(a["token_ids"], b["token_ids"])
+    cpu_eng = LLMEngine("t", runner_factory=oracle_runner_factory(), **kw)
+    cpu_out, cm = cpu_eng.generate(prompts, sp, use_tqdm=False)
+    for i, (a, b) in enumerate(zip(gpu_out, cpu_out)):
+        n = assert_stream_matches(a["token_ids"], b["token_ids"], seq_margins(cpu_eng.model_runner.margin_log, i), len(prompts[i]),
+                                  what=f"batch/prefix/preempt seq {i}")
         print("prefix-cache/batch/preempt: identical tokens", n, "of", len(b["token_ids"]))
-        assert n >= 6
     assert len(gpu_out) == 4 and all(len(o["token_ids"]) == 14 for o in gpu_out)
 
 
@@ -327,12 +320,13 @@ def test_prefill_gemm_kernel_in_engine(gpu, monkeypatch):
     real = ops.gemm_pf
     monkeypatch.setattr(ops, "gemm_pf", lambda *a, **k: (calls.append(a[3]), real(*a, **k))[1])
     gpu_out, _ = LLMEngine("t", **kw).generate(prompts, sp, use_tqdm=False)
-    cpu_out, _ = LLMEngine("t", runner_factory=oracle_runner_factory(), **kw).generate(prompts, sp, use_tqdm=False)
+    cpu_eng = LLMEngine("t", runner_factory=oracle_runner_factory(), **kw)
+    cpu_out, _ = cpu_eng.generate(prompts, sp, use_tqdm=False)
     assert calls and max(calls) == 128, calls[:8]
-    for a, b in zip(gpu_out, cpu_out):
-        n = common_prefix(a["token_ids"], b["token_ids"])
+    for i, (a, b) in enumerate(zip(gpu_out, cpu_out)):
+        n = assert_stream_matches(a["token_ids"], b["token_ids"], seq_margins(cpu_eng.model_runner.margin_log, i), len(prompts[i]),
+                                  what=f"prefill-gemm seq {i}")
         print("prefill-gemm engine: identical tokens", n, "of", len(b["token_ids"]))
-        assert n >= 6
 
 
 def test_llm_from_model_directory_safetensors(gpu, tmp_path):
@@ -398,7 +392,10 @@ def test_full_size_1b_speculation_is_exact(gpu):
     random.seed(0)
     prompt = [random.randint(0, 10000) for _ in range(128)]
     sp = SamplingParams(temperature=0, max_new_tokens=36, ignore_eos=True)
-    ar, _ = LLMEngine("llama-3.2-1b", **kw).generate([prompt], sp, use_tqdm=False)
+    ar_eng = LLMEngine("llama-3.2-1b", **kw)
+    ar_eng.model_runner.margin_log = {}
+    ar, _ = ar_eng.generate([prompt], sp, use_tqdm=False)
+    ar_margins = seq_margins(ar_eng.model_runner.margin_log, 0)
     K = 6
     sd_kw = dict(kw, draft="llama-3.2-1b", draft_hf_config=cfg, speculate=True, speculate_k=K, draft_weights_seed=0,
                  num_draft_kvcache_blocks=6)
@@ -410,7 +407,9 @@ def test_full_size_1b_speculation_is_exact(gpu):
     a, s, y = ar[0]["token_ids"], sync[0]["token_ids"], asy[0]["token_ids"]
     print("1B exactness: common prefix sync", common_prefix(a, s), "async", common_prefix(a, y), "of", len(a),
           "| accepted", lens1, lens2)
-    assert common_prefix(a, s) >= 12 and common_prefix(a, y) >= 12
+    # every difference from the autoregressive stream must sit on a near-tie of the autoregressive run itself
+    assert_stream_matches(s, a, ar_margins, len(prompt), what="1B sync SD vs AR")
+    assert_stream_matches(y, a, ar_margins, len(prompt), what="1B async SSD vs AR")
     assert sum(lens1[:-1]) / max(1, len(lens1) - 1) >= K and sum(lens2[:-1]) / max(1, len(lens2) - 1) >= K
 
 
@@ -427,7 +426,9 @@ def test_long_generation_crosses_context_buckets(gpu):
     prompt = [(11 * j + 3) % 512 for j in range(300)]
     n = 2300
     sp = SamplingParams(temperature=0, max_new_tokens=n, ignore_eos=True)
-    ar, _ = LLMEngine("t", **kw).generate([prompt], sp, use_tqdm=False)
+    ar_eng = LLMEngine("t", **kw)
+    ar_eng.model_runner.margin_log = {}
+    ar, _ = ar_eng.generate([prompt], sp, use_tqdm=False)
     K = 4
     sd, m = LLMEngine("t", draft="d", draft_hf_config=t, speculate=True, speculate_k=K, draft_weights_seed=0,
                       num_draft_kvcache_blocks=20, **kw).generate([prompt], sp, use_tqdm=False)
@@ -437,4 +438,5 @@ def test_long_generation_crosses_context_buckets(gpu):
     print("long generation: common prefix", cp, "of", n, "| mean accepted", sum(lens) / len(lens), "steps", len(lens))
     assert len(a) == len(s) == n
     assert sum(lens) / len(lens) > K                     # of K+1: the draft keeps being accepted at every context length
-    assert cp >= 600                                      # identical well past the first bucket boundary
+    # identical to the end, or the first difference sits on a near-tie of the autoregressive run
+    assert_stream_matches(s, a, seq_margins(ar_eng.model_runner.margin_log, 0), len(prompt), what="long generation SD vs AR")

@@ -43,9 +43,10 @@ def test_tp2_equals_tp1_on_one_gpu():
     two = run(2)
     assert two[0]["custom_ar"] and two[1]["custom_ar"], "one-shot all-reduce was not enabled"
     assert two[0]["tokens"] == two[1]["tokens"], "TP ranks disagree (SPMD lock-step broken)"
-    for a, b in zip(one["tokens"], two[0]["tokens"]):
-        n = 0
-        while n < len(a) and a[n] == b[n]:
-            n += 1
+    from tests.util import assert_stream_matches
+    for i, (a, b) in enumerate(zip(one["tokens"], two[0]["tokens"])):
+        # TP = 2 sums two bf16 partials per row-parallel GEMM where TP = 1 has one fp32 accumulation: identical to the end,
+        # or the first difference sits on a near-tie of the TP = 1 run
+        margins = {int(k): v for k, v in one["margins"][i].items()}
+        n = assert_stream_matches(b, a, margins, one["prompt_lens"][i], what=f"TP=2 vs TP=1 seq {i}")
         print("TP=2 vs TP=1 identical tokens:", n, "of", len(a))
-        assert n >= 8, (a, b)

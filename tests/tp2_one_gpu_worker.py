@@ -20,9 +20,16 @@ def main():
                     max_model_len=256, max_num_batched_tokens=256, kvcache_block_size=16, num_kvcache_blocks=40,
                     num_draft_kvcache_blocks=40, weights_std=0.1, enforce_eager=True)
     prompts = [[(5 * i + 3 * j) % 512 for j in range(9 + 2 * i)] for i in range(2)]
+    if tp == 1:
+        eng.model_runner.margin_log = {}
     out, m = eng.generate(prompts, SamplingParams(temperature=0, max_new_tokens=16, ignore_eos=True), use_tqdm=False)
     ar = eng.model_runner.model.custom_ar is not None
-    print("RESULT " + json.dumps({"tokens": [o["token_ids"] for o in out], "custom_ar": ar,
+    margins = []
+    if tp == 1:
+        from tests.util import seq_margins
+        margins = [{str(k): v for k, v in seq_margins(eng.model_runner.margin_log, i).items()} for i in range(len(prompts))]
+    print("RESULT " + json.dumps({"tokens": [o["token_ids"] for o in out], "custom_ar": ar, "margins": margins,
+                                  "prompt_lens": [len(p) for p in prompts],
                                   "lens": m["accepted_suffix_lens_with_recovery"]}), flush=True)
     if tp > 1:
         import torch.distributed as dist

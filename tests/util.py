@@ -33,3 +33,84 @@ def assert_close_bf16(a, b, max_ulp=1, max_frac=0.02, abs_floor=0.0, rel_floor=0
     mx, frac = int(d.max()), float((d > 0).float().mean())
     assert mx <= max_ulp, f"{what}: max ulp diff {mx} (> {max_ulp}); max abs diff {(af - bf).abs().max().item():.4g}"
     assert frac <= max_frac, f"{what}: {frac:.4f} of elements differ (> {max_frac})"
+
+
+def common_prefix(a, b) -> int:
+    n = 0
+    for x, y in zip(a, b):
+        if x != y:
+            break
+        n += 1
+    return n
+
+
+def seq_margins(margin_log: dict, index: int) -> dict:
+    """{position: margin} of the index-th sequence (by seq_id order, the order generate() returns outputs in) out of a
+    runner's margin_log {(seq_id, position): top-2 margin}."""
+    sids = sorted({sid for sid, _ in margin_log})
+    return {pos: m for (sid, pos), m in margin_log.items() if sid == sids[index]}
+
+
+NEAR_TIE = 0.0625
+
+
+def assert_stream_matches(got, want, margins: dict, prompt_len: int, what: str = "", thr: float = NEAR_TIE) -> int:
+    """Greedy streams must be IDENTICAL to the end, unless the reference's own top-2 margin at the first differing
+    decision is below `thr` (a near-tie that a different fp32 accumulation order may legitimately flip; after such a flip
+    the two runs see different inputs and are no longer comparable).  Returns the common prefix length."""
+    assert len(got) == len(want), f"{what}: lengths differ ({len(got)} vs {len(want)})"
+    n = common_prefix(got, want)
+    if n < len(want):
+        m = margins.get(prompt_len + n)
+        assert m is not None, f"{what}: diverged at token {n} and the reference recorded no margin there"
+        assert m < thr, f"{what}: diverged at token {n} although the reference margin there is {m:.4f} (>= {thr})"
+    return n
+
+
+def truth_forward(cfg, w: dict, tokens: list[int]) -> torch.Tensor:
+    """Exact-arithmetic (float64) Llama / Qwen3 forward over one full sequence with causal attention: logits at every
+    position.  The bf16 weights are upcast; NOTHING is rounded in between -- the "truth" both the reference's bf16
+    pipeline and the HIP pipeline approximate.  Mathematically equal to prefill + cached decode / verify."""
+    D = torch.float64
+    T = len(tokens)
+    h = w["model.embed_tokens.weight"].to(D)[torch.tensor(tokens)]
+    hd, nh, nkv = cfg.head_dim, cfg.num_heads, cfg.num_kv_heads
+    inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, hd, 2, dtype=D) / hd))
+    fr = torch.arange(T, dtype=D)[:, None] * inv[None, :]
+    cos, sin = fr.cos()[:, None, :], fr.sin()[:, None, :]
+
+    def norm(x, wt, eps):
+        return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps) * wt.to(D)
+
+    def rot(x):
+        x1, x2 = x.chunk(2, -1)
+        return torch.cat((x1 * cos - x2 * sin, x2 * cos + x1 * sin), -1)
+
+    mask = torch.full((T, T), float("-inf"), dtype=D).triu(1)
+    res = None
+    for li in range(cfg.num_layers):
+        p = f"model.layers.{li}."
+        res = h if res is None else h + res
+        x = norm(res, w[p + "input_layernorm.weight"], cfg.rms_norm_eps)
+        qkv = x @ w[p + "self_attn.qkv_proj.weight"].to(D).t()
+        if p + "self_attn.qkv_proj.bias" in w:
+            qkv = qkv + w[p + "self_attn.qkv_proj.bias"].to(D)
+        q, k, v = qkv.split([nh * hd, nkv * hd, nkv * hd], -1)
+        q, k, v = q.view(T, nh, hd), k.view(T, nkv, hd), v.view(T, nkv, hd)
+        if cfg.qk_norm:
+            q = norm(q, w[p + "self_attn.q_norm.weight"], cfg.rms_norm_eps)
+            k = norm(k, w[p + "self_attn.k_norm.weight"], cfg.rms_norm_eps)
+        q, k = rot(q), rot(k)
+        g = nh // nkv
+        k, v = k.repeat_interleave(g, 1), v.repeat_interleave(g, 1)
+        s = torch.einsum("qhd,khd->hqk", q, k) * hd ** -0.5 + mask
+        o = torch.einsum("hqk,khd->qhd", s.softmax(-1), v).reshape(T, nh * hd)
+        h = o @ w[p + "self_attn.o_proj.weight"].to(D).t()
+        res = h + res
+        x = norm(res, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
+        gu = x @ w[p + "mlp.gate_up_proj.weight"].to(D).t()
+        a, b = gu.chunk(2, -1)
+        h = (a * torch.sigmoid(a) * b) @ w[p + "mlp.down_proj.weight"].to(D).t()
+    x = norm(h + res, w["model.norm.weight"], cfg.rms_norm_eps)
+    head = w["model.embed_tokens.weight"] if cfg.tie_word_embeddings else w["lm_head.weight"]
+    return x @ head.to(D).t()
