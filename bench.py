@@ -105,6 +105,7 @@ def gemm_roofline(legs):
     as in the real forward; the L launches are captured in a hipGraph and the replay is timed (the real forward is a
     graph replay too; eager launches through ctypes are host-bound for the small shapes)."""
     import torch
+    torch.inference_mode(True).__enter__()       # the engine's buffers are inference tensors (ModelRunner runs under inference_mode)
     tot_bytes = tot_time = 0.0
     tot_launch = 0
     per_kind = {}
@@ -172,6 +173,7 @@ def collective_probe(engine, M):
     m = engine.model_runner.model
     if not m.use_coll:
         return None
+    torch.inference_mode(True).__enter__()
     t = torch.zeros(M, m.h, dtype=torch.bfloat16, device=m.device)
     n = 64
 

@@ -92,7 +92,11 @@ def test_gate_up_silu_default_dispatch(H, label, I, K):
         act_f = torch.zeros(H.frag_numel(M, I), dtype=BF, device="cuda")
         H.gemm(LY.rows_to_frag_ref(x).cuda(), wf, act_f, M, 2 * I, K, 0, epilogue=H.EPI_SILU_FRAG)
         act = LY.frag_to_rows_ref(act_f.cpu(), M, I)
-        assert_close_bf16(act, ref, max_ulp=1, max_frac=0.04, rel_floor=2 ** -7, what=f"{label} gate_up+silu M={M}")
+        # silu(g) * u of two operands that may EACH sit one ulp off (accumulation order) -> up to 2 ulps on the product
+        assert_close_bf16(act, ref, max_ulp=2, max_frac=0.04, rel_floor=2 ** -7, what=f"{label} gate_up+silu M={M}")
+        two = ((act.float() - ref.float()).abs() > 1.5 * 2.0 ** (torch.floor(torch.log2(ref.float().abs().clamp_min(1e-30))) - 7)).float().mean().item()
+        assert two <= 0.002, f"{label} M={M}: {two:.4f} of the outputs are 2 ulps off"
+
 
 
 QKV_SHAPES = [("1b", 32, 8, 64, 2048), ("8b", 32, 8, 128, 4096), ("70b", 64, 8, 128, 8192), ("70b/tp4", 16, 2, 128, 8192),
@@ -192,10 +196,15 @@ def test_decoder_layer_and_head_at_real_shapes(H, preset):
         same = got.argmax(-1) == ref.float().argmax(-1)
         assert bool((same | ((top2[:, 0] - top2[:, 1]) < 0.0625)).all())
         # KV rows written by this forward (fused RoPE + store epilogue at M <= 16) vs the oracle's cache, layer 1
+        # (layer 1's inputs already carry layer 0's propagated 1-ulp flips, and RoPE's x*cos - y*sin cancels: an absolute
+        # bar of 2 ulps of the largest magnitude, not a per-element ulp count)
         for which in (0, 1):
-            ref_rows = torch.stack([orc.kv_cache[which, 1, table[p // bs], p % bs] for p in ps])          # [M, nkv, hd]
-            got_rows = torch.stack([dec.kv_cache[1, which, table[p // bs], :, p % bs, :] for p in ps]).cpu()
-            assert_close_bf16(got_rows, ref_rows, max_ulp=2, max_frac=0.10, rel_floor=2 ** -6, what=f"{preset} kv[{which}] M={M}")
+            ref_rows = torch.stack([orc.kv_cache[which, 1, table[p // bs], p % bs] for p in ps]).float()  # [M, nkv, hd]
+            got_rows = torch.stack([dec.kv_cache[1, which, table[p // bs], :, p % bs, :] for p in ps]).cpu().float()
+            tol = 2.0 ** (math.floor(math.log2(ref_rows.abs().max().item())) - 6)
+            dkv = (got_rows - ref_rows).abs()
+            assert dkv.max().item() <= tol and dkv.mean().item() <= tol / 16, \
+                f"{preset} kv[{which}] M={M}: max {dkv.max().item():.4f} mean {dkv.mean().item():.5f} (tol {tol})"
         pos0 += M
 
 
