@@ -105,7 +105,6 @@ def gemm_roofline(legs):
     as in the real forward; the L launches are captured in a hipGraph and the replay is timed (the real forward is a
     graph replay too; eager launches through ctypes are host-bound for the small shapes)."""
     import torch
-    torch.inference_mode(True).__enter__()       # the engine's buffers are inference tensors (ModelRunner runs under inference_mode)
     tot_bytes = tot_time = 0.0
     tot_launch = 0
     per_kind = {}
@@ -173,7 +172,6 @@ def collective_probe(engine, M):
     m = engine.model_runner.model
     if not m.use_coll:
         return None
-    torch.inference_mode(True).__enter__()
     t = torch.zeros(M, m.h, dtype=torch.bfloat16, device=m.device)
     n = 64
 
@@ -368,9 +366,10 @@ def main():
         "tokens_per_s_at_accepted_len": {str(a): round(a / (dt / args.steps), 1) for a in (1, 2, 4, K + 1)},
     }
     if not args.no_roofline:          # every rank launches the same sequence (shard shapes); rank 0 reports
-        roof = gemm_roofline(legs)
-        if tp > 1:
-            out["collective"] = collective_probe(engine, K + 1)
+        with torch.inference_mode():      # the engine's buffers are inference tensors (ModelRunner runs under inference_mode)
+            roof = gemm_roofline(legs)
+            if tp > 1:
+                out["collective"] = collective_probe(engine, K + 1)
         out["roofline"] = roof
     if rank == 0:
         if not args.no_cpu_baseline:

@@ -62,6 +62,11 @@ int ssd_embedding(const int64_t* ids, const void* table_rows, void* out_rows, in
 int ssd_rmsnorm(const void* x_rows, const void* res_in, void* res_out, const void* weight, float eps,
                 void* out_rows, void* out_frag, const int32_t* gather_rows, int T, int H, void* stream);
 
+/* ssd_rmsnorm whose x is the bf16 rounding of the sum of `splits` fp32 partial slabs [splits][slab_rows][H] written by
+ * ssd_gemm_parts (the row-parallel GEMM that precedes every add_norm_forward, ssd/models/llama3.py:185-199). */
+int ssd_rmsnorm_parts(const void* parts, int splits, int slab_rows, const void* res_in, void* res_out, const void* weight,
+                      float eps, void* out_rows, void* out_frag, int T, int H, void* stream);
+
 /* F.linear(x, W, b) -- ssd/layers/linear.py:65,98,196; ssd/layers/embed_head.py:88,95,111.
  * x_frag [M][K] frag, w_frag [N][K] frag, bias bf16[N] or NULL.  M <= 128 per call.
  * SSD_EPI_SILU_FRAG additionally fuses SiluAndMul.forward -- ssd/layers/activation.py:11-14. */
@@ -76,6 +81,14 @@ int ssd_gemm_wf_cfg(const void* x_frag, const void* w_frag, const void* bias, vo
  * fixed order.  workspace >= (N/16)*splits KiB; counters >= N/16 uint32, zeroed once.  M <= 16, bf16 rows. */
 int ssd_gemm_splitk(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K, int ldy,
                     int splits, int waves, void* workspace, void* counters, void* stream);
+
+/* The same F.linear in its latency-optimal form for small matrices at M <= 16 (csrc/gemm_sk.hip gemm_sp_kernel): K is
+ * split over `splits` workgroups per 16-row group, every wave keeps all its k-tiles in flight, and the partial sums are
+ * NOT combined here: `parts` receives fp32 slabs [splits][M][N] which the consumer (ssd_gemm_fused_parts /
+ * ssd_rmsnorm_parts) sums in slab order while forming x = bf16(sum) + residual -- the kernel boundary is the only
+ * synchronisation.  parts == NULL: splits must be 1 and bf16 rows (+ bias) go to y.  ceil(K/32/splits/waves) <= 8. */
+int ssd_gemm_parts(const void* x_frag, const void* w_frag, const void* bias, void* y, void* parts, int M, int N, int K,
+                   int ldy, int splits, int waves, void* stream);
 
 /* Prefill-chunk GEMM, 16 < M <= 128 (csrc/gemm_pf.hip): the reference's eager prefill F.linear calls
  * (ssd/engine/model_runner.py:602 -> ssd/layers/linear.py:65,98,196).  Same operands and epilogues (SSD_EPI_ROWS,
@@ -100,6 +113,13 @@ int ssd_gemm_fused(const void* x_frag, const void* h_rows, const void* res_in, v
                    const void* w_frag, const void* bias, int M, int N, int K, int epilogue, void* y, int ldy,
                    const int64_t* positions, const float* cos_sin, const int32_t* slots, void* q_out, void* k_cache,
                    void* v_cache, int nh, int nkv, int hd, int block_size, int nt, int waves, void* stream);
+
+/* ssd_gemm_fused with the norm prologue fed by the producer GEMM's fp32 partial slabs [splits][M][K] (ssd_gemm_parts)
+ * instead of bf16 rows: h = bf16(sum over the slabs, in order), the value the reference's F.linear would have stored. */
+int ssd_gemm_fused_parts(const void* h_parts, int splits, const void* res_in, void* res_out, const void* norm_w, float eps,
+                         const void* w_frag, const void* bias, int M, int N, int K, int epilogue, void* y, int ldy,
+                         const int64_t* positions, const float* cos_sin, const int32_t* slots, void* q_out, void* k_cache,
+                         void* v_cache, int nh, int nkv, int hd, int block_size, int nt, int waves, void* stream);
 
 /* (RMSHeadNorm q/k, Qwen3: ssd/models/qwen3.py:96-104) + RotaryEmbedding.forward
  * (ssd/layers/rotary_embedding.py:40-60) + store_kvcache (ssd/layers/attention.py:10-41).

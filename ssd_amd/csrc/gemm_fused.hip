@@ -27,6 +27,8 @@ struct FusedParams {
   const u32x4_t* Wf;
   const u32x4_t* Xf;        // fragment-major x (when h == nullptr)
   const bf16_t* h;          // row-major [M][K] (XNORM)
+  const float* h_parts;     // XNORM alternative to h: fp32 [S][M][K] split-K partial sums of the producer GEMM (gemm_sk.hip
+  int S;                    //   ssd_gemm_parts); h = bf16(sum over s, in s order) is formed here
   const bf16_t* res_in;     // row-major [M][K] or nullptr
   bf16_t* res_out;          // row-major [M][K] or nullptr
   const bf16_t* norm_w;     // [K]
@@ -44,9 +46,38 @@ struct FusedParams {
   int scratch_bytes;        // LDS bytes in front of the x^ image (split-K combine area, also the prologue scratch)
 };
 
-constexpr int FUSED_MAXC = 4;   // 8-element chunks of (h + res) a thread may hold in registers during the prologue
+// 8-element chunks of (h + res) a thread may hold in registers during the prologue: template parameter MAXC (1 when M*K/8
+// fits the workgroup's threads -- the single-token draft decode -- which keeps the kernel clear of the 128-VGPR ceiling)
 
-template <int NT, int EPI, bool XNORM>
+// x32[0..7] = fp32(h) + fp32(res) for chunk k8 of row mm, where h is either the producer's bf16 rows or the bf16 rounding
+// of the sum of its S fp32 partial slabs (summed in slab order: deterministic; the rounding mirrors the bf16 store of the
+// reference's F.linear).  All loads of a chunk are issued before any arithmetic.
+__device__ __forceinline__ void fused_load_x32(const FusedParams& p, int mm, int k8, float (&x)[8]) {
+  u32x4_t rv = {0u, 0u, 0u, 0u};
+  if (p.res_in) rv = *reinterpret_cast<const u32x4_t*>(p.res_in + (size_t)mm * p.K + k8 * 8);
+  float hf[8];
+  if (p.h_parts) {
+    f32x4_t lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+    for (int sidx = 0; sidx < p.S; ++sidx) {
+      const float* src = p.h_parts + ((size_t)sidx * p.M + mm) * p.K + k8 * 8;
+      lo += *reinterpret_cast<const f32x4_t*>(src);
+      hi += *reinterpret_cast<const f32x4_t*>(src + 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { hf[j] = round_bf(lo[j]); hf[4 + j] = round_bf(hi[j]); }
+  } else {
+    const u32x4_t hv = *reinterpret_cast<const u32x4_t*>(p.h + (size_t)mm * p.K + k8 * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { hf[2 * j] = bf2f(hv[j] & 0xffffu); hf[2 * j + 1] = bf2f(hv[j] >> 16); }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    x[2 * j] = hf[2 * j] + bf2f(rv[j] & 0xffffu);
+    x[2 * j + 1] = hf[2 * j + 1] + bf2f(rv[j] >> 16);
+  }
+}
+
+template <int NT, int EPI, bool XNORM, int FUSED_MAXC>
 __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -87,96 +118,102 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
   const int kt0 = wave * U;
   const int ngroups = KT / U;
   const int nmain = ngroups > wave ? (ngroups - wave + nw - 1) / nw : 0;   // groups of this wave
-  if (nmain > 0) loadw(0, kt0);   // the first weight tiles fly while the norm prologue runs
+  // the first TWO groups of weight tiles fly while the norm prologue runs (for the 1B draft that is the whole K range:
+  // one HBM round trip per wave; a kernel this short is a latency chain)
+  if (nmain > 0) loadw(0, kt0);
+  if (nmain > 1) loadw(1, kt0 + kstep);
+  // RoPE epilogue operands of the wave that will own row group `wave` (positions -> cos/sin rows -> slot: a chain of
+  // dependent L2 round trips if left to the epilogue), fetched now, behind the weight stream
+  float pre_cs[8];
+  int pre_slot = -1;
+  bool pre_ok = false;
+  if (EPI == FEPI_QKV_ROPE && wave < NT && mcol < M) {
+    const int grp = tile0 + wave;
+    const int gph = p.hd >> 4;
+    pre_slot = p.slots[mcol];
+    if (grp < (p.nh + p.nkv) * gph) {
+      const int d = (grp % gph) * 8 + (q4 & 1) * 4;
+      const float* cs = p.cos_sin + (size_t)p.positions[mcol] * p.hd;
+      const f32x4_t c4 = *reinterpret_cast<const f32x4_t*>(cs + d), s4 = *reinterpret_cast<const f32x4_t*>(cs + (p.hd >> 1) + d);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { pre_cs[r] = c4[r]; pre_cs[4 + r] = s4[r]; }
+    }
+    pre_ok = true;
+  }
   if (XNORM) {
     // ---- prologue: x32 = h + res kept in registers; per-chunk sums of squares -> per-row rs (fixed order) ->
     //      x^ = bf16(x32 * rs * w) into the LDS image; residual slice written to res_out ----
-    float* ssbuf = reinterpret_cast<float*>(smem);      // [M*K8]
-    float x32[FUSED_MAXC][8];
-    u32x4_t wv[FUSED_MAXC];
+    float* ssbuf = reinterpret_cast<float*>(smem);      // [M*K8] chunk sums, then [nw][16] per-wave copies of rs
+    constexpr int MC = FUSED_MAXC > 0 ? FUSED_MAXC : 1;     // MAXC = 0: no register cache, two passes over the L2-resident rows
+    float x32[MC][8];
+    u32x4_t wv[MC];
     const int total = M * K8;
-    const bool cached = total <= FUSED_MAXC * (int)blockDim.x;     // block-uniform
+    const bool cached = FUSED_MAXC > 0 && total <= FUSED_MAXC * (int)blockDim.x;     // block-uniform
+    const int cpb = (K8 + gridDim.x - 1) / gridDim.x;              // residual: workgroup b owns chunk columns [b*cpb, (b+1)*cpb)
     if (!cached) {   // large M*K (or few waves): two passes over the L2-resident rows instead of registers
       for (int c = threadIdx.x; c < total; c += blockDim.x) {
         const int mm = c / K8, k8 = c % K8;
-        const u32x4_t hv = *reinterpret_cast<const u32x4_t*>(p.h + (size_t)mm * K + k8 * 8);
-        u32x4_t rv = {0u, 0u, 0u, 0u};
-        if (p.res_in) rv = *reinterpret_cast<const u32x4_t*>(p.res_in + (size_t)mm * K + k8 * 8);
+        float xx[8];
+        fused_load_x32(p, mm, k8, xx);
         float ss = 0.f;
         u32x4_t o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float lo = bf2f(hv[j] & 0xffffu) + bf2f(rv[j] & 0xffffu);
-          const float hi = bf2f(hv[j] >> 16) + bf2f(rv[j] >> 16);
-          ss += lo * lo; ss += hi * hi;
-          o[j] = pack_bf2(lo, hi);
+          ss += xx[2 * j] * xx[2 * j]; ss += xx[2 * j + 1] * xx[2 * j + 1];
+          o[j] = pack_bf2(xx[2 * j], xx[2 * j + 1]);
         }
         ssbuf[c] = ss;
-        if (p.res_out) {
-          const int cpb = (K8 + gridDim.x - 1) / gridDim.x;
-          if (k8 / cpb == (int)blockIdx.x) *reinterpret_cast<u32x4_t*>(p.res_out + (size_t)mm * K + k8 * 8) = o;
-        }
+        if (p.res_out && k8 / cpb == (int)blockIdx.x) *reinterpret_cast<u32x4_t*>(p.res_out + (size_t)mm * K + k8 * 8) = o;
       }
     }
 #pragma unroll
-    for (int i = 0; i < FUSED_MAXC; ++i) {
+    for (int i = 0; i < MC; ++i) {
       const int c = threadIdx.x + i * blockDim.x;
       if (cached && c < total) {
         const int mm = c / K8, k8 = c % K8;
-        const u32x4_t hv = *reinterpret_cast<const u32x4_t*>(p.h + (size_t)mm * K + k8 * 8);
-        u32x4_t rv = {0u, 0u, 0u, 0u};
-        if (p.res_in) rv = *reinterpret_cast<const u32x4_t*>(p.res_in + (size_t)mm * K + k8 * 8);
+        fused_load_x32(p, mm, k8, x32[i]);
         wv[i] = *reinterpret_cast<const u32x4_t*>(p.norm_w + k8 * 8);
         float ss = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float lo = bf2f(hv[j] & 0xffffu) + bf2f(rv[j] & 0xffffu);
-          const float hi = bf2f(hv[j] >> 16) + bf2f(rv[j] >> 16);
-          x32[i][2 * j] = lo; x32[i][2 * j + 1] = hi;
-          ss += lo * lo; ss += hi * hi;
-        }
+        for (int j = 0; j < 4; ++j) { ss += x32[i][2 * j] * x32[i][2 * j]; ss += x32[i][2 * j + 1] * x32[i][2 * j + 1]; }
         ssbuf[c] = ss;
-        // residual: workgroup b owns chunk columns [b*cpb, (b+1)*cpb)
-        if (p.res_out) {
-          const int cpb = (K8 + gridDim.x - 1) / gridDim.x;
-          if (k8 / cpb == (int)blockIdx.x) {
-            u32x4_t o;
+        if (p.res_out && k8 / cpb == (int)blockIdx.x) {
+          u32x4_t o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = pack_bf2(x32[i][2 * j], x32[i][2 * j + 1]);
-            *reinterpret_cast<u32x4_t*>(p.res_out + (size_t)mm * K + k8 * 8) = o;
-          }
+          for (int j = 0; j < 4; ++j) o[j] = pack_bf2(x32[i][2 * j], x32[i][2 * j + 1]);
+          *reinterpret_cast<u32x4_t*>(p.res_out + (size_t)mm * K + k8 * 8) = o;
         }
       }
     }
     __syncthreads();
-    float* rsbuf = ssbuf + total;                        // [M], behind the chunk sums
-    for (int mm = wave; mm < M; mm += nw) {
+    // every wave reduces the chunk sums of all M rows itself (same order as ssd_rmsnorm: lane-strided partials, then the
+    // xor tree) and keeps rs in its own LDS row: no second workgroup barrier
+    float* rsbuf = ssbuf + total + wave * 16;           // behind the chunk sums
+    for (int mm = 0; mm < M; ++mm) {
       float t = 0.f;
       for (int c = lane; c < K8; c += 64) t += ssbuf[mm * K8 + c];
       t = wave_sum(t);
       if (lane == 0) rsbuf[mm] = 1.0f / sqrtf(t / (float)K + p.eps);
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (!cached) {
       for (int c = threadIdx.x; c < total; c += blockDim.x) {
         const int mm = c / K8, k8 = c % K8;
         const float rs = rsbuf[mm];
-        const u32x4_t hv = *reinterpret_cast<const u32x4_t*>(p.h + (size_t)mm * K + k8 * 8);
-        u32x4_t rv = {0u, 0u, 0u, 0u};
-        if (p.res_in) rv = *reinterpret_cast<const u32x4_t*>(p.res_in + (size_t)mm * K + k8 * 8);
+        float xx[8];
+        fused_load_x32(p, mm, k8, xx);
         const u32x4_t nwv = *reinterpret_cast<const u32x4_t*>(p.norm_w + k8 * 8);
         u32x4_t o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float lo = bf2f(hv[j] & 0xffffu) + bf2f(rv[j] & 0xffffu);
-          const float hi = bf2f(hv[j] >> 16) + bf2f(rv[j] >> 16);
-          o[j] = pack_bf2((lo * rs) * bf2f(nwv[j] & 0xffffu), (hi * rs) * bf2f(nwv[j] >> 16));
-        }
+        for (int j = 0; j < 4; ++j)
+          o[j] = pack_bf2((xx[2 * j] * rs) * bf2f(nwv[j] & 0xffffu), (xx[2 * j + 1] * rs) * bf2f(nwv[j] >> 16));
         xlds[k8 * M + mm] = o;
       }
     }
 #pragma unroll
-    for (int i = 0; i < FUSED_MAXC; ++i) {
+    for (int i = 0; i < MC; ++i) {
       const int c = threadIdx.x + i * blockDim.x;
       if (cached && c < total) {
         const int mm = c / K8, k8 = c % K8;
@@ -198,17 +235,19 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
     return o;
   };
 
-  // ---- main loop: weights (and fragment-major x) double-buffered in registers ----
+  // ---- main loop: two groups of weight tiles (and fragment-major x) are in flight from the start; the buffer just
+  //      consumed is refilled with the group two steps ahead ----
   int kt = kt0;
   auto stage = [&](auto curc, int it) {          // curc: compile-time buffer index (runtime-indexed register
     constexpr int cur = decltype(curc)::value;   // arrays would go to scratch)
-    if (it + 1 < nmain) loadw(cur ^ 1, kt + kstep);
+    u32x4_t xb[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const u32x4_t xb = xfrag(cur, u, kt + u);
+    for (int u = 0; u < U; ++u) xb[u] = xfrag(cur, u, kt + u);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(wa[cur][u][nt], xb, acc[nt]);
-    }
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(wa[cur][u][nt], xb[u], acc[nt]);
+    if (it + 2 < nmain) loadw(cur, kt + 2 * kstep);
     kt += kstep;
   };
   for (int it = 0; it < nmain; it += 2) {
@@ -283,11 +322,19 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
           if (m < M) {
             const int hi = q4 >> 1;                       // 0: first half of the head dim (x1), 1: second half (x2)
             const int d = j * 8 + (q4 & 1) * 4;           // dim within the half
-            const float* cs = p.cos_sin + (size_t)p.positions[m] * p.hd;
+            float cs8[8];
+            if (nt == wave && pre_ok) {
+#pragma unroll
+              for (int r = 0; r < 8; ++r) cs8[r] = pre_cs[r];
+            } else {
+              const float* cs = p.cos_sin + (size_t)p.positions[m] * p.hd;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { cs8[r] = cs[d + r]; cs8[4 + r] = cs[half + d + r]; }
+            }
             float yv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float co = cs[d + r], si = cs[half + d + r];
+              const float co = cs8[r], si = cs8[4 + r];
               yv[r] = hi ? __fadd_rn(__fmul_rn(x[r], co), __fmul_rn(other[r], si))
                          : __fsub_rn(__fmul_rn(x[r], co), __fmul_rn(other[r], si));
             }
@@ -296,7 +343,7 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
             if (head < p.nh) {
               *reinterpret_cast<u32x2_t*>(p.q_out + ((size_t)m * p.nh + head) * p.hd + dim) = v;
             } else {
-              const int slot = p.slots[m];
+              const int slot = (nt == wave && pre_ok) ? pre_slot : p.slots[m];
               if (slot >= 0) {
                 const size_t rowi = ((size_t)(slot / p.bs) * p.nkv + (head - p.nh)) * p.bs + (slot % p.bs);
                 *reinterpret_cast<u32x2_t*>(p.k_cache + rowi * p.hd + dim) = v;
@@ -306,7 +353,7 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
         } else if (m < M) {   // V: natural row order, straight to the paged cache
           const int vg = grp - qk_groups;
           const int kvh = vg / gph, dim = (vg % gph) * 16 + nrow;
-          const int slot = p.slots[m];
+          const int slot = (nt == wave && pre_ok) ? pre_slot : p.slots[m];
           if (slot >= 0) {
             const size_t rowi = ((size_t)(slot / p.bs) * p.nkv + kvh) * p.bs + (slot % p.bs);
             const u32x2_t v = {pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3])};
@@ -318,26 +365,37 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
   }
 }
 
-template <int NT, int EPI, bool XNORM>
-static int launch_fused(const FusedParams& p, int waves, hipStream_t st) {
+template <int NT, int EPI, bool XNORM, int MAXC>
+static int launch_fused_c(const FusedParams& p, int waves, hipStream_t st) {
   const int blocks = (p.N / 16) / NT;
   size_t lds = (size_t)waves * NT * 64 * sizeof(f32x4_t);
   FusedParams q = p;
   if (XNORM) {
     const size_t chunks = (size_t)p.M * (p.K / 8);
-    if (lds < chunks * 4 + 64) lds = (chunks * 4 + 64 + 15) & ~(size_t)15;    // chunk sums + rs live in the scratch area
+    const size_t need = chunks * 4 + (size_t)waves * 64;                      // chunk sums + one rs row per wave
+    if (lds < need) lds = (need + 15) & ~(size_t)15;
     q.scratch_bytes = (int)lds;
     lds += chunks * 16;                                                       // x^ image
     if (lds > 160 * 1024) return SSD_ERR_SHAPE;
   } else {
     q.scratch_bytes = (int)lds;
   }
-  auto kern = gemm_fused_kernel<NT, EPI, XNORM>;
+  auto kern = gemm_fused_kernel<NT, EPI, XNORM, MAXC>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return SSD_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, st, q);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
+template <int NT, int EPI, bool XNORM>
+static int launch_fused(const FusedParams& p, int waves, hipStream_t st) {
+  if constexpr (XNORM) {
+    if (p.M * (p.K / 8) <= waves * 64) return launch_fused_c<NT, EPI, true, 1>(p, waves, st);
+    return launch_fused_c<NT, EPI, true, 0>(p, waves, st);
+  } else {
+    return launch_fused_c<NT, EPI, false, 1>(p, waves, st);
+  }
 }
 
 template <int EPI, bool XNORM>
@@ -351,14 +409,15 @@ static int launch_fused_nt(const FusedParams& p, int nt, int waves, hipStream_t 
   return SSD_ERR_ARG;
 }
 
-extern "C" int ssd_gemm_fused(const void* x_frag, const void* h_rows, const void* res_in, void* res_out,
-                              const void* norm_w, float eps, const void* w_frag, const void* bias, int M, int N, int K,
-                              int epilogue, void* y, int ldy, const int64_t* positions, const float* cos_sin,
-                              const int32_t* slots, void* q_out, void* k_cache, void* v_cache, int nh, int nkv, int hd,
-                              int block_size, int nt, int waves, void* stream) {
+static int fused_impl(const void* x_frag, const void* h_rows, const float* h_parts, int S, const void* res_in, void* res_out,
+                      const void* norm_w, float eps, const void* w_frag, const void* bias, int M, int N, int K,
+                      int epilogue, void* y, int ldy, const int64_t* positions, const float* cos_sin,
+                      const int32_t* slots, void* q_out, void* k_cache, void* v_cache, int nh, int nkv, int hd,
+                      int block_size, int nt, int waves, void* stream) {
   if (M <= 0 || M > 16 || (N & 15) || (K & 31) || N <= 0 || K <= 0) return SSD_ERR_SHAPE;
-  if ((h_rows == nullptr) == (x_frag == nullptr)) return SSD_ERR_ARG;     // exactly one x source
-  if (h_rows && !norm_w) return SSD_ERR_ARG;
+  if ((h_rows != nullptr) + (x_frag != nullptr) + (h_parts != nullptr) != 1) return SSD_ERR_ARG;     // exactly one x source
+  if ((h_rows || h_parts) && !norm_w) return SSD_ERR_ARG;
+  if (h_parts && (S < 1 || S > 16)) return SSD_ERR_ARG;
   if (res_out && res_out == res_in) return SSD_ERR_ARG;                   // in-place residual would race
   const int groups = N / 16;
   if (nt <= 0 || waves <= 0) {
@@ -376,12 +435,13 @@ extern "C" int ssd_gemm_fused(const void* x_frag, const void* h_rows, const void
   }
   FusedParams p;
   p.Wf = (const u32x4_t*)w_frag; p.Xf = (const u32x4_t*)x_frag; p.h = (const bf16_t*)h_rows;
+  p.h_parts = h_parts; p.S = S;
   p.res_in = (const bf16_t*)res_in; p.res_out = (bf16_t*)res_out; p.norm_w = (const bf16_t*)norm_w;
   p.bias = (const bf16_t*)bias; p.y = y; p.positions = positions; p.cos_sin = cos_sin; p.slots = slots;
   p.q_out = (bf16_t*)q_out; p.k_cache = (bf16_t*)k_cache; p.v_cache = (bf16_t*)v_cache;
   p.eps = eps; p.M = M; p.N = N; p.K = K; p.ldy = ldy; p.nh = nh; p.nkv = nkv; p.hd = hd; p.bs = block_size;
   hipStream_t st = (hipStream_t)stream;
-  const bool xn = h_rows != nullptr;
+  const bool xn = h_rows != nullptr || h_parts != nullptr;
 #define FUSED_DISPATCH(E)                                                                          \
   return xn ? launch_fused_nt<E, true>(p, nt, waves, st) : launch_fused_nt<E, false>(p, nt, waves, st);
   switch (epilogue) {
@@ -391,4 +451,24 @@ extern "C" int ssd_gemm_fused(const void* x_frag, const void* h_rows, const void
     default: return SSD_ERR_ARG;
   }
 #undef FUSED_DISPATCH
+}
+
+extern "C" int ssd_gemm_fused(const void* x_frag, const void* h_rows, const void* res_in, void* res_out,
+                              const void* norm_w, float eps, const void* w_frag, const void* bias, int M, int N, int K,
+                              int epilogue, void* y, int ldy, const int64_t* positions, const float* cos_sin,
+                              const int32_t* slots, void* q_out, void* k_cache, void* v_cache, int nh, int nkv, int hd,
+                              int block_size, int nt, int waves, void* stream) {
+  return fused_impl(x_frag, h_rows, nullptr, 0, res_in, res_out, norm_w, eps, w_frag, bias, M, N, K, epilogue, y, ldy, positions,
+                    cos_sin, slots, q_out, k_cache, v_cache, nh, nkv, hd, block_size, nt, waves, stream);
+}
+
+// Same, with the producer GEMM's output given as `splits` fp32 partial slabs [splits][M][K] (ssd_gemm_parts) instead of
+// bf16 rows: the prologue sums them in slab order, rounds to bf16 (the reference's F.linear store) and continues as above.
+extern "C" int ssd_gemm_fused_parts(const void* h_parts, int splits, const void* res_in, void* res_out, const void* norm_w,
+                                    float eps, const void* w_frag, const void* bias, int M, int N, int K, int epilogue, void* y,
+                                    int ldy, const int64_t* positions, const float* cos_sin, const int32_t* slots, void* q_out,
+                                    void* k_cache, void* v_cache, int nh, int nkv, int hd, int block_size, int nt, int waves,
+                                    void* stream) {
+  return fused_impl(nullptr, nullptr, (const float*)h_parts, splits, res_in, res_out, norm_w, eps, w_frag, bias, M, N, K, epilogue,
+                    y, ldy, positions, cos_sin, slots, q_out, k_cache, v_cache, nh, nkv, hd, block_size, nt, waves, stream);
 }

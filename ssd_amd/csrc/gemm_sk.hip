@@ -103,3 +103,106 @@ extern "C" int ssd_gemm_splitk(const void* x_frag, const void* w_frag, const voi
                      K, ldy, (unsigned long long*)workspace, (unsigned int*)counters);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// gemm_sp_kernel: the latency-optimal form for the SMALL matrices of a decode layer (1B-class o_proj / down_proj: 8-34 MB,
+// N = 2048 -> only 128 row groups).  Two measured facts shape it (profiles/r02_draft_probe.txt):
+//   * one CU pulls ~25-28 GB/s from HBM whatever it runs, so 128 workgroups cap a launch at ~3 TB/s: the K range is split
+//     over gridDim.y = S workgroups per row group (>= 256 workgroups in total);
+//   * a launch this short is a latency chain, not a stream: every wave therefore puts ALL of its k-tiles in flight at
+//     once (TPW 1-KiB weight loads per lane, one HBM round trip) instead of walking groups of 4.
+// The S partial sums are NOT combined here (an in-launch cross-workgroup combine costs an agent-scope release + acquire,
+// ~3.5 us, more than the kernel itself -- gemm_sk_kernel above measures that): they are written as fp32 slabs
+// P[z][m][n], and the CONSUMER kernel (the next fused norm+GEMM's prologue, gemm_fused.hip, or ssd_rmsnorm) sums the S
+// slabs in z order while it forms x = bf16(sum) + residual anyway.  The kernel boundary is the only synchronisation.
+// With P == nullptr and S == 1 it writes bf16 rows (+ bias) like gemm_sk_kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int TPW, int MT>
+__global__ void __launch_bounds__(1024)
+gemm_sp_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, const bf16_t* __restrict__ bias,
+               bf16_t* __restrict__ Y, float* __restrict__ P, int M, int N, int K, int ldy) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nw = blockDim.x >> 6;
+  const int KT = K >> 5;
+  const int g = blockIdx.x, z = blockIdx.y, S = gridDim.y;
+  const int kz0 = (int)(((long)KT * z) / S), kz1 = (int)(((long)KT * (z + 1)) / S);
+  const u32x4_t* wp = Wf + ((size_t)g * KT << 6) + lane;
+  const u32x4_t* xp = Xf + lane;
+  const size_t xstride = (size_t)KT << 6;      // chunks between the 16-row tiles of x
+  u32x4_t a[TPW], b[TPW][MT];
+  // tiles are dealt round-robin (wave w: kz0 + w, kz0 + w + nw, ...): the workgroup walks its K slice linearly
+  // (every load is unconditional on a clamped tile index: a branch around a load makes hipcc drain vmcnt per element; a
+  // slot past the slice end is zeroed after the fact)
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int kt = min(kz0 + wave + i * nw, kz1 - 1);        // wave-uniform
+    a[i] = __builtin_nontemporal_load(wp + ((size_t)kt << 6));
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      b[i][mt] = u32x4_t{0u, 0u, 0u, 0u};
+      if (mt * 16 + (lane & 15) < M) b[i][mt] = xp[mt * xstride + ((size_t)kt << 6)];    // padding token rows are not loaded
+    }
+  }
+  f32x4_t acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    if (kz0 + wave + i * nw >= kz1) a[i] = u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(a[i], b[i][mt], acc[mt]);
+  }
+  f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);        // [nw][MT][64]
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) red[(wave * MT + mt) * 64 + lane] = acc[mt];
+  __syncthreads();
+  if (wave >= MT) return;                                  // wave mt finishes m-tile mt
+  const int mt = wave;
+  f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+  for (int w = 0; w < nw; ++w) s += red[(w * MT + mt) * 64 + lane];
+  const int m = mt * 16 + (lane & 15), n = g * 16 + (lane >> 4) * 4;
+  if (m >= M) return;
+  if (P) {
+    *reinterpret_cast<f32x4_t*>(P + ((size_t)z * M + m) * N + n) = s;
+  } else {
+    if (bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[r] += bf2f(bias[n + r]);
+    }
+    const u32x2_t v = {pack_bf2(s[0], s[1]), pack_bf2(s[2], s[3])};
+    *reinterpret_cast<u32x2_t*>(Y + (size_t)m * ldy + n) = v;
+  }
+}
+
+// parts: fp32 [splits][M][N] slabs (y must be null) or null (splits must be 1; bf16 rows into y, + bias).
+// M <= 32; splits 1..16, waves 1..16 (>= 2 when M > 16), and ceil((K/32 / splits) / waves) <= 8 k-tiles per wave.
+extern "C" int ssd_gemm_parts(const void* x_frag, const void* w_frag, const void* bias, void* y, void* parts, int M, int N,
+                              int K, int ldy, int splits, int waves, void* stream) {
+  if (M <= 0 || M > 32 || (N & 15) || (K & 31) || N <= 0 || K <= 0) return SSD_ERR_SHAPE;
+  if (splits < 1 || splits > 16 || waves < 1 || waves > 16) return SSD_ERR_ARG;
+  if ((parts == nullptr) == (y == nullptr)) return SSD_ERR_ARG;
+  if (!parts && splits != 1) return SSD_ERR_ARG;
+  const int KT = K >> 5;
+  const int mt = (M + 15) / 16;
+  if (KT < splits || waves < mt) return SSD_ERR_ARG;
+  const int per_wg = (KT + splits - 1) / splits;
+  const int tpw = (per_wg + waves - 1) / waves;
+  if (tpw > 8) return SSD_ERR_ARG;
+  const dim3 grid(N / 16, splits), block(64 * waves);
+  const size_t lds = (size_t)waves * mt * 64 * sizeof(f32x4_t);
+  hipStream_t st = (hipStream_t)stream;
+#define SP_LAUNCH(T, MTV)                                                                                               \
+  hipLaunchKernelGGL((gemm_sp_kernel<T, MTV>), grid, block, lds, st, (const u32x4_t*)w_frag, (const u32x4_t*)x_frag,     \
+                     (const bf16_t*)bias, (bf16_t*)y, (float*)parts, M, N, K, ldy)
+#define SP_TPW(MTV)                                                                                                     \
+  if (tpw <= 1) SP_LAUNCH(1, MTV);                                                                                      \
+  else if (tpw <= 2) SP_LAUNCH(2, MTV);                                                                                 \
+  else if (tpw <= 4) SP_LAUNCH(4, MTV);                                                                                 \
+  else SP_LAUNCH(8, MTV)
+  if (mt == 1) { SP_TPW(1); } else { SP_TPW(2); }
+#undef SP_TPW
+#undef SP_LAUNCH
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}

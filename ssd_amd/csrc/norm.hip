@@ -35,7 +35,8 @@ constexpr int NORM_MAXC = 8;  // chunks of 8 elements per thread -> H <= 256*8*8
 __global__ void __launch_bounds__(NORM_THREADS)
 rmsnorm_kernel(const u32x4_t* __restrict__ x, const u32x4_t* __restrict__ res_in, u32x4_t* __restrict__ res_out,
                const u32x4_t* __restrict__ w, float eps, u32x4_t* __restrict__ out_rows,
-               u32x4_t* __restrict__ out_frag, const int32_t* __restrict__ gather, int H) {
+               u32x4_t* __restrict__ out_frag, const int32_t* __restrict__ gather, int H,
+               const float* __restrict__ parts, int S, int slab_rows) {
   __shared__ float red[NORM_THREADS / 64];
   const int row_out = blockIdx.x;
   const int row_in = gather ? gather[row_out] : row_out;
@@ -47,7 +48,18 @@ rmsnorm_kernel(const u32x4_t* __restrict__ x, const u32x4_t* __restrict__ res_in
   for (int i = 0; i < NORM_MAXC; ++i) {
     const int c = threadIdx.x + i * NORM_THREADS;
     if (c < H8) {
-      const u32x4_t xv = x[(size_t)row_in * H8 + c];
+      u32x4_t xv;
+      if (parts) {      // x = bf16(sum of the producer GEMM's S fp32 partial slabs, in slab order) -- csrc/gemm_sk.hip ssd_gemm_parts
+        f32x4_t a = {0.f, 0.f, 0.f, 0.f}, b = a;
+        for (int sidx = 0; sidx < S; ++sidx) {
+          const float* src = parts + ((size_t)sidx * slab_rows + row_in) * H + c * 8;
+          a += *reinterpret_cast<const f32x4_t*>(src);
+          b += *reinterpret_cast<const f32x4_t*>(src + 4);
+        }
+        xv = u32x4_t{pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(b[0], b[1]), pack_bf2(b[2], b[3])};
+      } else {
+        xv = x[(size_t)row_in * H8 + c];
+      }
       u32x4_t rv = {0u, 0u, 0u, 0u};
       if (res_in) rv = res_in[(size_t)row_in * H8 + c];
       u32x4_t ro;
@@ -92,6 +104,18 @@ extern "C" int ssd_rmsnorm(const void* x_rows, const void* res_in, void* res_out
   if (T <= 0 || H <= 0 || (H & 31) || H > NORM_THREADS * NORM_MAXC * 8) return SSD_ERR_SHAPE;
   hipLaunchKernelGGL(rmsnorm_kernel, dim3(T), dim3(NORM_THREADS), 0, (hipStream_t)stream, (const u32x4_t*)x_rows,
                      (const u32x4_t*)res_in, (u32x4_t*)res_out, (const u32x4_t*)weight, eps, (u32x4_t*)out_rows,
-                     (u32x4_t*)out_frag, gather_rows, H);
+                     (u32x4_t*)out_frag, gather_rows, H, (const float*)nullptr, 0, 0);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
+// Same with x given as `splits` fp32 partial slabs [splits][slab_rows][H] of the producing split-K GEMM (ssd_gemm_parts):
+// x = bf16(sum over the slabs in order), then exactly ssd_rmsnorm.
+extern "C" int ssd_rmsnorm_parts(const void* parts, int splits, int slab_rows, const void* res_in, void* res_out,
+                                 const void* weight, float eps, void* out_rows, void* out_frag, int T, int H, void* stream) {
+  if (T <= 0 || H <= 0 || (H & 31) || H > NORM_THREADS * NORM_MAXC * 8 || splits < 1 || splits > 16 || slab_rows < T) return SSD_ERR_SHAPE;
+  if (!parts) return SSD_ERR_ARG;
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3(T), dim3(NORM_THREADS), 0, (hipStream_t)stream, (const u32x4_t*)nullptr,
+                     (const u32x4_t*)res_in, (u32x4_t*)res_out, (const u32x4_t*)weight, eps, (u32x4_t*)out_rows,
+                     (u32x4_t*)out_frag, (const int32_t*)nullptr, H, (const float*)parts, splits, slab_rows);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }

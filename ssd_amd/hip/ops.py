@@ -67,6 +67,19 @@ def gemm_splitk(x_frag, w_frag, y, M: int, N: int, K: int, ldy: int, splits: int
                                           _p(counters), _stream()), "ssd_gemm_splitk")
 
 
+def gemm_parts(x_frag, w_frag, M: int, N: int, K: int, *, parts=None, splits: int = 1, waves: int = 8, y=None, ldy: int = 0, bias=None):
+    """Latency-optimal small-matrix GEMM (csrc/gemm_sk.hip gemm_sp_kernel): K split over `splits` workgroups per row group,
+    fp32 partial slabs [splits][M][N] into `parts` (summed by the consumer), or bf16 rows into y when splits == 1."""
+    _check(load_library().ssd_gemm_parts(_p(x_frag), _p(w_frag), _p(bias), _p(y), _p(parts), M, N, K, ldy, splits, waves,
+                                         _stream()), "ssd_gemm_parts")
+
+
+def rmsnorm_parts(parts, splits: int, slab_rows: int, weight, eps: float, T: int, H: int, res_in=None, res_out=None, out_rows=None,
+                  out_frag=None):
+    _check(load_library().ssd_rmsnorm_parts(_p(parts), splits, slab_rows, _p(res_in), _p(res_out), _p(weight), eps, _p(out_rows),
+                                            _p(out_frag), T, H, _stream()), "ssd_rmsnorm_parts")
+
+
 def gemm_pf_workspace_bytes(M: int, N: int, K: int) -> int:
     import ctypes
     out = ctypes.c_int64(0)
@@ -100,10 +113,17 @@ def rows_to_frag_qkv(src, dst, nh: int, nkv: int, hd: int, K: int):
 FEPI_ROWS, FEPI_SILU_FRAG, FEPI_QKV_ROPE = 0, 1, 3
 
 
-def gemm_fused(w_frag, M: int, N: int, K: int, epilogue: int, *, x_frag=None, h_rows=None, res_in=None, res_out=None,
+def gemm_fused(w_frag, M: int, N: int, K: int, epilogue: int, *, x_frag=None, h_rows=None, h_parts=None, splits: int = 0,
+               res_in=None, res_out=None,
                norm_w=None, eps: float = 0.0, bias=None, y=None, ldy: int = 0, positions=None, cos_sin=None, slots=None,
                q_out=None, k_cache=None, v_cache=None, nh: int = 0, nkv: int = 0, hd: int = 0, block_size: int = 0,
                nt: int = 0, waves: int = 0):
+    if h_parts is not None:     # norm prologue fed by the producer's fp32 split-K slabs [splits][M][K]
+        _check(load_library().ssd_gemm_fused_parts(_p(h_parts), splits, _p(res_in), _p(res_out), _p(norm_w), eps, _p(w_frag),
+                                                   _p(bias), M, N, K, epilogue, _p(y), ldy, _p(positions), _p(cos_sin), _p(slots),
+                                                   _p(q_out), _p(k_cache), _p(v_cache), nh, nkv, hd, block_size, nt, waves,
+                                                   _stream()), "ssd_gemm_fused_parts")
+        return
     _check(load_library().ssd_gemm_fused(_p(x_frag), _p(h_rows), _p(res_in), _p(res_out), _p(norm_w), eps, _p(w_frag),
                                          _p(bias), M, N, K, epilogue, _p(y), ldy, _p(positions), _p(cos_sin), _p(slots),
                                          _p(q_out), _p(k_cache), _p(v_cache), nh, nkv, hd, block_size, nt, waves,

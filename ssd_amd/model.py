@@ -94,6 +94,14 @@ class HipDecoder:
         self.buf_af = z(H.frag_numel(T, self.qn))
         self.buf_actf = z(H.frag_numel(T, self.I))
         self.buf_lastf = z(H.frag_numel(self.max_logit_rows, self.h))
+        # split-K partial slabs of o_proj / down_proj for models whose hidden size gives too few 16-row groups to fill
+        # the chip (csrc/gemm_sk.hip gemm_sp_kernel): fp32 [S][T][h], summed by the consumer's prologue / ssd_rmsnorm_parts
+        self.use_parts = os.environ.get("SSD_PARTS", "1") != "0" and (self.h // 16) < 256
+        self.parts_cfg_o = self._parts_cfg(self.h, self.qn)
+        self.parts_cfg_d = self._parts_cfg(self.h, self.I)
+        pt = min(T, 32)
+        self.buf_parts_o = z(self.parts_cfg_o[0] * pt * self.h, dtype=torch.float32) if self.use_parts else None
+        self.buf_parts_d = z(self.parts_cfg_d[0] * pt * self.h, dtype=torch.float32) if self.use_parts else None
         self.logits = z(self.max_logit_rows, self.V)
         self.max_splits = 16
         self._ws_pf = None           # fp32 split-K partials of the prefill GEMM, allocated by the first prefill
@@ -222,6 +230,27 @@ class HipDecoder:
             splits = 1
         return splits, waves
 
+    @staticmethod
+    def _parts_cfg(N: int, K: int) -> tuple[int, int]:
+        """(K splits, waves) of the split-K partial-slab GEMM for a [N, K] matrix: >= 256 workgroups, <= 8 k-tiles per wave
+        (all in flight at once: one HBM round trip), 4-16 waves (profiles/r02_draft_probe.txt)."""
+        groups, KT = N // 16, K // 32
+        S = 1
+        while groups * S < 256 and S < 8 and KT // (S * 2) >= 4:
+            S *= 2
+        while KT // S > 16 * 8 and S < 16:
+            S *= 2
+        per = -(-KT // S)
+        waves = 4
+        while waves < 16 and -(-per // waves) > 4:
+            waves *= 2
+        return S, waves
+
+    def parts_plan(self, T: int) -> bool:
+        """o_proj / down_proj as split-K partial slabs consumed by the next norm: single-rank models with < 256 row groups at
+        decode-sized T (the draft's chain / glue / tree forwards)."""
+        return self.use_parts and not self.use_coll and T <= 32
+
     # ---- the four GEMM launches of a layer (also used one by one by bench.py's roofline timing) ----
     def fusion_plan(self, T: int) -> tuple[bool, bool]:
         """(small, norm_fuse).  T <= 16: RoPE + KV store ride the QKV epilogue (csrc/gemm_fused.hip).  The residual
@@ -243,15 +272,21 @@ class HipDecoder:
         rope = dict(positions=positions, cos_sin=self.cos_sin, slots=slot_mapping, q_out=self.buf_q, k_cache=kc, v_cache=vc,
                     nh=self.nh, nkv=self.nkv, hd=self.hd, block_size=self.block_size)
         h, res, xf = self.buf_h, self.buf_res, self.buf_xf
+        parts = self.parts_plan(T) and li > 0          # the previous layer's down_proj left fp32 partial slabs, not rows
         if norm_fuse:
-            H.gemm_fused(w[p + "self_attn.qkv_proj.weight"], T, self.qkv_n, self.h, H.FEPI_QKV_ROPE, h_rows=h,
+            src = dict(h_parts=self.buf_parts_d, splits=self.parts_cfg_d[0]) if parts else dict(h_rows=h)
+            H.gemm_fused(w[p + "self_attn.qkv_proj.weight"], T, self.qkv_n, self.h, H.FEPI_QKV_ROPE,
                          res_in=None if li == 0 else res, res_out=self.buf_res2, norm_w=w[p + "input_layernorm.weight"],
-                         eps=cfg.rms_norm_eps, bias=w.get(p + "self_attn.qkv_proj.bias"), waves=16, **rope)
+                         eps=cfg.rms_norm_eps, bias=w.get(p + "self_attn.qkv_proj.bias"), waves=16, **src, **rope)
             return
         # residual is None on layer 0 (llama3.py:187-190): residual := embeddings, x := norm(embeddings)
         if not gemm_only and not pre_normed:
-            H.rmsnorm(h, w[p + "input_layernorm.weight"], cfg.rms_norm_eps, T, self.h, res_in=None if li == 0 else res,
-                      res_out=res, out_frag=xf)
+            if parts:
+                H.rmsnorm_parts(self.buf_parts_d, self.parts_cfg_d[0], T, w[p + "input_layernorm.weight"], cfg.rms_norm_eps, T, self.h,
+                                res_in=res, res_out=res, out_frag=xf)
+            else:
+                H.rmsnorm(h, w[p + "input_layernorm.weight"], cfg.rms_norm_eps, T, self.h, res_in=None if li == 0 else res,
+                          res_out=res, out_frag=xf)
         if small:
             H.gemm_fused(w[p + "self_attn.qkv_proj.weight"], T, self.qkv_n, self.h, H.FEPI_QKV_ROPE, x_frag=xf,
                          bias=w.get(p + "self_attn.qkv_proj.bias"), **rope)
@@ -265,24 +300,38 @@ class HipDecoder:
                             k_norm_w=w.get(p + "self_attn.k_norm.weight"), eps=cfg.rms_norm_eps, qkv_perm=1)
 
     def launch_o(self, li: int, T: int) -> None:
-        self._gemm(self.buf_af, self.qn, self.w[f"model.layers.{li}.self_attn.o_proj.weight"], self.h, self.buf_h, T, self.h)
+        w = self.w[f"model.layers.{li}.self_attn.o_proj.weight"]
+        if self.parts_plan(T):
+            H.gemm_parts(self.buf_af, w, T, self.h, self.qn, parts=self.buf_parts_o, splits=self.parts_cfg_o[0], waves=self.parts_cfg_o[1])
+        else:
+            self._gemm(self.buf_af, self.qn, w, self.h, self.buf_h, T, self.h)
 
     def launch_gate_up(self, li: int, T: int, gemm_only: bool = False, pre_normed: bool = False) -> None:
         cfg, w = self.cfg, self.w
         p = f"model.layers.{li}."
         _, norm_fuse = self.fusion_plan(T)
+        parts = self.parts_plan(T)                     # o_proj left fp32 partial slabs
         if norm_fuse:
-            H.gemm_fused(w[p + "mlp.gate_up_proj.weight"], T, 2 * self.I, self.h, H.FEPI_SILU_FRAG, h_rows=self.buf_h,
+            src = dict(h_parts=self.buf_parts_o, splits=self.parts_cfg_o[0]) if parts else dict(h_rows=self.buf_h)
+            H.gemm_fused(w[p + "mlp.gate_up_proj.weight"], T, 2 * self.I, self.h, H.FEPI_SILU_FRAG,
                          res_in=self.buf_res2, res_out=self.buf_res, norm_w=w[p + "post_attention_layernorm.weight"],
-                         eps=cfg.rms_norm_eps, y=self.buf_actf, waves=8)     # profiles/micro/fused_probe.py: 13.2 us vs 16.4 (16 waves)
+                         eps=cfg.rms_norm_eps, y=self.buf_actf, waves=8, **src)     # profiles/micro/fused_probe.py: 13.2 us vs 16.4 (16 waves)
         else:
             if not gemm_only and not pre_normed:
-                H.rmsnorm(self.buf_h, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps, T, self.h,
-                          res_in=self.buf_res, res_out=self.buf_res, out_frag=self.buf_xf)
+                if parts:
+                    H.rmsnorm_parts(self.buf_parts_o, self.parts_cfg_o[0], T, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps,
+                                    T, self.h, res_in=self.buf_res, res_out=self.buf_res, out_frag=self.buf_xf)
+                else:
+                    H.rmsnorm(self.buf_h, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps, T, self.h,
+                              res_in=self.buf_res, res_out=self.buf_res, out_frag=self.buf_xf)
             self._gemm(self.buf_xf, self.h, w[p + "mlp.gate_up_proj.weight"], 2 * self.I, self.buf_actf, T, 0, epi=H.EPI_SILU_FRAG)
 
     def launch_down(self, li: int, T: int) -> None:
-        self._gemm(self.buf_actf, self.I, self.w[f"model.layers.{li}.mlp.down_proj.weight"], self.h, self.buf_h, T, self.h)
+        w = self.w[f"model.layers.{li}.mlp.down_proj.weight"]
+        if self.parts_plan(T):
+            H.gemm_parts(self.buf_actf, w, T, self.h, self.I, parts=self.buf_parts_d, splits=self.parts_cfg_d[0], waves=self.parts_cfg_d[1])
+        else:
+            self._gemm(self.buf_actf, self.I, w, self.h, self.buf_h, T, self.h)
 
     def forward(self, input_ids: torch.Tensor, positions: torch.Tensor, T: int, meta: AttnMeta) -> None:
         """Runs all layers; leaves the final (pre-norm) hidden state in buf_h and the residual in buf_res."""
@@ -293,6 +342,7 @@ class HipDecoder:
         self._allreduce(h[:T])
         splits, attn_waves = self._attn_cfg(T, meta)
         scale = self.hd ** -0.5
+        self._fwd_T = T          # compute_logits must know whether the last down_proj left rows or partial slabs
         # tensor parallel with the one-shot collective: the all-reduce after o_proj / down_proj absorbs the residual add
         # and the RMSNorm that follow it (csrc/comm.hip), 2 launches fewer per half layer
         ar = self.custom_ar
@@ -323,8 +373,13 @@ class HipDecoder:
         LM-head GEMM into self.logits[:rows] (this rank's vocab shard).  Returns the number of logit rows."""
         n = T if gather is None else rows
         assert n <= self.max_logit_rows
-        H.rmsnorm(self.buf_h, self.w["model.norm.weight"], self.cfg.rms_norm_eps, n, self.h, res_in=self.buf_res,
-                  out_frag=self.buf_lastf, gather=gather)
+        if self.parts_plan(getattr(self, "_fwd_T", 1 << 30)):
+            assert gather is None and n == self._fwd_T
+            H.rmsnorm_parts(self.buf_parts_d, self.parts_cfg_d[0], n, self.w["model.norm.weight"], self.cfg.rms_norm_eps, n, self.h,
+                            res_in=self.buf_res, out_frag=self.buf_lastf)
+        else:
+            H.rmsnorm(self.buf_h, self.w["model.norm.weight"], self.cfg.rms_norm_eps, n, self.h, res_in=self.buf_res,
+                      out_frag=self.buf_lastf, gather=gather)
         self._gemm(self.buf_lastf, self.h, self.w["lm_head.weight"], self.V, self.logits, n, self.V)
         return n
 

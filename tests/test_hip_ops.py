@@ -511,3 +511,108 @@ def test_attn_multiwave_inblock_merge(H, waves):
     got = run_attn(H, q.view(MQ, -1), kc, vc, bt, mb, ctx, nh, nkv, hd, bs, q_per_seq=MQ, splits=1, waves=waves,
                    mode=H.MODE_TREE, tree_K=K, tree_mq=MQ, tree_step=3, tree_F=F)
     assert_close_bf16(got, ref, what="tree multiwave", **ATTN_TOL)
+
+
+# ------------------------------------------------------------------------------------------------
+# split-K partial slabs (csrc/gemm_sk.hip gemm_sp_kernel) and their consumers
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(1, 2048, 2048), (1, 2048, 8192), (7, 1024, 3072), (24, 2048, 2048), (24, 2048, 8192),
+                                   (16, 256, 256), (3, 80, 96), (32, 512, 1024)])
+def test_gemm_parts_vs_oracle(H, M, N, K):
+    """y = x . W^T as `splits` fp32 partial slabs: their in-order sum, rounded once to bf16, is the F.linear result up to
+    the accumulation order; every (splits, waves) decomposition is deterministic; splits = 1 can write bf16 rows directly."""
+    torch.manual_seed(M + N + K)
+    x = torch.randn(M, K).to(BF)
+    w = (torch.randn(N, K) * 0.05).to(BF)
+    b = torch.randn(N).to(BF)
+    w[3, :] = 0.5
+    x[M - 1, : K // 2] = -1.0
+    ref = O.linear(x, w)
+    xf, wf = to_frag_dev(x), to_frag_dev(w)
+    KT = K // 32
+    tried = 0
+    for splits in (1, 2, 3, 4, 8):
+        for waves in (2, 4, 8, 16):
+            per = -(-KT // splits)
+            if KT < splits or -(-per // waves) > 8:
+                continue
+            tried += 1
+            outs = []
+            for _ in range(2):
+                parts = torch.full((splits, M, N), float("nan"), dtype=torch.float32, device="cuda")
+                H.gemm_parts(xf, wf, M, N, K, parts=parts, splits=splits, waves=waves)
+                outs.append(parts)
+            assert torch.equal(outs[0], outs[1]), "partial slabs are not deterministic"
+            acc = outs[0][0].clone()
+            for z in range(1, splits):
+                acc += outs[0][z]
+            assert_close_bf16(acc.to(BF), ref, max_ulp=1, max_frac=0.03, rel_floor=2 ** -7, what=f"gemm_parts S{splits} w{waves}")
+            if splits == 1:
+                y = torch.full((M, N), float("nan"), dtype=BF, device="cuda")
+                H.gemm_parts(xf, wf, M, N, K, y=y, ldy=N, splits=1, waves=waves, bias=dev(b))
+                want = (outs[0][0] + dev(b).float()).to(BF)
+                assert torch.equal(y.view(torch.int16), want.view(torch.int16))
+    assert tried >= 3
+
+
+@pytest.mark.parametrize("T,Hd,S", [(1, 2048, 2), (7, 1024, 4), (24, 2048, 2), (5, 256, 8)])
+def test_rmsnorm_parts_equals_rmsnorm_of_the_rounded_sum(H, T, Hd, S):
+    torch.manual_seed(T + Hd)
+    parts = torch.randn(S, T + 3, Hd, device="cuda")            # slab_rows > T: extra rows are ignored
+    res = torch.randn(T, Hd).to(BF).cuda()
+    w = (1 + 0.1 * torch.randn(Hd)).to(BF).cuda()
+    acc = parts[0].clone()
+    for z in range(1, S):
+        acc += parts[z]
+    x = acc[:T].to(BF).contiguous()
+    want = [torch.zeros(T, Hd, dtype=BF, device="cuda") for _ in range(2)] + [torch.zeros(H.frag_numel(T, Hd), dtype=BF, device="cuda")]
+    got = [torch.zeros_like(t) for t in want]
+    H.rmsnorm(x, w, 1e-5, T, Hd, res_in=res, res_out=want[0], out_rows=want[1], out_frag=want[2])
+    H.rmsnorm_parts(parts, S, T + 3, w, 1e-5, T, Hd, res_in=res, res_out=got[0], out_rows=got[1], out_frag=got[2])
+    for a, b_ in zip(got, want):
+        assert torch.equal(a.view(torch.int16), b_.view(torch.int16))
+
+
+@pytest.mark.parametrize("M,K,S", [(1, 2048, 2), (4, 2048, 4), (7, 4096, 2), (16, 512, 3)])
+def test_fused_gemm_with_partial_slab_prologue(H, M, K, S):
+    """The fused norm + GEMM kernels fed by partial slabs must equal the same kernels fed the bf16 rounding of the slab sum
+    bit for bit (QKV + RoPE + KV store, and gate_up + SiLU)."""
+    torch.manual_seed(M * K + S)
+    nh, nkv, hd, bs, nb = 8, 2, 64, 16, 8
+    N = (nh + 2 * nkv) * hd
+    parts = (torch.randn(S, M, K, device="cuda") * 0.7)
+    acc = parts[0].clone()
+    for z in range(1, S):
+        acc += parts[z]
+    h = acc.to(BF).contiguous()
+    res = torch.randn(M, K).to(BF).cuda()
+    nw = (1 + 0.1 * torch.randn(K)).to(BF).cuda()
+    w = (torch.randn(N, K) * 0.05).to(BF).cuda()
+    wf = torch.zeros(w.numel(), dtype=BF, device="cuda")
+    H.rows_to_frag_qkv(w, wf, nh, nkv, hd, K)
+    pos = torch.randint(0, 300, (M,), dtype=torch.int64).cuda()
+    slots = torch.randperm(nb * bs)[:M].to(torch.int32).cuda()
+    cache = O.make_cos_sin_cache(hd, 512, 5e5).cuda()
+    outs = []
+    for src in (dict(h_rows=h), dict(h_parts=parts, splits=S)):
+        q_out = torch.zeros(M, nh * hd, dtype=BF, device="cuda")
+        kc = torch.zeros(nb, nkv, bs, hd, dtype=BF, device="cuda")
+        vc = torch.zeros_like(kc)
+        res_out = torch.zeros(M, K, dtype=BF, device="cuda")
+        H.gemm_fused(wf, M, N, K, H.FEPI_QKV_ROPE, res_in=res, res_out=res_out, norm_w=nw, eps=1e-5, positions=pos, cos_sin=cache,
+                     slots=slots, q_out=q_out, k_cache=kc, v_cache=vc, nh=nh, nkv=nkv, hd=hd, block_size=bs, **src)
+        outs.append((q_out, kc, vc, res_out))
+    for a, b_ in zip(*outs):
+        assert torch.equal(a.view(torch.int16), b_.view(torch.int16))
+    I = 256
+    wg = (torch.randn(2 * I, K) * 0.06).to(BF).cuda()
+    wgf = torch.zeros(wg.numel(), dtype=BF, device="cuda")
+    H.rows_to_frag(wg, wgf, 2 * I, K, mode=1)
+    outs = []
+    for src in (dict(h_rows=h), dict(h_parts=parts, splits=S)):
+        act = torch.zeros(H.frag_numel(M, I), dtype=BF, device="cuda")
+        res_out = torch.zeros(M, K, dtype=BF, device="cuda")
+        H.gemm_fused(wgf, M, 2 * I, K, H.FEPI_SILU_FRAG, res_in=res, res_out=res_out, norm_w=nw, eps=1e-5, y=act, **src)
+        outs.append((act, res_out))
+    for a, b_ in zip(*outs):
+        assert torch.equal(a.view(torch.int16), b_.view(torch.int16))
