@@ -51,6 +51,10 @@ class Config:
     fan_out_list_miss: list[int] | None = None
     sampler_x: float | None = None
     jit_speculate: bool = False
+    # draft data-parallelism (BASELINE.json configs[4]; on the reference's roadmap only, README.md:129-130): the last
+    # num_draft_gpus ranks form a draft group; every member keeps the trunk KV and the glue forward, the MQ_LEN tree
+    # branches and the speculation cache are sharded over the members (engine/draft_runner.py)
+    num_draft_gpus: int = 1
 
     # EAGLE-3 (out of scope: no BASELINE config uses it; accepted so reference kwargs do not break)
     use_eagle: bool = False
@@ -79,6 +83,8 @@ class Config:
 
     def __post_init__(self):
         assert 1 <= self.num_gpus <= 8, "single node only (reference ssd/config.py:55)"
+        assert self.num_draft_gpus >= 1 and (self.num_draft_gpus == 1 or (self.speculate and self.draft_async)), \
+            "num_draft_gpus > 1 needs draft_async"
         assert not self.use_eagle, "EAGLE-3 drafts are out of scope for this engine (SURVEY.md section 2, row 19)"
         if self.hf_config is None:
             self.hf_config = resolve_model_config(self.model)

@@ -28,14 +28,54 @@ def branch_positions(fan_out: list[int]) -> list[int]:
     return [j for j, f in enumerate(fan_out) for _ in range(f)]
 
 
+class DraftGroup:
+    """Draft data-parallelism (BASELINE.json configs[4]: "draft x4 data-parallel"; the reference has it on its roadmap
+    only, README.md:129-130).  The D draft ranks all keep the trunk KV (prefill + glue are replicated: one K+1-token
+    forward), but the MQ_LEN branches of the speculation tree -- K forwards of MQ_LEN rows, the bulk of a round -- and
+    the speculation cache built from them are SHARDED: member d owns a contiguous slice of the branches.  Only the
+    leader (member 0) talks to the target; per request it broadcasts the payload to the group, every member looks the
+    key up in its own cache shard, the members all-gather (hit, tokens) -- a few dozen int64 -- and the owner's answer
+    goes back through the leader.  Every member then knows the answered tokens, which seed the next round's glue."""
+
+    def __init__(self, group, dp_rank: int, dp_size: int, device):
+        import torch.distributed as dist
+        self.group, self.rank, self.size = group, dp_rank, dp_size
+        self.wire = torch.device("cpu") if dist.get_backend(group) == "gloo" else device
+        self.leader = dist.get_global_rank(group, 0)
+        self.dist = dist
+
+    def bcast_ints(self, values, n: int) -> list[int]:
+        t = torch.tensor(values if self.rank == 0 else [0] * n, dtype=torch.int64).to(self.wire)
+        self.dist.broadcast(t, src=self.leader, group=self.group)
+        return t.tolist()
+
+    def allgather_ints(self, values: list[int]) -> list[list[int]]:
+        t = torch.tensor(values, dtype=torch.int64).to(self.wire)
+        out = [torch.empty_like(t) for _ in range(self.size)]
+        self.dist.all_gather(out, t, group=self.group)
+        return [o.tolist() for o in out]
+
+    def bcast_tensor(self, t: torch.Tensor, src_member: int) -> torch.Tensor:
+        dev = t.device
+        w = t.to(self.wire).contiguous()
+        self.dist.broadcast(w, src=self.dist.get_global_rank(self.group, src_member), group=self.group)
+        return w.to(dev)
+
+    def shard(self, n: int) -> tuple[int, int]:
+        """Contiguous slice [lo, hi) of n branches owned by this member."""
+        per = -(-n // self.size)
+        return min(n, self.rank * per), min(n, (self.rank + 1) * per)
+
+
 class DraftServer:
-    def __init__(self, config, runner, transport, stream=None, deferred: bool = False):
+    def __init__(self, config, runner, transport, stream=None, deferred: bool = False, dp: DraftGroup | None = None):
         """stream / deferred: co-located mode (the server shares the target's process and GPU).  All draft work is
         issued on `stream` so that it overlaps the target's verify on the device, and the work that follows the reply
         (glue + fork + tree decode) is parked until the target has launched its verify (`run_deferred`, called from
         ModelRunner.verify_chain just before it blocks), instead of delaying that launch."""
         self.config, self.runner, self.tx = config, runner, transport
         self.stream, self.deferred = stream, deferred
+        self.dp = dp                        # draft data-parallel group (None: a single draft GPU); transport is None off the leader
         self._parked = None
         self.K = config.speculate_k
         self.mq = config.MQ_LEN
@@ -66,13 +106,24 @@ class DraftServer:
         return self._on_stream(self._handle_one)
 
     def _handle_one(self) -> bool:
-        cmd, B, n, flags = self.tx.recv_ints(P.HEADER_LEN)
+        dp = self.dp
+        lead = dp is None or dp.rank == 0
+        hdr = self.tx.recv_ints(P.HEADER_LEN) if lead else None
+        if dp is not None:
+            hdr = dp.bcast_ints(hdr, P.HEADER_LEN)
+        cmd, B, n, flags = hdr
         if cmd == P.CMD_EXIT:
             return False
         if cmd == P.CMD_HELLO:
-            self.tx.send_ints([self.runner.num_kvcache_blocks])
+            blocks = self.runner.num_kvcache_blocks
+            if dp is not None:          # every member allocates its own cache: the scheduler may use what the smallest has
+                blocks = min(v[0] for v in dp.allgather_ints([blocks]))
+            if lead:
+                self.tx.send_ints([blocks])
             return True
-        payload = self.tx.recv_ints(n) if n else []
+        payload = (self.tx.recv_ints(n) if n else []) if lead else None
+        if dp is not None and n:
+            payload = dp.bcast_ints(payload, n)
         if cmd == P.CMD_PREFILL:
             toks, tables = P.unpack_prefill(payload, B, self.max_blocks)
             self.runner.draft_prefill(toks, tables)
@@ -94,53 +145,94 @@ class DraftServer:
         forks = self.pending_forks.tolist()         # the only device read of a round, after all its work is queued
         seq_ids, jlists = self.pending_meta
         self.cache_keys = {}
+        width = self.pending_forks.shape[1]          # MQ_LEN, or this member's slice of it under draft data-parallelism
         for b, row in enumerate(forks):
             for i, tok in enumerate(row):
-                self.cache_keys.setdefault((seq_ids[b], jlists[b][i], tok), b * self.mq + i)
+                self.cache_keys.setdefault((seq_ids[b], jlists[b][i], tok), b * width + i)
         self.pending_forks = None
 
     def _speculate(self, B: int, payload: list[int], flags: int) -> None:
         K = self.K
+        dp = self.dp
+        lead = dp is None or dp.rank == 0
         keys, num_tokens, tables, temps = P.unpack_speculate(payload, B, self.max_blocks)
         want_logits = bool(flags & P.FLAG_WANT_LOGITS)
         sample = any(t > 0 for t in temps)
         self._mirror_keys()
-        idx = [self.cache_keys.get(tuple(k), -1) for k in keys]
+        idx = [self.cache_keys.get(tuple(k), -1) for k in keys]         # rows of MY cache shard
         hits = [1 if i >= 0 else 0 for i in idx]
+        owner = [0 if h else -1 for h in hits]                           # group member that holds each row's branch
+        if dp is not None:
+            # (hit, K tokens) per sequence from every member: the first member with a hit owns the row (keys are unique
+            # across shards -- top-F picks distinct tokens per position -- so there is at most one)
+            mine = []
+            rows = self.cache_tokens[torch.tensor([i if i >= 0 else 0 for i in idx], dtype=torch.int64, device=self.cache_tokens.device)].tolist() \
+                if (self.cache_tokens is not None and any(hits)) else [[0] * K] * B
+            for b in range(B):
+                mine.extend([hits[b]] + (list(rows[b]) if hits[b] else [0] * K))
+            everyone = dp.allgather_ints(mine)
+            owner, merged = [], []
+            for b in range(B):
+                o = next((d for d in range(dp.size) if everyone[d][b * (K + 1)] == 1), -1)
+                owner.append(o)
+                merged.append(everyone[o][b * (K + 1) + 1:(b + 1) * (K + 1)] if o >= 0 else [0] * K)
+            hits = [1 if o >= 0 else 0 for o in owner]
         self.stats["requests"] += B
         self.stats["hits"] += sum(hits)
         rec = [k[2] for k in keys]
         logits_q = None
         jit = self.config.jit_speculate
         serve_from_cache = (any(hits) and not jit) or (all(hits) and jit)
+        dev = self.runner.zeros_tokens(1, 1).device
         if serve_from_cache:
-            rows = torch.tensor([i if i >= 0 else 0 for i in idx], dtype=torch.int64, device=self.cache_tokens.device)
-            tokens = self.cache_tokens[rows]
-            if not all(hits):       # "fast" backup: miss rows carry filler tokens (the reference uses random ones)
-                tokens = tokens * torch.tensor(hits, dtype=torch.int64, device=tokens.device).unsqueeze(1)
-            if want_logits and self.cache_logits is not None:
-                logits_q = self.cache_logits[rows]          # [B, K, V]: the q the hit branch was sampled from
+            if dp is None:
+                rows = torch.tensor([i if i >= 0 else 0 for i in idx], dtype=torch.int64, device=self.cache_tokens.device)
+                tokens = self.cache_tokens[rows]
+                if not all(hits):       # "fast" backup: miss rows carry filler tokens (the reference uses random ones)
+                    tokens = tokens * torch.tensor(hits, dtype=torch.int64, device=tokens.device).unsqueeze(1)
+                if want_logits and self.cache_logits is not None:
+                    logits_q = self.cache_logits[rows]          # [B, K, V]: the q the hit branch was sampled from
+            else:
+                tokens = torch.tensor(merged, dtype=torch.int64, device=dev)
+                if want_logits and sample:      # the owner's branch logits travel to the leader (and on to the target)
+                    V = self.runner.cfg.vocab_size
+                    logits_q = torch.zeros(B, K, V, dtype=torch.bfloat16, device=dev)
+                    for b in range(B):
+                        if owner[b] < 0:
+                            continue
+                        src = self.cache_logits[idx[b]] if (owner[b] == dp.rank and self.cache_logits is not None) else logits_q[b]
+                        logits_q[b] = dp.bcast_tensor(src.contiguous(), owner[b])
         elif jit:
-            tokens = self.runner.draft_jit(rec, num_tokens, tables, temps)  # [B, K] on the draft device
-            if want_logits and sample:
-                logits_q = self.runner.logits_q(B)
+            if lead:
+                tokens = self.runner.draft_jit(rec, num_tokens, tables, temps)  # [B, K] on the draft device
+                if want_logits and sample:
+                    logits_q = self.runner.logits_q(B)
+            else:
+                tokens = self.runner.zeros_tokens(B, K)
+            if dp is not None:          # the chain ran on the leader only; its tokens seed every member's glue
+                tokens = dp.bcast_tensor(tokens, 0)
         else:
             tokens = self.runner.zeros_tokens(B, K)
-        resp = torch.cat([torch.tensor(hits, dtype=torch.int64, device=tokens.device), tokens.reshape(-1)])
-        self.tx.send_tensor(resp)
-        if want_logits:
-            # rows that are neither hits nor JIT-drafted never take the ratio path (verify.py:57-62): zeros will do
-            if logits_q is None:
-                logits_q = torch.zeros(B, K, self.runner.cfg.vocab_size, dtype=torch.bfloat16, device=tokens.device)
-            self.tx.send_tensor(logits_q)
+        if lead:
+            resp = torch.cat([torch.tensor(hits, dtype=torch.int64, device=tokens.device), tokens.reshape(-1)])
+            self.tx.send_tensor(resp)
+            if want_logits:
+                # rows that are neither hits nor JIT-drafted never take the ratio path (verify.py:57-62): zeros will do
+                if logits_q is None:
+                    logits_q = torch.zeros(B, K, self.runner.cfg.vocab_size, dtype=torch.bfloat16, device=tokens.device)
+                self.tx.send_tensor(logits_q)
         # ---- from here on the target is verifying; pre-compute the next round's cache ----
         def next_round():
             fan = [self.config.fan_out_list if h else self.config.fan_out_list_miss for h in hits]
             jl = [self.j_hit if h else self.j_miss for h in hits]
             glue_ids = torch.cat([torch.tensor(rec, dtype=torch.int64, device=tokens.device).unsqueeze(1), tokens], dim=1)
-            forks = self.runner.draft_glue_fork(glue_ids, num_tokens, tables, fan)          # [B, MQ]
-            self.cache_tokens = self.runner.draft_tree(forks, num_tokens, tables, jl, temps)  # [B*MQ, K]
-            self.cache_logits = self.runner.tree_logits(B * self.mq) if sample else None
+            forks = self.runner.draft_glue_fork(glue_ids, num_tokens, tables, fan)          # [B, MQ] (replicated under DP)
+            if dp is not None:          # my slice of the branches: K tree steps of MQ/D rows instead of MQ
+                lo, hi = dp.shard(self.mq)
+                forks = forks[:, lo:hi].contiguous()
+                jl = [j[lo:hi] for j in jl]
+            self.cache_tokens = self.runner.draft_tree(forks, num_tokens, tables, jl, temps)  # [B*mq', K]
+            self.cache_logits = self.runner.tree_logits(forks.numel()) if sample else None
             self.pending_forks = forks
             self.pending_meta = ([k[0] for k in keys], jl)
             self.stats["rounds"] += 1

@@ -98,7 +98,12 @@ class LLMEngine:
             from ssd_amd.engine.async_proto import DistTransport
             runner = factory(config, config.draft_hf_config, is_draft=True, topo=self.topo, memory_utilization=0.8,
                              num_kvcache_blocks=config.num_draft_kvcache_blocks)
-            self.draft_server = DraftServer(config, runner, DistTransport(self.topo.async_group, 0, self.topo.device))
+            dp = None
+            if self.topo.dp_size > 1:
+                from ssd_amd.engine.draft_runner import DraftGroup
+                dp = DraftGroup(self.topo.draft_group, self.topo.dp_rank, self.topo.dp_size, self.topo.device)
+            tx = DistTransport(self.topo.async_group, 0, self.topo.device) if self.topo.dp_rank == 0 else None
+            self.draft_server = DraftServer(config, runner, tx, dp=dp)
             return
         self.model_runner = factory(config, config.hf_config, is_draft=False, topo=self.topo,
                                     num_kvcache_blocks=config.num_kvcache_blocks)

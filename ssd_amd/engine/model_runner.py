@@ -601,6 +601,7 @@ class ModelRunner:
         self.d_fan_off = torch.zeros(B, K + 1, dtype=torch.int32, **dev)
         self.d_forks = torch.zeros(B, self.mq, dtype=torch.int64, **dev)
         self.d_jidx = torch.zeros(B, self.mq, dtype=torch.int32, **dev)
+        self.d_jidx_flat = self.d_jidx.view(-1)      # packed [B][tree width] (the width may be a slice of MQ_LEN)
         self.d_tree_pos = torch.zeros(K, T, dtype=torch.int64, **dev)
         self.d_tree_slots = torch.zeros(K, T, dtype=torch.int32, **dev)
         self.d_tree_ctx = torch.zeros(K, B, dtype=torch.int32, **dev)
@@ -638,10 +639,11 @@ class ModelRunner:
             self.graphs[(*key, self._ctx_hint)].replay()
         return self.d_forks[:B].clone()
 
-    def _body_tree(self, B: int, d: int, sample: bool = False) -> None:
-        T = B * self.mq
-        meta = AttnMeta(H.MODE_TREE, B, self.mq, self.d_tree_slots[d], self.d_tree_ctx[d], self.d_bt, q_per_seq=self.mq,
-                        tree_K=self.K, tree_mq=self.mq, tree_step=d, tree_F=1, tree_jidx=self.d_jidx,
+    def _body_tree(self, B: int, d: int, sample: bool = False, mq: int | None = None) -> None:
+        mq = mq or self.mq          # tree width: MQ_LEN, or one member's slice of it under draft data-parallelism
+        T = B * mq
+        meta = AttnMeta(H.MODE_TREE, B, mq, self.d_tree_slots[d], self.d_tree_ctx[d], self.d_bt, q_per_seq=mq,
+                        tree_K=self.K, tree_mq=mq, tree_step=d, tree_F=1, tree_jidx=self.d_jidx,
                         ctx_hint=self._ctx_hint)
         self.model.forward(self.d_ids, self.d_tree_pos[d], T, meta)
         self.model.compute_logits(T)
@@ -651,10 +653,10 @@ class ModelRunner:
             H.store_step_rows(lg, V, self.d_tree_logits, T, V, self.K, self.d_steps_const[d:])
             if self.sx is not None:          # Sampler(is_tree=True) with sampler_x (sampler.py:29-31)
                 H.topk_rows(lg, V, T, V, self.sx_k, self.d_boost)
-                H.sample_rows(lg, V, T, V, self.d_temps, self.mq, self.d_rng, 4, self.d_next, boost_idx=self.d_boost,
+                H.sample_rows(lg, V, T, V, self.d_temps, mq, self.d_rng, 4, self.d_next, boost_idx=self.d_boost,
                               boost_k=self.sx_k, boost_x=self.sx)
             else:
-                H.sample_rows(lg, V, T, V, self.d_temps, self.mq, self.d_rng, 4, self.d_next)
+                H.sample_rows(lg, V, T, V, self.d_temps, mq, self.d_rng, 4, self.d_next)
             H.rng_advance(self.d_rng)
         else:
             self.model.argmax(T, self.d_next)
@@ -666,14 +668,15 @@ class ModelRunner:
         """K tree-decode steps with the structural branch mask; tokens (greedy, or sampled when some temperature is
         > 0) are chained on the device.  Returns tokens [B*MQ, K]; the branches' logits stay in `tree_logits`."""
         self._ensure_tree_buffers()
-        B, K, mq = forks.shape[0], self.K, self.mq
+        B, K, mq = forks.shape[0], self.K, forks.shape[1]      # mq < MQ_LEN: one member's branch slice (draft data-parallelism)
+        assert mq <= self.mq
         T = B * mq
         self._note_ctx(max(num_tokens) + self._async_lookahead())
         sample = temps is not None and any(t > 0 for t in temps)
         if sample:
             self._ensure_stochastic()
             if self.d_tree_logits is None:
-                self.d_tree_logits = torch.zeros(self.max_bs * mq, K, self.cfg.vocab_size, dtype=torch.bfloat16, device=self.device)
+                self.d_tree_logits = torch.zeros(self.max_bs * self.mq, K, self.cfg.vocab_size, dtype=torch.bfloat16, device=self.device)
 
         def stage():
             pos = [[0] * T for _ in range(K)]
@@ -691,7 +694,7 @@ class ModelRunner:
                 self._stage_row(self.d_tree_pos, d, pos[d], torch.int64)
                 self._stage_row(self.d_tree_slots, d, slots[d], torch.int32)
                 self._stage_row(self.d_tree_ctx, d, ctx[d], torch.int32)
-            self._upload(self.d_jidx, [list(j) for j in jlists], torch.int32)
+            self._upload(self.d_jidx_flat, [v for j in jlists for v in j], torch.int32)     # packed [B][mq]
             self._upload_tables(tables)
             self.d_ids[:T].copy_(forks.reshape(-1))
             if sample:
@@ -699,10 +702,10 @@ class ModelRunner:
 
         def all_steps():                 # the K tree steps in ONE hipGraph (each step has its own static metadata rows)
             for d in range(K):
-                self._body_tree(B, d, sample)
+                self._body_tree(B, d, sample, mq)
 
         stage()
-        key = ("tree_s" if sample else "tree", B)
+        key = ("tree_s" if sample else "tree", B, mq)
         if self._launch(key, all_steps) == "captured":
             self.d_ids[:T].copy_(forks.reshape(-1))      # the eager warm-up consumed the inputs
             self.graphs[(*key, self._ctx_hint)].replay()

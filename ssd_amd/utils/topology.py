@@ -26,6 +26,9 @@ class Topology:
     async_group: object = None   # [rank 0, draft rank]
     draft_rank: int = -1
     ctl_group: object = None     # gloo group of the target ranks: control messages of a single-process launch
+    draft_group: object = None   # draft data-parallel group (draft ranks only); dp_rank / dp_size = position in it
+    dp_rank: int = 0
+    dp_size: int = 1
 
     def single(self) -> "Topology":
         """Same device, no tensor parallelism (a sync-speculation draft is replicated on every rank)."""
@@ -68,12 +71,16 @@ def resolve_topology(config, colocated_draft: bool = False) -> Topology:
         return Topology(0, 1, device, "target", 0, 1)
     assert world == config.num_gpus, f"WORLD_SIZE={world} but num_gpus={config.num_gpus}"
     if config.speculate and config.draft_async and not colocated_draft:
-        tp = world - 1
+        D = getattr(config, "num_draft_gpus", 1)
+        tp = world - D
+        assert tp >= 1, f"num_gpus={world} leaves no target rank beside {D} draft ranks"
         tp_group = dist.new_group(list(range(tp)))
-        async_group = dist.new_group([0, tp])
+        async_group = dist.new_group([0, tp])                      # head <-> draft leader
         ctl = dist.new_group(list(range(tp)), backend="gloo")
-        if rank == tp:
-            return Topology(rank, world, device, "draft", 0, 1, None, async_group, tp)
+        draft_group = dist.new_group(list(range(tp, world))) if D > 1 else None
+        if rank >= tp:
+            return Topology(rank, world, device, "draft", 0, 1, None, async_group if rank == tp else None, tp,
+                            draft_group=draft_group, dp_rank=rank - tp, dp_size=D)
         return Topology(rank, world, device, "target", rank, tp, tp_group, async_group if rank == 0 else None, tp, ctl)
     tp_group = dist.new_group(list(range(world)))
     ctl = dist.new_group(list(range(world)), backend="gloo")

@@ -196,3 +196,67 @@ def test_correlated_pair_recipe_gives_partial_acceptance():
     lens = m["accepted_suffix_lens_with_recovery"]
     assert 1.5 < sum(lens) / len(lens) < 5.0, lens                  # neither ~1.0 (random pair) nor always K+1 (draft == target)
     assert 0.0 < sum(m2["cache_hits"]) / len(m2["cache_hits"]) <= 1.0
+
+
+def _worker_draft_dp(rank, world, port, q, temperature):
+    """1 target rank + (world - 1) draft ranks (draft data-parallel): branches and speculation cache sharded."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    torch.manual_seed(0)
+    from oracle.runner import oracle_runner_factory
+    from ssd_amd.engine.llm_engine import LLMEngine
+    from ssd_amd.sampling_params import SamplingParams
+    t, d = cfgs()
+    eng = LLMEngine("t", hf_config=t, runner_factory=oracle_runner_factory(), num_gpus=world, num_draft_gpus=world - 1, draft="d",
+                    draft_hf_config=t, draft_weights_seed=0, speculate=True, speculate_k=3, draft_async=True, async_fan_out=2,
+                    jit_speculate=True, max_num_seqs=2, **KW)
+    out, m = eng.generate(PROMPTS, SamplingParams(temperature=temperature, max_new_tokens=14, ignore_eos=True), use_tqdm=False)
+    stats = eng.draft_server.stats if eng.draft_server is not None else None
+    eng.exit()
+    q.put((rank, [o["token_ids"] for o in out], m["cache_hits"], m["accepted_suffix_lens_with_recovery"], stats))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_draft_dp(world, temperature=0.0):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 90) + world
+    ps = [ctx.Process(target=_worker_draft_dp, args=(r, world, port, q, temperature)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, toks, hits, lens, stats = q.get(timeout=300)
+        got[r] = (toks, hits, lens, stats)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return got
+
+
+def test_draft_data_parallel_shards_the_tree_and_stays_exact():
+    """BASELINE.json configs[4] shape (target + draft x D data-parallel) with D = 2 and D = 3 on gloo: same stream as
+    autoregressive decoding; with draft == target every request after the first hits -- whichever member owns the branch --
+    and everything is accepted, exactly like the single-draft run."""
+    ar, _, _ = run("ar", bs=2)
+    single, m1, _ = run("async", bs=2, same=True)
+    for world in (3, 4):
+        got = _run_draft_dp(world)
+        assert got[0][0] == ar == single
+        assert got[0][1] == m1["cache_hits"] and got[0][2] == m1["accepted_suffix_lens_with_recovery"]
+        rounds = [got[r][3]["rounds"] for r in range(1, world)]
+        hits = [got[r][3]["hits"] for r in range(1, world)]
+        assert len(set(rounds)) == 1 and len(set(hits)) == 1          # every member sees every request and the merged verdict
+        assert all(got[r][0] == [] for r in range(1, world))
+
+
+def test_draft_data_parallel_with_sampling():
+    """temperature > 0 through the draft group: the owner's branch logits reach the target via the leader; with
+    draft == target p == q so every drafted token is accepted."""
+    got = _run_draft_dp(3, temperature=0.8)
+    lens = got[0][2]
+    assert all(len(t) == 14 for t in got[0][0])
+    assert all(n == 4 for n in lens[:-2]), lens
