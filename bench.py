@@ -16,7 +16,9 @@ Workload (``--workload``):
        one 288 GB MI355X, so N = 1 is the same model) and the draft server shares TP rank 0's GPU on its own HIP stream,
        pre-computing the next round's speculation tree while the verify runs; ``dedicated`` (``--placement dedicated``,
        N - 1 a power of two) -- the draft has the last GPU to itself and talks to TP rank 0 over RCCL p2p (the
-       reference's 4 + 1 GPU layout is ``--gpus 5 --placement dedicated``).  Same total work at every N -> "strong".
+       reference's 4 + 1 GPU layout is ``--gpus 5 --placement dedicated``); ``--draft-dp D`` gives the draft D GPUs that
+       shard the speculation tree (``--gpus 8 --placement dedicated --draft-dp 4`` = BASELINE.json configs[4]'s layout).
+       Same total work at every N -> "strong".
   c3   the same pair, SYNCHRONOUS speculation k = 6 (BASELINE.json configs[2]); draft replicated on every rank.
   c2   Llama-3.1-8B target + 1B draft, sync k = 6 on one GPU (configs[1]).
   c5t  Qwen3-32B target + Qwen3-0.6B draft, async k = 7 f = 3 (configs[4] without the draft data-parallelism).
@@ -63,6 +65,7 @@ def parse(argv=None):
     ap.add_argument("--k", type=int, default=None, help="speculation length (default: 7 async, 6 sync)")
     ap.add_argument("--f", type=int, default=3, help="async fan-out")
     ap.add_argument("--placement", default="colocated", choices=["colocated", "dedicated"])
+    ap.add_argument("--draft-dp", type=int, default=1, help="dedicated placement: draft ranks (data-parallel tree shards)")
     ap.add_argument("--pair", default="correlated", choices=["correlated", "random"])
     ap.add_argument("--pair-snr", type=float, default=8.0)
     ap.add_argument("--input-len", type=int, default=128)
@@ -261,12 +264,14 @@ def main():
         dcfg = dataclasses.replace(dcfg, tie_word_embeddings=False)
         recipe = {"kind": "pair", "shared": min(dcfg.hidden_size, tcfg.hidden_size), "snr": args.pair_snr, "layer_gain": 0.005}
     dedicated = is_async and args.placement == "dedicated" and world > 1
-    tp = world - 1 if dedicated else world
+    ndraft = max(1, args.draft_dp) if dedicated else 1
+    tp = world - ndraft if dedicated else world
+    assert tp >= 1 and tp & (tp - 1) == 0, f"target tensor-parallel degree {tp} must be a power of two" 
     kw = dict(hf_config=tcfg, draft=dname, draft_hf_config=dcfg, speculate=True, speculate_k=K, num_gpus=args.gpus,
               max_num_seqs=1, max_model_len=max_len, max_num_batched_tokens=max_len, kvcache_block_size=256,
               num_kvcache_blocks=blocks, num_draft_kvcache_blocks=blocks, enforce_eager=args.eager, weights_recipe=recipe)
     if is_async:
-        kw.update(draft_async=True, async_fan_out=args.f, jit_speculate=True, inprocess_draft=not dedicated)
+        kw.update(draft_async=True, async_fan_out=args.f, jit_speculate=True, inprocess_draft=not dedicated, num_draft_gpus=ndraft)
     engine = LLMEngine(tname, **kw)
     if engine.is_draft_process:             # dedicated draft GPU: serve until the target says EXIT, then join the barrier
         engine.serve()
@@ -356,7 +361,7 @@ def main():
                    if recipe else "(independent N(0,0.02): acceptance ~0)"),
         "config": {"workload": f"{args.workload}: {tname} target TP={tp} + {dname} draft, {mode}, b=1, temp=0, "
                                f"input_len={args.input_len}, kv block 256, max_model_len {max_len}",
-                   "parallelism": f"tp{tp}" + ("+draft1" if dedicated else ""), "hipgraph": not args.eager, "pair": args.pair},
+                   "parallelism": f"tp{tp}" + (f"+draft{ndraft}" if dedicated else ""), "hipgraph": not args.eager, "pair": args.pair},
         "mean_accepted_len": round(tokens / max(1, len(lens)), 4),
         "cache_hit_rate": None if hit_rate is None else round(hit_rate, 4),
         "ttft_p50_ms": round(ttft_p50, 3),

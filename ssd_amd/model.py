@@ -97,6 +97,7 @@ class HipDecoder:
         # split-K partial slabs of o_proj / down_proj for models whose hidden size gives too few 16-row groups to fill
         # the chip (csrc/gemm_sk.hip gemm_sp_kernel): fp32 [S][T][h], summed by the consumer's prologue / ssd_rmsnorm_parts
         self.use_parts = os.environ.get("SSD_PARTS", "1") != "0" and (self.h // 16) < 256
+        self._in_prefill = False        # set by forward(): a varlen prefill never takes the slab path (its last-token gather reads rows)
         self.parts_cfg_o = self._parts_cfg(self.h, self.qn)
         self.parts_cfg_d = self._parts_cfg(self.h, self.I)
         pt = min(T, 32)
@@ -232,24 +233,26 @@ class HipDecoder:
 
     @staticmethod
     def _parts_cfg(N: int, K: int) -> tuple[int, int]:
-        """(K splits, waves) of the split-K partial-slab GEMM for a [N, K] matrix: >= 256 workgroups, <= 8 k-tiles per wave
-        (all in flight at once: one HBM round trip), 4-16 waves (profiles/r02_draft_probe.txt)."""
+        """(K splits, waves) of the split-K partial-slab GEMM for a [N, K] matrix (profiles/r02_draft_probe.txt, 1B shapes:
+        o_proj 4.5 -> 3.7 us at (4, 8), down_proj 10.0 -> 7.6 us at (4, 8); M = 24: 8.1 -> 4.2 and 16.7 -> 9.0): enough
+        workgroups to put >= 2 on every CU, <= 4 slabs (what the fused norm prologue sums), <= 8 k-tiles per wave so that
+        every wave has its whole share in flight at once."""
         groups, KT = N // 16, K // 32
         S = 1
-        while groups * S < 256 and S < 8 and KT // (S * 2) >= 4:
-            S *= 2
-        while KT // S > 16 * 8 and S < 16:
+        while groups * S < 512 and S < 4 and KT // (S * 2) >= 8:
             S *= 2
         per = -(-KT // S)
-        waves = 4
-        while waves < 16 and -(-per // waves) > 4:
+        waves = 8
+        while waves < 16 and -(-per // waves) > 8:
             waves *= 2
+        while waves > 2 and per // waves < 1:
+            waves //= 2
         return S, waves
 
     def parts_plan(self, T: int) -> bool:
         """o_proj / down_proj as split-K partial slabs consumed by the next norm: single-rank models with < 256 row groups at
         decode-sized T (the draft's chain / glue / tree forwards)."""
-        return self.use_parts and not self.use_coll and T <= 32
+        return self.use_parts and not self.use_coll and T <= 32 and not self._in_prefill
 
     # ---- the four GEMM launches of a layer (also used one by one by bench.py's roofline timing) ----
     def fusion_plan(self, T: int) -> tuple[bool, bool]:
@@ -343,6 +346,7 @@ class HipDecoder:
         splits, attn_waves = self._attn_cfg(T, meta)
         scale = self.hd ** -0.5
         self._fwd_T = T          # compute_logits must know whether the last down_proj left rows or partial slabs
+        self._in_prefill = meta.cu_q is not None
         # tensor parallel with the one-shot collective: the all-reduce after o_proj / down_proj absorbs the residual add
         # and the RMSNorm that follow it (csrc/comm.hip), 2 launches fewer per half layer
         ar = self.custom_ar

@@ -69,3 +69,8 @@ def test_bench_async_placements():
     assert d2["config"]["parallelism"] == "tp1+draft1"
     # same models, same greedy decision rule: placement must not change what gets accepted
     assert abs(a1["mean_accepted_len"] - d2["mean_accepted_len"]) < 1e-9, (a1["mean_accepted_len"], d2["mean_accepted_len"])
+    # draft data-parallelism: two draft ranks shard the speculation tree (HIP kernels on a 12-branch slice each)
+    d3 = bench("--gpus", "3", "--workload", "tiny-async", "--placement", "dedicated", "--draft-dp", "2", shared_gpu=True)
+    check(d3, 3)
+    assert d3["config"]["parallelism"] == "tp1+draft2"
+    assert abs(a1["mean_accepted_len"] - d3["mean_accepted_len"]) < 1e-9 and abs(a1["cache_hit_rate"] - d3["cache_hit_rate"]) < 1e-9

@@ -63,7 +63,8 @@ def assert_stream_matches(got, want, margins: dict, prompt_len: int, what: str =
     if n < len(want):
         m = margins.get(prompt_len + n)
         assert m is not None, f"{what}: diverged at token {n} and the reference recorded no margin there"
-        assert m < thr, f"{what}: diverged at token {n} although the reference margin there is {m:.4f} (>= {thr})"
+        # (bf16 logits: at magnitude 8-16 one ulp IS 0.0625, the smallest non-zero margin there -- inclusive bound)
+        assert m <= thr, f"{what}: diverged at token {n} although the reference margin there is {m:.4f} (> {thr})"
     return n
 
 
