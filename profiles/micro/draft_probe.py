@@ -67,7 +67,7 @@ def main():
                     row(f"{name} parts S={S} waves={waves} ({h // 16 * S} WGs, {-(-per // waves)} tiles/wave)", us, mb)
         if M <= 16:
             small, nf = m.fusion_plan(M)
-            print(f"fusion_plan: small={small} norm_fuse={nf}; parts_plan={m.parts_plan(M)} cfg_o={m.parts_cfg_o} cfg_d={m.parts_cfg_d}")
+            print(f"fusion_plan: small={small} norm_fuse={nf}; parts_plan={m.parts_plan(M)} cfg_o={m._parts('o', M)} cfg_d={m._parts('d', M)}")
             for use in (False, True):
                 m.use_parts = use
                 row(f"qkv launch_qkv(li>0) use_parts={use}", timed(lambda li: m.launch_qkv(max(li, 1), M, r.d_pos, r.d_slots, gemm_only=True), L), m.qkv_n * h * 2 / 1e6)
@@ -79,7 +79,7 @@ def main():
                     for nt in (2, 4):
                         us = timed(lambda li: H.gemm_fused(m.w[p(li) + "mlp.gate_up_proj.weight"], M, 2 * I, h, H.FEPI_SILU_FRAG, res_in=m.buf_res2,
                                                             res_out=m.buf_res, norm_w=m.w[p(li) + "post_attention_layernorm.weight"], eps=1e-5,
-                                                            y=m.buf_actf, h_parts=m.buf_parts_o, splits=m.parts_cfg_o[0], nt=nt, waves=waves), L)
+                                                            y=m.buf_actf, h_parts=m.buf_parts_o, splits=m._parts('o', M)[0], nt=nt, waves=waves), L)
                         row(f"gate_up fused parts nt={nt} waves={waves}", us, 2 * I * h * 2 / 1e6)
         # attention at two context lengths
         for ctx in (150, 640):
@@ -96,12 +96,12 @@ def main():
                 meta = AttnMeta(H.MODE_CAUSAL, 1, M, r.d_slots, r.d_ctx, r.d_bt, q_per_seq=M, ctx_hint=1024)
             splits, waves = m._attn_cfg(M, meta)
             scale = m.hd ** -0.5
-            for wv in sorted({waves, 4, 8}):
+            for wv, fl in [(w_, 0) for w_ in sorted({waves, 4, 8})] + ([(8, 4), (4, 4)] if M == 24 else []):
                 us = timed(lambda li: H.attn_paged(m.buf_q, m.kv_cache[li, 0], m.kv_cache[li, 1], meta.block_tables, m.max_blocks, meta.context_lens,
                                                    1, M, M, m.nh, m.nkv, m.hd, m.block_size, scale, q_per_seq=meta.q_per_seq, mode=meta.mode,
                                                    tree_K=meta.tree_K, tree_mq=meta.tree_mq, tree_step=0, tree_F=1, tree_jidx=meta.tree_jidx,
-                                                   splits=splits, ws_o=m.ws_o, ws_ml=m.ws_ml, out_frag=m.buf_af, waves=wv), L)
-                row(f"attention ctx={ctx} waves={wv}{' (default)' if wv == waves else ''}", us, 2 * ctx * m.nkv * m.hd * 2 / 1e6)
+                                                   splits=splits, flags=fl, ws_o=m.ws_o, ws_ml=m.ws_ml, out_frag=m.buf_af, waves=wv), L)
+                row(f"attention ctx={ctx} waves={wv}{' rt=1' if fl else ''}{' (default)' if wv == waves and not fl else ''}", us, 2 * ctx * m.nkv * m.hd * 2 / 1e6)
         # whole forward (all layers + head + argmax), slab path on / off
         r.d_ctx[:1].fill_(150)
         r._ctx_hint = 1024

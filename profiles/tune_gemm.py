@@ -18,8 +18,13 @@ SHAPES = {
     "70b_tp2": [(5120, 8192), (8192, 4096), (28672, 8192), (8192, 14336), (64128, 8192)],
     "70b_tp4": [(2560, 8192), (8192, 2048), (14336, 8192), (8192, 7168), (32064, 8192)],
     "70b_tp8": [(1280, 8192), (8192, 1024), (7168, 8192), (8192, 3584), (16032, 8192)],
+    # BASELINE.json configs[4]: Qwen3-32B (h 5120, I 25600, 64/8 heads x 128, V 151936) at TP 1 / 4, Qwen3-0.6B draft
+    "q32b_tp1": [(10240, 5120), (5120, 8192), (51200, 5120), (5120, 25600), (151936, 5120)],
+    "q32b_tp4": [(2560, 5120), (5120, 2048), (12800, 5120), (5120, 6400), (37984, 5120)],
+    "q06b": [(4096, 1024), (1024, 2048), (6144, 1024), (1024, 3072), (151936, 1024)],
 }
-MS = {"1b": [1, 24], "8b": [7], "70b_tp1": [7], "70b_tp2": [7], "70b_tp4": [7], "70b_tp8": [7]}
+MS = {"1b": [1, 24], "8b": [7], "70b_tp1": [7], "70b_tp2": [7], "70b_tp4": [7], "70b_tp8": [7], "q32b_tp1": [8], "q32b_tp4": [8],
+      "q06b": [1, 24]}
 TPWS = (1, 2, 3, 4, 7, 8)      # consecutive tiles per workgroup (persistent variant), encoded in bits 8.. of `waves`
 if len(sys.argv) > 1:
     SHAPES = {k: v for k, v in SHAPES.items() if k in sys.argv[1:]}
@@ -58,7 +63,8 @@ def main():
             ws = [torch.randn(N * K // 2, device="cuda", dtype=torch.float32).view(BF).view(-1)[:N * K].contiguous() for _ in range(copies)]
             for M in MS[fam]:
                 x = torch.randn(H.frag_numel(M, K), device="cuda").to(BF)
-                is_gu = (N, K) in [(16384, 2048), (28672, 4096), (57344, 8192), (28672, 8192), (14336, 8192), (7168, 8192)]
+                is_gu = (N, K) in [(16384, 2048), (28672, 4096), (57344, 8192), (28672, 8192), (14336, 8192), (7168, 8192),
+                                   (51200, 5120), (12800, 5120), (6144, 1024)]
                 epi = H.EPI_SILU_FRAG if is_gu else H.EPI_ROWS
                 y = torch.zeros(max(M, 16) * N, device="cuda", dtype=BF)
                 best = None

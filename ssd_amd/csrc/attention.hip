@@ -411,10 +411,10 @@ static int attn_launch_rt(const AttnParams& p, dim3 grid, int waves, hipStream_t
 // Row tiles per workgroup: two for prefill-sized query blocks (K/V bytes shared by 32 rows), one for the decode-side
 // shapes (more workgroups: the scan is bound by per-CU load bandwidth and latency, not by K/V bytes).
 template <int HD>
-static int attn_launch(const AttnParams& p, int B, int T, int max_q, int waves, hipStream_t st) {
+static int attn_launch(const AttnParams& p, int B, int T, int max_q, int waves, int force_rt1, hipStream_t st) {
   const int G = p.nh / p.nkv;
   const int row_tiles = (max_q * G + 15) / 16;
-  const int rt = row_tiles > 4 ? 2 : 1;
+  const int rt = (row_tiles > 4 && !force_rt1) ? 2 : 1;
   dim3 grid((row_tiles + rt - 1) / rt, B * p.nkv, p.splits);
   // one key tile in flight per wave (KT = 1): measured on MI355X, KT = 2/4 buy nothing -- with 8 waves per workgroup
   // the scan is bound by the handful of CUs it occupies, not by a single wave's load latency
@@ -455,5 +455,7 @@ extern "C" int ssd_attn_paged(const void* q_rows, const void* k_cache, const voi
   int waves = (flags >> 8) & 0xf;
   if (waves < 1) waves = 1;
   if (waves > 8) waves = 8;
-  return hd == 128 ? attn_launch<128>(p, B, T, max_q, waves, st) : attn_launch<64>(p, B, T, max_q, waves, st);
+  // flags bit 2: one 16-row tile per workgroup even for wider query blocks (twice the workgroups for the 24-branch tree)
+  const int rt1 = (flags >> 2) & 1;
+  return hd == 128 ? attn_launch<128>(p, B, T, max_q, waves, rt1, st) : attn_launch<64>(p, B, T, max_q, waves, rt1, st);
 }

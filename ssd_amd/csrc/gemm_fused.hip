@@ -23,9 +23,6 @@
 
 enum { FEPI_ROWS = 0, FEPI_SILU_FRAG = 1, FEPI_QKV_ROPE = 3 };
 
-constexpr int FUSED_MAXS_C = 4;   // fp32 partial slabs the norm prologue can sum (ssd_gemm_fused_parts: splits <= 4)
-constexpr int FUSED_MAXS = FUSED_MAXS_C;
-
 struct FusedParams {
   const u32x4_t* Wf;
   const u32x4_t* Xf;        // fragment-major x (when h == nullptr)
@@ -47,95 +44,50 @@ struct FusedParams {
   int M, N, K, ldy;
   int nh, nkv, hd, bs;
   int scratch_bytes;        // LDS bytes in front of the x^ image (split-K combine area, also the prologue scratch)
-  int nprod;                // XNORM: producer waves appended to the `waves` consumer waves (see the kernel); 0 otherwise
 };
 
 // 8-element chunks of (h + res) a thread may hold in registers during the prologue: template parameter MAXC (1 when M*K/8
 // fits the workgroup's threads -- the single-token draft decode -- which keeps the kernel clear of the 128-VGPR ceiling)
 
-// Raw operands of one 8-element chunk of (h, res): everything is ISSUED here and consumed later (fused_x32), so that the
-// caller can put its weight loads in flight in between.  h is either the producer's bf16 rows or <= 4 fp32 partial slabs
-// of a split-K producer (always four slab loads on a clamped slab index -- a branch around a load would drain vmcnt).
-template <bool PARTS>
-struct FusedRaw {
-  u32x4_t rv, hv;
-};
-template <>
-struct FusedRaw<true> {
-  u32x4_t rv;
-  f32x4_t lo[FUSED_MAXS_C], hi[FUSED_MAXS_C];
-};
-
-template <bool PARTS>
-__device__ __forceinline__ void fused_issue(const FusedParams& p, int mm, int k8, FusedRaw<PARTS>& r) {
-  // (no branch around the load -- hipcc would drain vmcnt there: a null residual reads h / the slab instead and is zeroed)
-  const bf16_t* rp = p.res_in ? p.res_in : (PARTS ? reinterpret_cast<const bf16_t*>(p.h_parts) : p.h);
-  r.rv = *reinterpret_cast<const u32x4_t*>(rp + (size_t)mm * p.K + k8 * 8);
-  if constexpr (PARTS) {
-#pragma unroll
-    for (int sidx = 0; sidx < FUSED_MAXS_C; ++sidx) {
-      const float* src = p.h_parts + ((size_t)min(sidx, p.S - 1) * p.M + mm) * p.K + k8 * 8;
-      r.lo[sidx] = *reinterpret_cast<const f32x4_t*>(src);
-      r.hi[sidx] = *reinterpret_cast<const f32x4_t*>(src + 4);
-    }
-  } else {
-    r.hv = *reinterpret_cast<const u32x4_t*>(p.h + (size_t)mm * p.K + k8 * 8);
-  }
-}
-
-// x32[0..7] = fp32(h) + fp32(res), where h = the bf16 rows, or the bf16 rounding of the slab sum (slab order: deterministic;
-// the rounding mirrors the bf16 store of the reference's F.linear).
-template <bool PARTS>
-__device__ __forceinline__ void fused_x32(const FusedParams& p, const FusedRaw<PARTS>& r, float (&x)[8]) {
+// x32[0..7] = fp32(h) + fp32(res) for chunk k8 of row mm, where h is either the producer's bf16 rows or the bf16 rounding
+// of the sum of its S fp32 partial slabs (summed in slab order: deterministic; the rounding mirrors the bf16 store of the
+// reference's F.linear).  All loads of a chunk are issued before any arithmetic.
+__device__ __forceinline__ void fused_load_x32(const FusedParams& p, int mm, int k8, float (&x)[8]) {
+  u32x4_t rv = {0u, 0u, 0u, 0u};
+  if (p.res_in) rv = *reinterpret_cast<const u32x4_t*>(p.res_in + (size_t)mm * p.K + k8 * 8);
   float hf[8];
-  const uint32_t keep = p.res_in ? 0xffffffffu : 0u;
-  if constexpr (PARTS) {
-    f32x4_t lo = r.lo[0], hi = r.hi[0];
-#pragma unroll
-    for (int sidx = 1; sidx < FUSED_MAXS_C; ++sidx)
-      if (sidx < p.S) { lo += r.lo[sidx]; hi += r.hi[sidx]; }
+  if (p.h_parts) {
+    f32x4_t lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+    for (int sidx = 0; sidx < p.S; ++sidx) {
+      const float* src = p.h_parts + ((size_t)sidx * p.M + mm) * p.K + k8 * 8;
+      lo += *reinterpret_cast<const f32x4_t*>(src);
+      hi += *reinterpret_cast<const f32x4_t*>(src + 4);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { hf[j] = round_bf(lo[j]); hf[4 + j] = round_bf(hi[j]); }
   } else {
+    const u32x4_t hv = *reinterpret_cast<const u32x4_t*>(p.h + (size_t)mm * p.K + k8 * 8);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { hf[2 * j] = bf2f(r.hv[j] & 0xffffu); hf[2 * j + 1] = bf2f(r.hv[j] >> 16); }
+    for (int j = 0; j < 4; ++j) { hf[2 * j] = bf2f(hv[j] & 0xffffu); hf[2 * j + 1] = bf2f(hv[j] >> 16); }
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const uint32_t rj = r.rv[j] & keep;
-    x[2 * j] = hf[2 * j] + bf2f(rj & 0xffffu);
-    x[2 * j + 1] = hf[2 * j + 1] + bf2f(rj >> 16);
+    x[2 * j] = hf[2 * j] + bf2f(rv[j] & 0xffffu);
+    x[2 * j + 1] = hf[2 * j + 1] + bf2f(rv[j] >> 16);
   }
 }
 
-template <bool PARTS>
-__device__ __forceinline__ void fused_load_x32(const FusedParams& p, int mm, int k8, float (&x)[8]) {
-  FusedRaw<PARTS> r;
-  fused_issue<PARTS>(p, mm, k8, r);
-  fused_x32<PARTS>(p, r, x);
-}
-
-template <int NT, int EPI, bool XNORM, int FUSED_MAXC, bool PARTS>
+template <int NT, int EPI, bool XNORM, int FUSED_MAXC>
 __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nw = blockDim.x >> 6;
-  // Wave roles (XNORM only; p.nprod = 0 otherwise).  vmcnt retires a wave's loads IN ORDER, so a wave that has its weight
-  // tiles in flight cannot touch the L2-resident operands of the norm prologue before the HBM round trip completes (and a
-  // wave that loads the prologue operands first starts its weight stream late).  The two jobs therefore go to different
-  // waves: the first NC "consumer" waves put their weight tiles in flight at once and wait at the barrier; the last
-  // p.nprod "producer" waves run the norm prologue meanwhile, publish x^ in LDS, and later own the epilogue (whose
-  // RoPE operands they prefetched).
-  const int NC = nw - p.nprod;                 // consumer waves (all of them when there is no prologue)
-  const bool consumer = wave < NC;
-  const int ew = p.nprod ? wave - NC : wave;   // index among the epilogue waves (< 0: not one)
-  const int enw = p.nprod ? p.nprod : nw;
   const int M = p.M, K = p.K;
   const int KT = K >> 5, K8 = K >> 3;
   const int tile0 = blockIdx.x * NT;
   const int mcol = lane & 15, q4 = lane >> 4;
-  // LDS: [combine / prologue scratch: NC*NT KiB (>= M*K8*4 B + rs rows)] [x^ image: M*K*2 B, chunk (k8, m) at (k8*M + m)*16 B]
+  // LDS: [combine / prologue scratch: nw*NT KiB (>= M*K8*4 B)] [x^ image: M*K*2 B, chunk (k8, m) at (k8*M + m)*16 B]
   u32x4_t* xlds = reinterpret_cast<u32x4_t*>(smem + p.scratch_bytes);
 
   f32x4_t acc[NT];
@@ -160,128 +112,120 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
       }
     }
   };
-  // K is dealt to the consumer waves in groups of U k-tiles, round-robin (wave w: groups w, w + NC, ...): the workgroup walks
-  // each row group's K run linearly (see gemm.hip / profiles/micro/readpat.hip); the < U left-over k-tiles go to the last one
-  const int kstep = NC * U;
+  // K is dealt to the waves in groups of U k-tiles, round-robin (wave w: groups w, w + nw, ...): the workgroup walks each
+  // row group's K run linearly (see gemm.hip / profiles/micro/readpat.hip); the < U left-over k-tiles go to the last wave
+  const int kstep = nw * U;
   const int kt0 = wave * U;
   const int ngroups = KT / U;
-  const int nmain = (consumer && ngroups > wave) ? (ngroups - wave + NC - 1) / NC : 0;   // groups of this wave
-  // the first TWO groups of weight tiles fly from the start (for the 1B draft that is the whole K range: one HBM round
-  // trip per wave; a kernel this short is a latency chain)
+  const int nmain = ngroups > wave ? (ngroups - wave + nw - 1) / nw : 0;   // groups of this wave
+  // the first TWO groups of weight tiles fly while the norm prologue runs (for the 1B draft that is the whole K range:
+  // one HBM round trip per wave; a kernel this short is a latency chain)
   if (nmain > 0) loadw(0, kt0);
   if (nmain > 1) loadw(1, kt0 + kstep);
-
-  // RoPE epilogue operands of an epilogue wave's first row group (positions -> cos/sin rows, slot: a chain of dependent
-  // L2 round trips if left to the epilogue) -- fetched now; under XNORM by the producer waves, which have no other loads
-  // queued in front
-  f32x4_t pre_c = {0.f, 0.f, 0.f, 0.f}, pre_s = pre_c;
+  // RoPE epilogue operands of the wave that will own row group `wave` (positions -> cos/sin rows -> slot: a chain of
+  // dependent L2 round trips if left to the epilogue), fetched now, behind the weight stream
+  float pre_cs[8];
   int pre_slot = -1;
-  const bool pre_ok = EPI == FEPI_QKV_ROPE && ew >= 0 && ew < NT && mcol < M;
-  if (pre_ok) {
-    pre_slot = p.slots[mcol];
-    const int grp = tile0 + ew;
+  bool pre_ok = false;
+  if (EPI == FEPI_QKV_ROPE && wave < NT && mcol < M) {
+    const int grp = tile0 + wave;
     const int gph = p.hd >> 4;
+    pre_slot = p.slots[mcol];
     if (grp < (p.nh + p.nkv) * gph) {
       const int d = (grp % gph) * 8 + (q4 & 1) * 4;
       const float* cs = p.cos_sin + (size_t)p.positions[mcol] * p.hd;
-      pre_c = *reinterpret_cast<const f32x4_t*>(cs + d);
-      pre_s = *reinterpret_cast<const f32x4_t*>(cs + (p.hd >> 1) + d);
+      const f32x4_t c4 = *reinterpret_cast<const f32x4_t*>(cs + d), s4 = *reinterpret_cast<const f32x4_t*>(cs + (p.hd >> 1) + d);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { pre_cs[r] = c4[r]; pre_cs[4 + r] = s4[r]; }
     }
+    pre_ok = true;
   }
-
   if (XNORM) {
-    // ---- prologue (producer waves): x32 = h + res; per-chunk sums of squares -> per-row rs (fixed order) ->
+    // ---- prologue: x32 = h + res kept in registers; per-chunk sums of squares -> per-row rs (fixed order) ->
     //      x^ = bf16(x32 * rs * w) into the LDS image; residual slice written to res_out ----
-    float* ssbuf = reinterpret_cast<float*>(smem);      // [M*K8] chunk sums, then [nprod][16] per-wave copies of rs
+    float* ssbuf = reinterpret_cast<float*>(smem);      // [M*K8] chunk sums, then [nw][16] per-wave copies of rs
     constexpr int MC = FUSED_MAXC > 0 ? FUSED_MAXC : 1;     // MAXC = 0: no register cache, two passes over the L2-resident rows
-    constexpr bool cached = FUSED_MAXC > 0;                 // the host picks MAXC = 1 only when M*K/8 <= the producer threads
     float x32[MC][8];
     u32x4_t wv[MC];
     const int total = M * K8;
-    const int pt = (int)threadIdx.x - NC * 64, PT = p.nprod * 64;       // producer thread index / count
+    const bool cached = FUSED_MAXC > 0 && total <= FUSED_MAXC * (int)blockDim.x;     // block-uniform
     const int cpb = (K8 + gridDim.x - 1) / gridDim.x;              // residual: workgroup b owns chunk columns [b*cpb, (b+1)*cpb)
-    if (!consumer) {
-      if (!cached) {   // large M*K: two passes over the L2-resident rows instead of registers
-        for (int c = pt; c < total; c += PT) {
-          const int mm = c / K8, k8 = c % K8;
-          float xx[8];
-          fused_load_x32<PARTS>(p, mm, k8, xx);
-          float ss = 0.f;
+    if (!cached) {   // large M*K (or few waves): two passes over the L2-resident rows instead of registers
+      for (int c = threadIdx.x; c < total; c += blockDim.x) {
+        const int mm = c / K8, k8 = c % K8;
+        float xx[8];
+        fused_load_x32(p, mm, k8, xx);
+        float ss = 0.f;
+        u32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          ss += xx[2 * j] * xx[2 * j]; ss += xx[2 * j + 1] * xx[2 * j + 1];
+          o[j] = pack_bf2(xx[2 * j], xx[2 * j + 1]);
+        }
+        ssbuf[c] = ss;
+        if (p.res_out && k8 / cpb == (int)blockIdx.x) *reinterpret_cast<u32x4_t*>(p.res_out + (size_t)mm * K + k8 * 8) = o;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MC; ++i) {
+      const int c = threadIdx.x + i * blockDim.x;
+      if (cached && c < total) {
+        const int mm = c / K8, k8 = c % K8;
+        fused_load_x32(p, mm, k8, x32[i]);
+        wv[i] = *reinterpret_cast<const u32x4_t*>(p.norm_w + k8 * 8);
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ss += x32[i][2 * j] * x32[i][2 * j]; ss += x32[i][2 * j + 1] * x32[i][2 * j + 1]; }
+        ssbuf[c] = ss;
+        if (p.res_out && k8 / cpb == (int)blockIdx.x) {
           u32x4_t o;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            ss += xx[2 * j] * xx[2 * j]; ss += xx[2 * j + 1] * xx[2 * j + 1];
-            o[j] = pack_bf2(xx[2 * j], xx[2 * j + 1]);
-          }
-          ssbuf[c] = ss;
-          if (p.res_out && k8 / cpb == (int)blockIdx.x) *reinterpret_cast<u32x4_t*>(p.res_out + (size_t)mm * K + k8 * 8) = o;
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < MC; ++i) {
-          const int c = pt + i * PT;
-          if (c < total) {
-            const int mm = c / K8, k8 = c % K8;
-            fused_load_x32<PARTS>(p, mm, k8, x32[i]);
-            wv[i] = *reinterpret_cast<const u32x4_t*>(p.norm_w + k8 * 8);
-            float ss = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { ss += x32[i][2 * j] * x32[i][2 * j]; ss += x32[i][2 * j + 1] * x32[i][2 * j + 1]; }
-            ssbuf[c] = ss;
-            if (p.res_out && k8 / cpb == (int)blockIdx.x) {
-              u32x4_t o;
-#pragma unroll
-              for (int j = 0; j < 4; ++j) o[j] = pack_bf2(x32[i][2 * j], x32[i][2 * j + 1]);
-              *reinterpret_cast<u32x4_t*>(p.res_out + (size_t)mm * K + k8 * 8) = o;
-            }
-          }
+          for (int j = 0; j < 4; ++j) o[j] = pack_bf2(x32[i][2 * j], x32[i][2 * j + 1]);
+          *reinterpret_cast<u32x4_t*>(p.res_out + (size_t)mm * K + k8 * 8) = o;
         }
       }
     }
-    __syncthreads();         // chunk sums complete (consumers just pass through; their weight loads stay in flight)
-    if (!consumer) {
-      // every producer wave reduces the chunk sums of all M rows itself (same order as ssd_rmsnorm: lane-strided
-      // partials, then the xor tree) and keeps rs in its own LDS row: no further barrier among the producers
-      float* rsbuf = ssbuf + total + ew * 16;           // behind the chunk sums
-      for (int mm = 0; mm < M; ++mm) {
-        float t = 0.f;
-        for (int c = lane; c < K8; c += 64) t += ssbuf[mm * K8 + c];
-        t = wave_sum(t);
-        if (lane == 0) rsbuf[mm] = 1.0f / sqrtf(t / (float)K + p.eps);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (!cached) {
-        for (int c = pt; c < total; c += PT) {
-          const int mm = c / K8, k8 = c % K8;
-          const float rs = rsbuf[mm];
-          float xx[8];
-          fused_load_x32<PARTS>(p, mm, k8, xx);
-          const u32x4_t nwv = *reinterpret_cast<const u32x4_t*>(p.norm_w + k8 * 8);
-          u32x4_t o;
+    __syncthreads();
+    // every wave reduces the chunk sums of all M rows itself (same order as ssd_rmsnorm: lane-strided partials, then the
+    // xor tree) and keeps rs in its own LDS row: no second workgroup barrier
+    float* rsbuf = ssbuf + total + wave * 16;           // behind the chunk sums
+    for (int mm = 0; mm < M; ++mm) {
+      float t = 0.f;
+      for (int c = lane; c < K8; c += 64) t += ssbuf[mm * K8 + c];
+      t = wave_sum(t);
+      if (lane == 0) rsbuf[mm] = 1.0f / sqrtf(t / (float)K + p.eps);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (!cached) {
+      for (int c = threadIdx.x; c < total; c += blockDim.x) {
+        const int mm = c / K8, k8 = c % K8;
+        const float rs = rsbuf[mm];
+        float xx[8];
+        fused_load_x32(p, mm, k8, xx);
+        const u32x4_t nwv = *reinterpret_cast<const u32x4_t*>(p.norm_w + k8 * 8);
+        u32x4_t o;
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            o[j] = pack_bf2((xx[2 * j] * rs) * bf2f(nwv[j] & 0xffffu), (xx[2 * j + 1] * rs) * bf2f(nwv[j] >> 16));
-          xlds[k8 * M + mm] = o;
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < MC; ++i) {
-          const int c = pt + i * PT;
-          if (c < total) {
-            const int mm = c / K8, k8 = c % K8;
-            const float rs = rsbuf[mm];
-            u32x4_t o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              o[j] = pack_bf2((x32[i][2 * j] * rs) * bf2f(wv[i][j] & 0xffffu), (x32[i][2 * j + 1] * rs) * bf2f(wv[i][j] >> 16));
-            xlds[k8 * M + mm] = o;
-          }
-        }
+        for (int j = 0; j < 4; ++j)
+          o[j] = pack_bf2((xx[2 * j] * rs) * bf2f(nwv[j] & 0xffffu), (xx[2 * j + 1] * rs) * bf2f(nwv[j] >> 16));
+        xlds[k8 * M + mm] = o;
       }
     }
-    __syncthreads();         // x^ image published
+#pragma unroll
+    for (int i = 0; i < MC; ++i) {
+      const int c = threadIdx.x + i * blockDim.x;
+      if (cached && c < total) {
+        const int mm = c / K8, k8 = c % K8;
+        const float rs = rsbuf[mm];
+        u32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          o[j] = pack_bf2((x32[i][2 * j] * rs) * bf2f(wv[i][j] & 0xffffu), (x32[i][2 * j + 1] * rs) * bf2f(wv[i][j] >> 16));
+        xlds[k8 * M + mm] = o;
+      }
+    }
+    __syncthreads();
   }
 
   auto xfrag = [&](int buf, int u, int kt) -> u32x4_t {
@@ -291,8 +235,8 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
     return o;
   };
 
-  // ---- main loop (consumer waves): two groups of weight tiles (and fragment-major x) are in flight from the start; the
-  //      buffer just consumed is refilled with the group two steps ahead ----
+  // ---- main loop: two groups of weight tiles (and fragment-major x) are in flight from the start; the buffer just
+  //      consumed is refilled with the group two steps ahead ----
   int kt = kt0;
   auto stage = [&](auto curc, int it) {          // curc: compile-time buffer index (runtime-indexed register
     constexpr int cur = decltype(curc)::value;   // arrays would go to scratch)
@@ -310,7 +254,7 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
     stage(std::integral_constant<int, 0>{}, it);
     if (it + 1 < nmain) stage(std::integral_constant<int, 1>{}, it + 1);
   }
-  for (kt = (wave == NC - 1) ? ngroups * U : KT; kt < KT; ++kt) {
+  for (kt = (wave == nw - 1) ? ngroups * U : KT; kt < KT; ++kt) {
     u32x4_t xb;
     if (!XNORM) { xb = u32x4_t{0u, 0u, 0u, 0u}; if (mcol < M) xb = p.Xf[((size_t)kt << 6) + lane]; }
     else { xb = u32x4_t{0u, 0u, 0u, 0u}; if (mcol < M) xb = xlds[(kt * 4 + q4) * M + mcol]; }
@@ -320,13 +264,10 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
   }
 
   // ---- split-K combine through LDS in wave order ----
-  f32x4_t* cred = reinterpret_cast<f32x4_t*>(smem);   // [NC][NT][64]
-  if (consumer) {
+  f32x4_t* cred = reinterpret_cast<f32x4_t*>(smem);   // [nw][NT][64]
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) cred[(wave * NT + nt) * 64 + lane] = acc[nt];
-  }
+  for (int nt = 0; nt < NT; ++nt) cred[(wave * NT + nt) * 64 + lane] = acc[nt];
   __syncthreads();
-  if (ew < 0) return;
   const int nrow = q4 * 4;
   const int m = mcol;
 
@@ -334,9 +275,9 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
     constexpr int PAIRS = NT / 2;
     const int KT2 = (p.N >> 1) >> 5;
     u32x2_t* out = reinterpret_cast<u32x2_t*>(p.y);
-    for (int pr = ew; pr < PAIRS; pr += enw) {
+    for (int pr = wave; pr < PAIRS; pr += nw) {
       f32x4_t g = f32x4_t{0.f, 0.f, 0.f, 0.f}, u = g;
-      for (int w = 0; w < NC; ++w) {
+      for (int w = 0; w < nw; ++w) {
         g += cred[(w * NT + 2 * pr) * 64 + lane];
         u += cred[(w * NT + 2 * pr + 1) * 64 + lane];
       }
@@ -353,9 +294,9 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
       }
     }
   } else {
-    for (int nt = ew; nt < NT; nt += enw) {
+    for (int nt = wave; nt < NT; nt += nw) {
       f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      for (int w = 0; w < NC; ++w) s += cred[(w * NT + nt) * 64 + lane];
+      for (int w = 0; w < nw; ++w) s += cred[(w * NT + nt) * 64 + lane];
       const int grp = tile0 + nt;
       if (p.bias) {
 #pragma unroll
@@ -373,7 +314,6 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
         float x[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) x[r] = round_bf(s[r]);   // the reference stores qkv as bf16 before RoPE
-        const bool pre = nt == ew && pre_ok;
         if (grp < qk_groups) {
           const int head = grp / gph, j = grp % gph;
           float other[4];
@@ -382,16 +322,19 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
           if (m < M) {
             const int hi = q4 >> 1;                       // 0: first half of the head dim (x1), 1: second half (x2)
             const int d = j * 8 + (q4 & 1) * 4;           // dim within the half
-            f32x4_t c4 = pre_c, s4 = pre_s;
-            if (!pre) {
+            float cs8[8];
+            if (nt == wave && pre_ok) {
+#pragma unroll
+              for (int r = 0; r < 8; ++r) cs8[r] = pre_cs[r];
+            } else {
               const float* cs = p.cos_sin + (size_t)p.positions[m] * p.hd;
-              c4 = *reinterpret_cast<const f32x4_t*>(cs + d);
-              s4 = *reinterpret_cast<const f32x4_t*>(cs + half + d);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { cs8[r] = cs[d + r]; cs8[4 + r] = cs[half + d + r]; }
             }
             float yv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float co = c4[r], si = s4[r];
+              const float co = cs8[r], si = cs8[4 + r];
               yv[r] = hi ? __fadd_rn(__fmul_rn(x[r], co), __fmul_rn(other[r], si))
                          : __fsub_rn(__fmul_rn(x[r], co), __fmul_rn(other[r], si));
             }
@@ -400,7 +343,7 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
             if (head < p.nh) {
               *reinterpret_cast<u32x2_t*>(p.q_out + ((size_t)m * p.nh + head) * p.hd + dim) = v;
             } else {
-              const int slot = pre ? pre_slot : p.slots[m];
+              const int slot = (nt == wave && pre_ok) ? pre_slot : p.slots[m];
               if (slot >= 0) {
                 const size_t rowi = ((size_t)(slot / p.bs) * p.nkv + (head - p.nh)) * p.bs + (slot % p.bs);
                 *reinterpret_cast<u32x2_t*>(p.k_cache + rowi * p.hd + dim) = v;
@@ -410,7 +353,7 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
         } else if (m < M) {   // V: natural row order, straight to the paged cache
           const int vg = grp - qk_groups;
           const int kvh = vg / gph, dim = (vg % gph) * 16 + nrow;
-          const int slot = pre ? pre_slot : p.slots[m];
+          const int slot = (nt == wave && pre_ok) ? pre_slot : p.slots[m];
           if (slot >= 0) {
             const size_t rowi = ((size_t)(slot / p.bs) * p.nkv + kvh) * p.bs + (slot % p.bs);
             const u32x2_t v = {pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3])};
@@ -422,15 +365,14 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
   }
 }
 
-template <int NT, int EPI, bool XNORM, int MAXC, bool PARTS>
-static int launch_fused_c(const FusedParams& p, int waves, int nprod, hipStream_t st) {
+template <int NT, int EPI, bool XNORM, int MAXC>
+static int launch_fused_c(const FusedParams& p, int waves, hipStream_t st) {
   const int blocks = (p.N / 16) / NT;
-  size_t lds = (size_t)waves * NT * 64 * sizeof(f32x4_t);                     // split-K combine: one KiB per consumer wave and row group
+  size_t lds = (size_t)waves * NT * 64 * sizeof(f32x4_t);
   FusedParams q = p;
-  q.nprod = nprod;
   if (XNORM) {
     const size_t chunks = (size_t)p.M * (p.K / 8);
-    const size_t need = chunks * 4 + (size_t)nprod * 64;                      // chunk sums + one rs row per producer wave
+    const size_t need = chunks * 4 + (size_t)waves * 64;                      // chunk sums + one rs row per wave
     if (lds < need) lds = (need + 15) & ~(size_t)15;
     q.scratch_bytes = (int)lds;
     lds += chunks * 16;                                                       // x^ image
@@ -438,26 +380,21 @@ static int launch_fused_c(const FusedParams& p, int waves, int nprod, hipStream_
   } else {
     q.scratch_bytes = (int)lds;
   }
-  auto kern = gemm_fused_kernel<NT, EPI, XNORM, MAXC, PARTS>;
+  auto kern = gemm_fused_kernel<NT, EPI, XNORM, MAXC>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return SSD_ERR_LAUNCH;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3((waves + nprod) * 64), lds, st, q);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, st, q);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
 template <int NT, int EPI, bool XNORM>
 static int launch_fused(const FusedParams& p, int waves, hipStream_t st) {
   if constexpr (XNORM) {
-    // `waves` consumer waves stream the weights, nprod producer waves run the norm prologue (16 waves per workgroup at most)
-    int nprod = 4;
-    if (waves + nprod > 16) waves = 8;
-    if (waves <= 8) nprod = 8;
-    const bool fits = p.M * (p.K / 8) <= nprod * 64;
-    if (p.h_parts) return fits ? launch_fused_c<NT, EPI, true, 1, true>(p, waves, nprod, st) : launch_fused_c<NT, EPI, true, 0, true>(p, waves, nprod, st);
-    return fits ? launch_fused_c<NT, EPI, true, 1, false>(p, waves, nprod, st) : launch_fused_c<NT, EPI, true, 0, false>(p, waves, nprod, st);
+    if (p.M * (p.K / 8) <= waves * 64) return launch_fused_c<NT, EPI, true, 1>(p, waves, st);
+    return launch_fused_c<NT, EPI, true, 0>(p, waves, st);
   } else {
-    return launch_fused_c<NT, EPI, false, 1, false>(p, waves, 0, st);
+    return launch_fused_c<NT, EPI, false, 1>(p, waves, st);
   }
 }
 
@@ -480,7 +417,7 @@ static int fused_impl(const void* x_frag, const void* h_rows, const float* h_par
   if (M <= 0 || M > 16 || (N & 15) || (K & 31) || N <= 0 || K <= 0) return SSD_ERR_SHAPE;
   if ((h_rows != nullptr) + (x_frag != nullptr) + (h_parts != nullptr) != 1) return SSD_ERR_ARG;     // exactly one x source
   if ((h_rows || h_parts) && !norm_w) return SSD_ERR_ARG;
-  if (h_parts && (S < 1 || S > FUSED_MAXS)) return SSD_ERR_ARG;
+  if (h_parts && (S < 1 || S > 16)) return SSD_ERR_ARG;
   if (res_out && res_out == res_in) return SSD_ERR_ARG;                   // in-place residual would race
   const int groups = N / 16;
   if (nt <= 0 || waves <= 0) {

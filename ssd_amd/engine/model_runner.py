@@ -24,6 +24,9 @@ from ssd_amd import weights as W
 
 
 class ModelRunner:
+    PREFILL_GRAPHS = 4              # prefill shapes kept as hipGraphs
+    PREFILL_GRAPH_MAX_T = 1024      # longer prefills are GPU-bound by far: launch overhead does not matter
+
     def __init__(self, config, model_cfg: ModelConfig, *, is_draft: bool, device: torch.device, tp_rank: int = 0,
                  tp_size: int = 1, tp_group=None, model_path: str | None = None, weights_seed: int = 0,
                  gen_device: str | None = None, num_kvcache_blocks: int = -1, memory_utilization: float | None = None,
@@ -360,8 +363,23 @@ class ModelRunner:
             return toks
         if is_prefill:
             T, max_q = self._prepare_prefill(seqs)
-            self.model.forward(self.d_ids, self.d_pos, T, self._meta("prefill", B, max_q))
-            self.model.compute_logits(T, gather=self.d_gather, rows=B)
+
+            def body():
+                self.model.forward(self.d_ids, self.d_pos, T, self._meta("prefill", B, max_q))
+                self.model.compute_logits(T, gather=self.d_gather, rows=B)
+            # the reference prefills eagerly (model_runner.py:602); here a prefill SHAPE that comes back (fixed-length
+            # prompts: the benchmark protocol, batch jobs) replays one hipGraph -- every length-dependent quantity lives
+            # in the static device buffers, only (B, T, longest query, context bucket) fix the launch geometry.  A few
+            # shapes are kept; anything else runs eagerly as before (the first occurrence doubles as the warm-up run).
+            key = ("prefill", B, T, max_q)
+            if self.config.enforce_eager or T > self.PREFILL_GRAPH_MAX_T:
+                body()
+            else:
+                full = (*key, self._ctx_hint)
+                if full not in self.graphs and sum(1 for k in self.graphs if k[0] == "prefill") >= self.PREFILL_GRAPHS:
+                    for k in [k for k in self.graphs if k[0] == "prefill"][:1]:
+                        del self.graphs[k]
+                self._launch(key, body)             # "captured": the eager warm-up run already produced this call's result
             self._log_margins(B, [(s.seq_id, len(s)) for s in seqs])
             self._sample_or_argmax(seqs, B)
             toks = self._read_tokens(B)

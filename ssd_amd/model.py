@@ -98,11 +98,9 @@ class HipDecoder:
         # the chip (csrc/gemm_sk.hip gemm_sp_kernel): fp32 [S][T][h], summed by the consumer's prologue / ssd_rmsnorm_parts
         self.use_parts = os.environ.get("SSD_PARTS", "1") != "0" and (self.h // 16) < 256
         self._in_prefill = False        # set by forward(): a varlen prefill never takes the slab path (its last-token gather reads rows)
-        self.parts_cfg_o = self._parts_cfg(self.h, self.qn)
-        self.parts_cfg_d = self._parts_cfg(self.h, self.I)
         pt = min(T, 32)
-        self.buf_parts_o = z(self.parts_cfg_o[0] * pt * self.h, dtype=torch.float32) if self.use_parts else None
-        self.buf_parts_d = z(self.parts_cfg_d[0] * pt * self.h, dtype=torch.float32) if self.use_parts else None
+        self.buf_parts_o = z(4 * pt * self.h, dtype=torch.float32) if self.use_parts else None
+        self.buf_parts_d = z(4 * pt * self.h, dtype=torch.float32) if self.use_parts else None
         self.logits = z(self.max_logit_rows, self.V)
         self.max_splits = 16
         self._ws_pf = None           # fp32 split-K partials of the prefill GEMM, allocated by the first prefill
@@ -232,22 +230,30 @@ class HipDecoder:
         return splits, waves
 
     @staticmethod
-    def _parts_cfg(N: int, K: int) -> tuple[int, int]:
-        """(K splits, waves) of the split-K partial-slab GEMM for a [N, K] matrix (profiles/r02_draft_probe.txt, 1B shapes:
-        o_proj 4.5 -> 3.7 us at (4, 8), down_proj 10.0 -> 7.6 us at (4, 8); M = 24: 8.1 -> 4.2 and 16.7 -> 9.0): enough
-        workgroups to put >= 2 on every CU, <= 4 slabs (what the fused norm prologue sums), <= 8 k-tiles per wave so that
-        every wave has its whole share in flight at once."""
+    def _parts_cfg(N: int, K: int, fused_consumer: bool = False) -> tuple[int, int]:
+        """(K splits, waves) of the split-K partial-slab GEMM for a [N, K] matrix, from profiles/r02_draft_probe.txt (1B
+        shapes, us per launch; rows kernel -> slabs): M = 1: o_proj 4.5 -> 3.7 (4 splits, 8 waves) / 3.9 (2, 16), down_proj
+        10.0 -> 7.6 (4, 8) / 8.0 (2, 16); M = 24: 8.1 -> 4.2 and 16.7 -> 9.0.  Enough workgroups to put >= 2 on every CU and
+        <= 8 k-tiles per wave, so that every wave has its whole share in flight at once.  When the consumer is the fused
+        norm + GEMM prologue (every workgroup of the NEXT kernel re-reads the slabs) two slabs are the optimum: a third
+        and fourth cost the consumers more than they save here."""
         groups, KT = N // 16, K // 32
+        smax = 2 if fused_consumer else 4
         S = 1
-        while groups * S < 512 and S < 4 and KT // (S * 2) >= 8:
+        while groups * S < 512 and S < smax and KT // (S * 2) >= 8:
             S *= 2
         per = -(-KT // S)
-        waves = 8
+        waves = 16 if fused_consumer else 8
         while waves < 16 and -(-per // waves) > 8:
             waves *= 2
         while waves > 2 and per // waves < 1:
             waves //= 2
         return S, waves
+
+    def _parts(self, which: str, T: int) -> tuple[int, int]:
+        fused = self.fusion_plan(T)[1]
+        N, K = (self.h, self.qn) if which == "o" else (self.h, self.I)
+        return self._parts_cfg(N, K, fused)
 
     def parts_plan(self, T: int) -> bool:
         """o_proj / down_proj as split-K partial slabs consumed by the next norm: single-rank models with < 256 row groups at
@@ -277,7 +283,7 @@ class HipDecoder:
         h, res, xf = self.buf_h, self.buf_res, self.buf_xf
         parts = self.parts_plan(T) and li > 0          # the previous layer's down_proj left fp32 partial slabs, not rows
         if norm_fuse:
-            src = dict(h_parts=self.buf_parts_d, splits=self.parts_cfg_d[0]) if parts else dict(h_rows=h)
+            src = dict(h_parts=self.buf_parts_d, splits=self._parts("d", T)[0]) if parts else dict(h_rows=h)
             H.gemm_fused(w[p + "self_attn.qkv_proj.weight"], T, self.qkv_n, self.h, H.FEPI_QKV_ROPE,
                          res_in=None if li == 0 else res, res_out=self.buf_res2, norm_w=w[p + "input_layernorm.weight"],
                          eps=cfg.rms_norm_eps, bias=w.get(p + "self_attn.qkv_proj.bias"), waves=16, **src, **rope)
@@ -285,7 +291,7 @@ class HipDecoder:
         # residual is None on layer 0 (llama3.py:187-190): residual := embeddings, x := norm(embeddings)
         if not gemm_only and not pre_normed:
             if parts:
-                H.rmsnorm_parts(self.buf_parts_d, self.parts_cfg_d[0], T, w[p + "input_layernorm.weight"], cfg.rms_norm_eps, T, self.h,
+                H.rmsnorm_parts(self.buf_parts_d, self._parts("d", T)[0], T, w[p + "input_layernorm.weight"], cfg.rms_norm_eps, T, self.h,
                                 res_in=res, res_out=res, out_frag=xf)
             else:
                 H.rmsnorm(h, w[p + "input_layernorm.weight"], cfg.rms_norm_eps, T, self.h, res_in=None if li == 0 else res,
@@ -305,7 +311,8 @@ class HipDecoder:
     def launch_o(self, li: int, T: int) -> None:
         w = self.w[f"model.layers.{li}.self_attn.o_proj.weight"]
         if self.parts_plan(T):
-            H.gemm_parts(self.buf_af, w, T, self.h, self.qn, parts=self.buf_parts_o, splits=self.parts_cfg_o[0], waves=self.parts_cfg_o[1])
+            S, wv = self._parts("o", T)
+            H.gemm_parts(self.buf_af, w, T, self.h, self.qn, parts=self.buf_parts_o, splits=S, waves=wv)
         else:
             self._gemm(self.buf_af, self.qn, w, self.h, self.buf_h, T, self.h)
 
@@ -315,14 +322,14 @@ class HipDecoder:
         _, norm_fuse = self.fusion_plan(T)
         parts = self.parts_plan(T)                     # o_proj left fp32 partial slabs
         if norm_fuse:
-            src = dict(h_parts=self.buf_parts_o, splits=self.parts_cfg_o[0]) if parts else dict(h_rows=self.buf_h)
+            src = dict(h_parts=self.buf_parts_o, splits=self._parts("o", T)[0]) if parts else dict(h_rows=self.buf_h)
             H.gemm_fused(w[p + "mlp.gate_up_proj.weight"], T, 2 * self.I, self.h, H.FEPI_SILU_FRAG,
                          res_in=self.buf_res2, res_out=self.buf_res, norm_w=w[p + "post_attention_layernorm.weight"],
                          eps=cfg.rms_norm_eps, y=self.buf_actf, waves=8, **src)     # profiles/micro/fused_probe.py: 13.2 us vs 16.4 (16 waves)
         else:
             if not gemm_only and not pre_normed:
                 if parts:
-                    H.rmsnorm_parts(self.buf_parts_o, self.parts_cfg_o[0], T, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps,
+                    H.rmsnorm_parts(self.buf_parts_o, self._parts("o", T)[0], T, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps,
                                     T, self.h, res_in=self.buf_res, res_out=self.buf_res, out_frag=self.buf_xf)
                 else:
                     H.rmsnorm(self.buf_h, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps, T, self.h,
@@ -332,7 +339,8 @@ class HipDecoder:
     def launch_down(self, li: int, T: int) -> None:
         w = self.w[f"model.layers.{li}.mlp.down_proj.weight"]
         if self.parts_plan(T):
-            H.gemm_parts(self.buf_actf, w, T, self.h, self.I, parts=self.buf_parts_d, splits=self.parts_cfg_d[0], waves=self.parts_cfg_d[1])
+            S, wv = self._parts("d", T)
+            H.gemm_parts(self.buf_actf, w, T, self.h, self.I, parts=self.buf_parts_d, splits=S, waves=wv)
         else:
             self._gemm(self.buf_actf, self.I, w, self.h, self.buf_h, T, self.h)
 
@@ -379,7 +387,7 @@ class HipDecoder:
         assert n <= self.max_logit_rows
         if self.parts_plan(getattr(self, "_fwd_T", 1 << 30)):
             assert gather is None and n == self._fwd_T
-            H.rmsnorm_parts(self.buf_parts_d, self.parts_cfg_d[0], n, self.w["model.norm.weight"], self.cfg.rms_norm_eps, n, self.h,
+            H.rmsnorm_parts(self.buf_parts_d, self._parts("d", n)[0], n, self.w["model.norm.weight"], self.cfg.rms_norm_eps, n, self.h,
                             res_in=self.buf_res, out_frag=self.buf_lastf)
         else:
             H.rmsnorm(self.buf_h, self.w["model.norm.weight"], self.cfg.rms_norm_eps, n, self.h, res_in=self.buf_res,

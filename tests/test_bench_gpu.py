@@ -36,7 +36,7 @@ def check(line, n):
     assert line["n_gpus"] == n and line["value"] > 0 and line["ms_per_step"] > 0
     r = line["roofline"]
     assert r["bound"] == "hbm" and 0 < r["frac"] < 1.0 and r["achieved"] > 0 and r["peak"] == 8000.0
-    assert line["cpu_baseline"]["value"] and line["cpu_baseline"]["cores"] >= 1
+    assert line["cpu_baseline"]["value"] and line["cpu_baseline"]["cores"] >= 1, line["cpu_baseline"]
     assert "workload" in line["config"]
 
 

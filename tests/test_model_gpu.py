@@ -440,3 +440,20 @@ def test_long_generation_crosses_context_buckets(gpu):
     assert sum(lens) / len(lens) > K                     # of K+1: the draft keeps being accepted at every context length
     # identical to the end, or the first difference sits on a near-tie of the autoregressive run
     assert_stream_matches(s, a, seq_margins(ar_eng.model_runner.margin_log, 0), len(prompt), what="long generation SD vs AR")
+
+
+def test_prefill_shape_replays_its_hipgraph(gpu, golden):
+    """A prefill shape that comes back replays a captured hipGraph (the reference prefills eagerly): same tokens as the
+    eager engine, for a repeated prompt length and for a different one in between."""
+    from ssd_amd.engine.llm_engine import LLMEngine
+    from ssd_amd.sampling_params import SamplingParams
+    g = golden("engine_golden")
+    kw = dict(hf_config=mk_cfg(g, "llama", "t_"), **COMMON)
+    sp = SamplingParams(temperature=0, max_new_tokens=6, ignore_eos=True)
+    p1, p2 = g["prompt"].tolist(), g["prompt"].tolist()[:-3]
+    eager = LLMEngine("tiny", runner_factory=hip_factory(weights(g, "t.")), enforce_eager=True, **kw)
+    want = [eager.generate([p], sp, use_tqdm=False)[0][0]["token_ids"] for p in (p1, p2, p1, p1)]
+    eng = LLMEngine("tiny", runner_factory=hip_factory(weights(g, "t.")), **kw)
+    got = [eng.generate([p], sp, use_tqdm=False)[0][0]["token_ids"] for p in (p1, p2, p1, p1)]
+    assert got == want
+    assert sum(1 for k in eng.model_runner.graphs if k[0] == "prefill") == 2
