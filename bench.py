@@ -216,8 +216,10 @@ def cpu_baseline():
     cores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     cfg = PRESETS["llama-3.2-1b"]
+    from ssd_amd.utils.topology import Topology
     eng = LLMEngine("llama-3.2-1b", hf_config=cfg, runner_factory=oracle_runner_factory(), max_model_len=1024,
-                    max_num_batched_tokens=1024, kvcache_block_size=256, num_kvcache_blocks=4)
+                    max_num_batched_tokens=1024, kvcache_block_size=256, num_kvcache_blocks=4,
+                    topology=Topology(0, 1, torch.device("cpu"), "target", 0, 1))     # a plain single-process engine at every N
     random.seed(0)
     prompt = [random.randint(0, 10000) for _ in range(32)]
     # time-bounded sample: decode steps until ~12 s of CPU work have been spent (at least 4, at most 512 tokens)

@@ -408,13 +408,15 @@ static int attn_launch_rt(const AttnParams& p, dim3 grid, int waves, hipStream_t
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
-// Row tiles per workgroup: two for prefill-sized query blocks (K/V bytes shared by 32 rows), one for the decode-side
+// Row tiles per workgroup: two for prefill-sized query blocks (> 8 tiles; K/V bytes shared by 32 rows), one for the decode-side
 // shapes (more workgroups: the scan is bound by per-CU load bandwidth and latency, not by K/V bytes).
 template <int HD>
 static int attn_launch(const AttnParams& p, int B, int T, int max_q, int waves, int force_rt1, hipStream_t st) {
   const int G = p.nh / p.nkv;
   const int row_tiles = (max_q * G + 15) / 16;
-  const int rt = (row_tiles > 4 && !force_rt1) ? 2 : 1;
+  // (the 24-branch tree step has 6 row tiles per kv head: one tile per workgroup measured 10.5 -> 7.7 us at ctx 150 and
+  // 19.6 -> 12.6 us at ctx 640 on the 1B draft, profiles/r02_draft_probe.txt)
+  const int rt = (row_tiles > 8 && !force_rt1) ? 2 : 1;
   dim3 grid((row_tiles + rt - 1) / rt, B * p.nkv, p.splits);
   // one key tile in flight per wave (KT = 1): measured on MI355X, KT = 2/4 buy nothing -- with 8 waves per workgroup
   // the scan is bound by the handful of CUs it occupies, not by a single wave's load latency

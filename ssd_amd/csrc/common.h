@@ -62,17 +62,38 @@ __device__ __forceinline__ float wave_max(float v) {
 //   nt    row groups per workgroup (x operand amortised over nt weight tiles; fewer, fatter workgroups)
 //   waves K-split inside the workgroup
 //   tpw   consecutive tiles per workgroup (gemm.hip only)
+// Consecutive tiles per workgroup for `ntiles` tiles: the candidate that wastes the least of the last round of 256
+// workgroups (a launch whose workgroup count lands just above a multiple of the CU count pays a nearly empty round:
+// Qwen3-32B gate_up at 3 tiles -> 267 workgroups ran 117 us, at 4 -> 200 workgroups 85 us; profiles/r02_tune_qwen.txt),
+// larger runs winning ties.
+static inline int ssd_pick_tpw(int ntiles, const int* cand, int ncand) {
+  int best = 1;
+  double best_eff = -1.0;
+  for (int i = 0; i < ncand; ++i) {
+    const int t = cand[i];
+    const int blocks = (ntiles + t - 1) / t;
+    if (blocks < 192 && t > 1) continue;                     // never starve the chip for the sake of a full round
+    const double eff = (double)blocks / (double)(((blocks + 255) / 256) * 256);
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = t; }
+  }
+  return best;
+}
+
 static inline void ssd_pick_skinny_cfg(int groups, int KT, bool silu_pairs, int* nt, int* waves, int* tpw) {
   int n = 1, w = 8, t = 1;
   if (silu_pairs) {                       // gate_up: row groups come in (gate, up) pairs -> nt even
     n = (groups >= 1792 && groups % 4 == 0) ? 4 : 2;
-    if (n == 4 && KT > 128) {             // consecutive tiles per workgroup, but never fewer than ~224 workgroups
-      t = (groups / 4) / 224;
-      t = t < 1 ? 1 : (t > 4 ? 4 : t);
+    if (n == 4 && KT > 128) {             // consecutive tiles per workgroup
+      const int cand[] = {4, 3, 2, 1};
+      t = ssd_pick_tpw(groups / 4, cand, 4);
     }
   } else if (groups >= 4096) {            // LM heads
     n = (groups % 2 == 0) ? 2 : 1;
-    if (KT >= 128) { w = 16; t = 8; }
+    if (KT >= 128) {
+      const int cand[] = {8, 4, 2, 1};
+      t = ssd_pick_tpw(groups / n, cand, 4);
+      w = t > 1 ? 16 : 8;
+    }
   } else if (groups >= 1000 && KT >= 256 && groups % 2 == 0) {   // vocabulary shards
     n = 2; w = 16; t = 2;
   } else if (groups >= 640 && KT >= 256 && groups % 4 == 0) {    // 70B-class qkv

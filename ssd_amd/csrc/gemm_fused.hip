@@ -365,6 +365,146 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// QKV GEMM + RoPE + paged KV store for 17..32 token rows (the 24-branch tree-decode step of asynchronous speculation,
+// reference ssd/engine/draft_runner.py:713-812): the same epilogue as above over TWO 16-row token tiles, x in the
+// fragment-major layout (no norm prologue at this size: the normalised x comes from ssd_rmsnorm / ssd_rmsnorm_parts).
+// One launch instead of F.linear + rotary_emb + store_kvcache.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(1024) gemm_qkv_rope_m32_kernel(const FusedParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int MT = 2, U = 2;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nw = blockDim.x >> 6;
+  const int M = p.M, KT = p.K >> 5;
+  const int tile0 = blockIdx.x * NT;
+  const int mcol = lane & 15, q4 = lane >> 4;
+  const u32x4_t* wp = p.Wf + ((size_t)tile0 * KT << 6) + lane;
+  const size_t wstride = (size_t)KT << 6, xstride = (size_t)KT << 6;
+  f32x4_t acc[NT][MT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  u32x4_t wa[2][U][NT], xg[2][U][MT];
+  auto loadw = [&](int buf, int kt) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        wa[buf][u][nt] = __builtin_nontemporal_load(wp + nt * wstride + ((size_t)(kt + u) << 6));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        u32x4_t b = {0u, 0u, 0u, 0u};
+        if (mt * 16 + mcol < M) b = p.Xf[mt * xstride + ((size_t)(kt + u) << 6) + lane];
+        xg[buf][u][mt] = b;
+      }
+    }
+  };
+  const int kstep = nw * U, kt0 = wave * U, ngroups = KT / U;
+  const int nmain = ngroups > wave ? (ngroups - wave + nw - 1) / nw : 0;
+  if (nmain > 0) loadw(0, kt0);
+  if (nmain > 1) loadw(1, kt0 + kstep);
+  int kt = kt0;
+  auto stage = [&](auto curc, int it) {
+    constexpr int cur = decltype(curc)::value;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mfma16(wa[cur][u][nt], xg[cur][u][mt], acc[nt][mt]);
+    if (it + 2 < nmain) loadw(cur, kt + 2 * kstep);
+    kt += kstep;
+  };
+  for (int it = 0; it < nmain; it += 2) {
+    stage(std::integral_constant<int, 0>{}, it);
+    if (it + 1 < nmain) stage(std::integral_constant<int, 1>{}, it + 1);
+  }
+  for (kt = (wave == nw - 1) ? ngroups * U : KT; kt < KT; ++kt) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      u32x4_t xb = {0u, 0u, 0u, 0u};
+      if (mt * 16 + mcol < M) xb = p.Xf[mt * xstride + ((size_t)kt << 6) + lane];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[nt][mt] = mfma16(__builtin_nontemporal_load(wp + nt * wstride + ((size_t)kt << 6)), xb, acc[nt][mt]);
+    }
+  }
+  f32x4_t* cred = reinterpret_cast<f32x4_t*>(smem);   // [nw][NT*MT][64]
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) cred[(wave * NT * MT + nt * MT + mt) * 64 + lane] = acc[nt][mt];
+  __syncthreads();
+  const int nrow = q4 * 4;
+  const int gph = p.hd >> 4, qk_groups = (p.nh + p.nkv) * gph, half = p.hd >> 1;
+  for (int item = wave; item < NT * MT; item += nw) {
+    const int nt = item / MT, mt = item % MT;
+    f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int w = 0; w < nw; ++w) s += cred[(w * NT * MT + item) * 64 + lane];
+    const int grp = tile0 + nt;
+    const int m = mt * 16 + mcol;
+    if (p.bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[r] += bf2f(p.bias[grp * 16 + nrow + r]);
+    }
+    float x[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = round_bf(s[r]);   // the reference stores qkv as bf16 before RoPE
+    if (grp < qk_groups) {
+      const int head = grp / gph, j = grp % gph;
+      float other[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) other[r] = __shfl_xor(x[r], 32, 64);   // rotation partner: rows i <-> i + 8
+      if (m < M) {
+        const int hi = q4 >> 1;
+        const int d = j * 8 + (q4 & 1) * 4;
+        const float* cs = p.cos_sin + (size_t)p.positions[m] * p.hd;
+        const f32x4_t c4 = *reinterpret_cast<const f32x4_t*>(cs + d), s4 = *reinterpret_cast<const f32x4_t*>(cs + half + d);
+        float yv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          yv[r] = hi ? __fadd_rn(__fmul_rn(x[r], c4[r]), __fmul_rn(other[r], s4[r]))
+                     : __fsub_rn(__fmul_rn(x[r], c4[r]), __fmul_rn(other[r], s4[r]));
+        const u32x2_t v = {pack_bf2(yv[0], yv[1]), pack_bf2(yv[2], yv[3])};
+        const int dim = hi * half + d;
+        if (head < p.nh) {
+          *reinterpret_cast<u32x2_t*>(p.q_out + ((size_t)m * p.nh + head) * p.hd + dim) = v;
+        } else {
+          const int slot = p.slots[m];
+          if (slot >= 0) {
+            const size_t rowi = ((size_t)(slot / p.bs) * p.nkv + (head - p.nh)) * p.bs + (slot % p.bs);
+            *reinterpret_cast<u32x2_t*>(p.k_cache + rowi * p.hd + dim) = v;
+          }
+        }
+      }
+    } else if (m < M) {   // V: natural row order, straight to the paged cache
+      const int vg = grp - qk_groups;
+      const int kvh = vg / gph, dim = (vg % gph) * 16 + nrow;
+      const int slot = p.slots[m];
+      if (slot >= 0) {
+        const size_t rowi = ((size_t)(slot / p.bs) * p.nkv + kvh) * p.bs + (slot % p.bs);
+        const u32x2_t v = {pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3])};
+        *reinterpret_cast<u32x2_t*>(p.v_cache + rowi * p.hd + dim) = v;
+      }
+    }
+  }
+}
+
+template <int NT>
+static int launch_qkv_m32(const FusedParams& p, int waves, hipStream_t st) {
+  const size_t lds = (size_t)waves * NT * 2 * 64 * sizeof(f32x4_t);
+  auto kern = gemm_qkv_rope_m32_kernel<NT>;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return SSD_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, dim3((p.N / 16) / NT), dim3(waves * 64), lds, st, p);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
 template <int NT, int EPI, bool XNORM, int MAXC>
 static int launch_fused_c(const FusedParams& p, int waves, hipStream_t st) {
   const int blocks = (p.N / 16) / NT;
@@ -414,7 +554,8 @@ static int fused_impl(const void* x_frag, const void* h_rows, const float* h_par
                       int epilogue, void* y, int ldy, const int64_t* positions, const float* cos_sin,
                       const int32_t* slots, void* q_out, void* k_cache, void* v_cache, int nh, int nkv, int hd,
                       int block_size, int nt, int waves, void* stream) {
-  if (M <= 0 || M > 16 || (N & 15) || (K & 31) || N <= 0 || K <= 0) return SSD_ERR_SHAPE;
+  const bool m32 = M > 16 && M <= 32 && x_frag && !h_rows && !h_parts && epilogue == FEPI_QKV_ROPE;    // two token tiles
+  if (M <= 0 || (M > 16 && !m32) || (N & 15) || (K & 31) || N <= 0 || K <= 0) return SSD_ERR_SHAPE;
   if ((h_rows != nullptr) + (x_frag != nullptr) + (h_parts != nullptr) != 1) return SSD_ERR_ARG;     // exactly one x source
   if ((h_rows || h_parts) && !norm_w) return SSD_ERR_ARG;
   if (h_parts && (S < 1 || S > 16)) return SSD_ERR_ARG;
@@ -441,6 +582,10 @@ static int fused_impl(const void* x_frag, const void* h_rows, const float* h_par
   p.q_out = (bf16_t*)q_out; p.k_cache = (bf16_t*)k_cache; p.v_cache = (bf16_t*)v_cache;
   p.eps = eps; p.M = M; p.N = N; p.K = K; p.ldy = ldy; p.nh = nh; p.nkv = nkv; p.hd = hd; p.bs = block_size;
   hipStream_t st = (hipStream_t)stream;
+  if (m32) {
+    if (nt == 4) nt = 2;                       // two m-tiles double the accumulators and the x operands
+    return nt == 1 ? launch_qkv_m32<1>(p, waves, st) : launch_qkv_m32<2>(p, waves, st);
+  }
   const bool xn = h_rows != nullptr || h_parts != nullptr;
 #define FUSED_DISPATCH(E)                                                                          \
   return xn ? launch_fused_nt<E, true>(p, nt, waves, st) : launch_fused_nt<E, false>(p, nt, waves, st);

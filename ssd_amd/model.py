@@ -97,7 +97,7 @@ class HipDecoder:
         # split-K partial slabs of o_proj / down_proj for models whose hidden size gives too few 16-row groups to fill
         # the chip (csrc/gemm_sk.hip gemm_sp_kernel): fp32 [S][T][h], summed by the consumer's prologue / ssd_rmsnorm_parts
         self.use_parts = os.environ.get("SSD_PARTS", "1") != "0" and (self.h // 16) < 256
-        self._in_prefill = False        # set by forward(): a varlen prefill never takes the slab path (its last-token gather reads rows)
+        self._last_parts = False        # set by forward() for the compute_logits that follows it
         pt = min(T, 32)
         self.buf_parts_o = z(4 * pt * self.h, dtype=torch.float32) if self.use_parts else None
         self.buf_parts_d = z(4 * pt * self.h, dtype=torch.float32) if self.use_parts else None
@@ -220,7 +220,7 @@ class HipDecoder:
         below 1K keys the extra launch costs more than it saves)."""
         G = self.nh // self.nkv
         row_tiles = -(-(meta.max_q * G) // 16)
-        groups = -(-row_tiles // 2) if row_tiles > 4 else row_tiles       # csrc/attention.hip attn_launch
+        groups = -(-row_tiles // 2) if row_tiles > 8 else row_tiles       # csrc/attention.hip attn_launch
         base = max(1, groups * meta.B * self.nkv)
         waves = max(1, min(8, 512 // base))
         ctx = self.ctx_bucket(meta.ctx_hint if meta.ctx_hint > 0 else self.max_model_len)
@@ -258,7 +258,7 @@ class HipDecoder:
     def parts_plan(self, T: int) -> bool:
         """o_proj / down_proj as split-K partial slabs consumed by the next norm: single-rank models with < 256 row groups at
         decode-sized T (the draft's chain / glue / tree forwards)."""
-        return self.use_parts and not self.use_coll and T <= 32 and not self._in_prefill
+        return self.use_parts and not self.use_coll and T <= 32
 
     # ---- the four GEMM launches of a layer (also used one by one by bench.py's roofline timing) ----
     def fusion_plan(self, T: int) -> tuple[bool, bool]:
@@ -270,7 +270,8 @@ class HipDecoder:
         small = T <= 16 and not self.cfg.qk_norm
         return small, small and not self.use_coll and T * self.h // 8 <= 1024
 
-    def launch_qkv(self, li: int, T: int, positions, slot_mapping, gemm_only: bool = False, pre_normed: bool = False) -> None:
+    def launch_qkv(self, li: int, T: int, positions, slot_mapping, gemm_only: bool = False, pre_normed: bool = False,
+                   parts: bool | None = None) -> None:
         """gemm_only: skip the separate add+RMSNorm / RoPE launches of the unfused variants (kernel timing).
         pre_normed: buf_xf / buf_res already hold this layer's normalised input and residual (written by the fused
         all-reduce + add + RMSNorm that closed the previous layer)."""
@@ -281,7 +282,7 @@ class HipDecoder:
         rope = dict(positions=positions, cos_sin=self.cos_sin, slots=slot_mapping, q_out=self.buf_q, k_cache=kc, v_cache=vc,
                     nh=self.nh, nkv=self.nkv, hd=self.hd, block_size=self.block_size)
         h, res, xf = self.buf_h, self.buf_res, self.buf_xf
-        parts = self.parts_plan(T) and li > 0          # the previous layer's down_proj left fp32 partial slabs, not rows
+        parts = (self.parts_plan(T) if parts is None else parts) and li > 0   # the previous layer's down_proj left fp32 slabs, not rows
         if norm_fuse:
             src = dict(h_parts=self.buf_parts_d, splits=self._parts("d", T)[0]) if parts else dict(h_rows=h)
             H.gemm_fused(w[p + "self_attn.qkv_proj.weight"], T, self.qkv_n, self.h, H.FEPI_QKV_ROPE,
@@ -296,7 +297,7 @@ class HipDecoder:
             else:
                 H.rmsnorm(h, w[p + "input_layernorm.weight"], cfg.rms_norm_eps, T, self.h, res_in=None if li == 0 else res,
                           res_out=res, out_frag=xf)
-        if small:
+        if small or (16 < T <= 32 and not cfg.qk_norm):      # T in 17..32 (tree-decode step): the two-token-tile variant
             H.gemm_fused(w[p + "self_attn.qkv_proj.weight"], T, self.qkv_n, self.h, H.FEPI_QKV_ROPE, x_frag=xf,
                          bias=w.get(p + "self_attn.qkv_proj.bias"), **rope)
         else:
@@ -308,19 +309,19 @@ class HipDecoder:
                             self.hd, self.block_size, q_norm_w=w.get(p + "self_attn.q_norm.weight"),
                             k_norm_w=w.get(p + "self_attn.k_norm.weight"), eps=cfg.rms_norm_eps, qkv_perm=1)
 
-    def launch_o(self, li: int, T: int) -> None:
+    def launch_o(self, li: int, T: int, parts: bool | None = None) -> None:
         w = self.w[f"model.layers.{li}.self_attn.o_proj.weight"]
-        if self.parts_plan(T):
+        if self.parts_plan(T) if parts is None else parts:
             S, wv = self._parts("o", T)
             H.gemm_parts(self.buf_af, w, T, self.h, self.qn, parts=self.buf_parts_o, splits=S, waves=wv)
         else:
             self._gemm(self.buf_af, self.qn, w, self.h, self.buf_h, T, self.h)
 
-    def launch_gate_up(self, li: int, T: int, gemm_only: bool = False, pre_normed: bool = False) -> None:
+    def launch_gate_up(self, li: int, T: int, gemm_only: bool = False, pre_normed: bool = False, parts: bool | None = None) -> None:
         cfg, w = self.cfg, self.w
         p = f"model.layers.{li}."
         _, norm_fuse = self.fusion_plan(T)
-        parts = self.parts_plan(T)                     # o_proj left fp32 partial slabs
+        parts = self.parts_plan(T) if parts is None else parts      # o_proj left fp32 partial slabs
         if norm_fuse:
             src = dict(h_parts=self.buf_parts_o, splits=self._parts("o", T)[0]) if parts else dict(h_rows=self.buf_h)
             H.gemm_fused(w[p + "mlp.gate_up_proj.weight"], T, 2 * self.I, self.h, H.FEPI_SILU_FRAG,
@@ -336,9 +337,9 @@ class HipDecoder:
                               res_in=self.buf_res, res_out=self.buf_res, out_frag=self.buf_xf)
             self._gemm(self.buf_xf, self.h, w[p + "mlp.gate_up_proj.weight"], 2 * self.I, self.buf_actf, T, 0, epi=H.EPI_SILU_FRAG)
 
-    def launch_down(self, li: int, T: int) -> None:
+    def launch_down(self, li: int, T: int, parts: bool | None = None) -> None:
         w = self.w[f"model.layers.{li}.mlp.down_proj.weight"]
-        if self.parts_plan(T):
+        if self.parts_plan(T) if parts is None else parts:
             S, wv = self._parts("d", T)
             H.gemm_parts(self.buf_actf, w, T, self.h, self.I, parts=self.buf_parts_d, splits=S, waves=wv)
         else:
@@ -353,8 +354,10 @@ class HipDecoder:
         self._allreduce(h[:T])
         splits, attn_waves = self._attn_cfg(T, meta)
         scale = self.hd ** -0.5
-        self._fwd_T = T          # compute_logits must know whether the last down_proj left rows or partial slabs
-        self._in_prefill = meta.cu_q is not None
+        # a varlen prefill never takes the slab path (its last-token gather reads rows); compute_logits, which always follows
+        # in the same Python body, must know whether the last down_proj left rows or partial slabs
+        parts = self.parts_plan(T) and meta.cu_q is None
+        self._fwd_T, self._last_parts = T, parts
         # tensor parallel with the one-shot collective: the all-reduce after o_proj / down_proj absorbs the residual add
         # and the RMSNorm that follow it (csrc/comm.hip), 2 launches fewer per half layer
         ar = self.custom_ar
@@ -362,19 +365,19 @@ class HipDecoder:
         eps, res, xf = cfg.rms_norm_eps, self.buf_res, self.buf_xf
         L = cfg.num_layers
         for li in range(L):
-            self.launch_qkv(li, T, positions, meta.slot_mapping, pre_normed=fuse and li > 0)
+            self.launch_qkv(li, T, positions, meta.slot_mapping, pre_normed=fuse and li > 0, parts=parts)
             H.attn_paged(self.buf_q, self.kv_cache[li, 0], self.kv_cache[li, 1], meta.block_tables, self.max_blocks,
                          meta.context_lens, meta.B, T, meta.max_q, self.nh, self.nkv, self.hd, self.block_size, scale,
                          cu_q=meta.cu_q, q_per_seq=meta.q_per_seq, mode=meta.mode, tree_K=meta.tree_K, tree_mq=meta.tree_mq,
                          tree_step=meta.tree_step, tree_F=meta.tree_F, tree_jidx=meta.tree_jidx, splits=splits,
                          ws_o=self.ws_o, ws_ml=self.ws_ml, out_frag=self.buf_af, waves=attn_waves)
-            self.launch_o(li, T)
+            self.launch_o(li, T, parts=parts)
             if fuse:
                 ar.all_reduce_add_rmsnorm(h, res, res, w[f"model.layers.{li}.post_attention_layernorm.weight"], eps, T, self.h, out_frag=xf)
             else:
                 self._allreduce(h[:T])
-            self.launch_gate_up(li, T, pre_normed=fuse)
-            self.launch_down(li, T)
+            self.launch_gate_up(li, T, pre_normed=fuse, parts=parts)
+            self.launch_down(li, T, parts=parts)
             if fuse and li + 1 < L:
                 ar.all_reduce_add_rmsnorm(h, res, res, w[f"model.layers.{li + 1}.input_layernorm.weight"], eps, T, self.h, out_frag=xf)
             else:
@@ -385,7 +388,7 @@ class HipDecoder:
         LM-head GEMM into self.logits[:rows] (this rank's vocab shard).  Returns the number of logit rows."""
         n = T if gather is None else rows
         assert n <= self.max_logit_rows
-        if self.parts_plan(getattr(self, "_fwd_T", 1 << 30)):
+        if self._last_parts:
             assert gather is None and n == self._fwd_T
             H.rmsnorm_parts(self.buf_parts_d, self._parts("d", n)[0], n, self.w["model.norm.weight"], self.cfg.rms_norm_eps, n, self.h,
                             res_in=self.buf_res, out_frag=self.buf_lastf)

@@ -144,3 +144,41 @@ def test_fused_norm_gateup_silu(H, M, K, I):
         H.gemm_fused(wf2, M, I, K, H.FEPI_ROWS, h_rows=dev(h), res_in=dev(res), norm_w=dev(nw), eps=1e-6, y=y, ldy=I, nt=nt,
                      waves=waves)
         assert_close_bf16(y, y_ref, max_ulp=1, max_frac=0.04, rel_floor=2 ** -7, what=f"fused rows {nt},{waves}")
+
+
+@pytest.mark.parametrize("M,nh,nkv,hd,K", [(24, 32, 8, 64, 2048), (17, 8, 2, 128, 1024), (32, 16, 8, 128, 1024), (24, 4, 4, 64, 96)])
+def test_fused_qkv_rope_two_token_tiles(H, M, nh, nkv, hd, K):
+    """17..32 token rows (the 24-branch tree-decode step): QKV GEMM + RoPE + paged KV store in one launch over two
+    16-row token tiles (csrc/gemm_fused.hip gemm_qkv_rope_m32_kernel) vs the oracle chain linear -> RoPE -> store."""
+    torch.manual_seed(M + K)
+    bs, nb = 16, 8
+    N = (nh + 2 * nkv) * hd
+    x = torch.randn(M, K).to(BF)
+    w = (torch.randn(N, K) * 0.05).to(BF)
+    bias = (torch.randn(N) * 0.1).to(BF)
+    pos = torch.randint(0, 300, (M,), dtype=torch.int64)
+    slots = torch.randperm(nb * bs)[:M].to(torch.int32)
+    slots[5] = -1
+    cache = O.make_cos_sin_cache(hd, 512, 5e5)
+    qkv = O.linear(x, w, bias)
+    q, k, v = qkv.split([nh * hd, nkv * hd, nkv * hd], dim=-1)
+    q, k = O.rope(pos, q.contiguous(), k.contiguous(), cache, hd)
+    kref = torch.zeros(nb, bs, nkv, hd, dtype=BF)
+    vref = torch.zeros_like(kref)
+    O.store_kv(k.view(M, nkv, hd), v.contiguous().view(M, nkv, hd), kref, vref, slots)
+    wf = torch.zeros(w.numel(), dtype=BF, device="cuda")
+    H.rows_to_frag_qkv(dev(w), wf, nh, nkv, hd, K)
+    bias_p = dev(bias[qkv_perm(nh, nkv, hd)])
+    tol = dict(max_ulp=1, max_frac=0.04, rel_floor=2 ** -7,
+               abs_floor=float(2.0 ** (math.floor(math.log2(max(q.abs().max().item(), 1e-3))) - 7)))
+    for nt, waves in ((0, 0), (1, 4), (2, 8), (1, 16)):
+        if nt and (N // 16) % nt:
+            continue
+        q_out = torch.zeros(M, nh * hd, dtype=BF, device="cuda")
+        kc = torch.zeros(nb, nkv, bs, hd, dtype=BF, device="cuda")
+        vc = torch.zeros_like(kc)
+        H.gemm_fused(wf, M, N, K, H.FEPI_QKV_ROPE, x_frag=dev(LY.rows_to_frag_ref(x)), bias=bias_p, positions=dev(pos), cos_sin=dev(cache),
+                     slots=dev(slots), q_out=q_out, k_cache=kc, v_cache=vc, nh=nh, nkv=nkv, hd=hd, block_size=bs, nt=nt, waves=waves)
+        assert_close_bf16(q_out, q, what=f"m32 q nt{nt} w{waves}", **tol)
+        assert_close_bf16(LY.kv_hnd_to_nhd(kc.cpu()), kref, what=f"m32 k nt{nt} w{waves}", **tol)
+        assert_close_bf16(LY.kv_hnd_to_nhd(vc.cpu()), vref, what=f"m32 v nt{nt} w{waves}", max_ulp=1, max_frac=0.04, rel_floor=2 ** -7)
