@@ -229,6 +229,12 @@ int ssd_allreduce_add_rmsnorm_bf16(const void* in, const void* res_in, void* res
                                    void* const* flags, long slot_elems, void* counters, void* err, long spin_budget,
                                    void* stream);
 
+/* A stream restricted to the compute units whose bit is set in cu_mask (bit i of word i/32 = CU i): partitions the chip
+ * between the co-located draft server and the target's verify of asynchronous speculation (the reference gives the draft
+ * a GPU of its own, ssd/engine/llm_engine.py:82-89; on one GPU the two rounds otherwise serialise).  Start-up only. */
+int ssd_stream_create_cu_mask(void** out_stream, const uint32_t* cu_mask, int mask_words);
+int ssd_stream_destroy(void* stream);
+
 #ifdef __cplusplus
 }
 #endif

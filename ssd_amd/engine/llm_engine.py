@@ -91,6 +91,7 @@ class LLMEngine:
         factory = runner_factory or hip_runner_factory
 
         self.draft_runner = None
+        self._target_stream = None
         self.async_link = None
         self.draft_server = None
         if self.topo.role == "draft":               # dedicated draft GPU of async speculation
@@ -132,6 +133,15 @@ class LLMEngine:
                 # co-located draft: its own stream, next-round work parked until the target's verify is in flight
                 on_gpu = self.topo.device.type == "cuda"
                 side = torch.cuda.Stream(self.topo.device) if on_gpu and os.environ.get("SSD_COLOCATED_OVERLAP", "1") != "0" else None
+                # SSD_COLOCATED_CUS = n: partition the chip -- the draft server's stream gets n compute units, the target's
+                # steps run on a stream confined to the others (ssd_stream_create_cu_mask) -- so that the speculation tree
+                # is decoded WHILE the verify streams its weights instead of in the gaps between its kernels
+                ncu = int(os.environ.get("SSD_COLOCATED_CUS", "0")) if side is not None else 0
+                if ncu > 0:
+                    from ssd_amd.hip.ops import masked_stream
+                    total = torch.cuda.get_device_properties(self.topo.device).multi_processor_count
+                    side = masked_stream(self.topo.device, 0, ncu)
+                    self._target_stream = masked_stream(self.topo.device, ncu, total)
                 self.draft_server = DraftServer(config, self.draft_runner, server_end, stream=side, deferred=side is not None)
                 if side is not None:
                     self.model_runner.overlap_hook = self.draft_server.run_deferred
@@ -157,6 +167,9 @@ class LLMEngine:
         self.scheduler.add(Sequence(prompt, sampling_params))
 
     def step(self, step: InferenceStep):
+        if self._target_stream is not None and torch.cuda.current_stream(self.topo.device) != self._target_stream:
+            with torch.cuda.stream(self._target_stream):
+                return self.step(step)
         t = perf_counter()
         seqs, is_prefill = self.scheduler.schedule()
         n = step.prefill(seqs) if is_prefill else step.decode(seqs)
