@@ -133,9 +133,12 @@ class LLMEngine:
                 # co-located draft: its own stream, next-round work parked until the target's verify is in flight
                 on_gpu = self.topo.device.type == "cuda"
                 side = torch.cuda.Stream(self.topo.device) if on_gpu and os.environ.get("SSD_COLOCATED_OVERLAP", "1") != "0" else None
-                # SSD_COLOCATED_CUS = n: partition the chip -- the draft server's stream gets n compute units, the target's
-                # steps run on a stream confined to the others (ssd_stream_create_cu_mask) -- so that the speculation tree
-                # is decoded WHILE the verify streams its weights instead of in the gaps between its kernels
+                # SSD_COLOCATED_CUS = n (experimental, default off): partition the chip -- the draft server's stream gets n
+                # compute units, the target's steps run on a stream confined to the others (ssd_stream_create_cu_mask) -- so
+                # that the speculation tree is decoded WHILE the verify streams its weights instead of in the gaps between
+                # its kernels.  Measured on MI355X (70B + 1B, k=7 f=3): 30.5 ms/step unpartitioned vs 38.5 / 37.0 / 36.2 ms
+                # with 32 / 64 / 96 draft CUs: the target's launches are sized for 256 CUs (224-256 workgroups of 16 waves),
+                # so on fewer CUs every one of them takes a second, nearly empty round (profiles/r02_cu_partition.txt).
                 ncu = int(os.environ.get("SSD_COLOCATED_CUS", "0")) if side is not None else 0
                 if ncu > 0:
                     from ssd_amd.hip.ops import masked_stream
