@@ -266,6 +266,9 @@ extern "C" int ssd_gemm_wf(const void* x_frag, const void* w_frag, const void* b
   while (waves > 1 && KT / waves < 4) waves >>= 1;
   const int blocks = groups / nt;
   if (blocks >= 1024 && waves > 8) waves = 8;
+  // two token tiles (the 24-branch tree step) on a mid-sized matrix: 4 waves x 16 k-tiles beat 16 x 4 (1B gate_up at M = 24:
+  // 16.2 -> 13.4 us, profiles/r02_tune_1b.txt) -- more workgroups resident per CU, fewer partials to combine
+  if (mt == 2 && blocks >= 512 && blocks < 2048 && waves > 4 && KT / 4 >= 4) waves = 4;
   if (mt >= 4 && waves > 8) waves = 8;  // LDS for the combine: waves*nt*mt KiB
   if (mt >= 8 && waves > 4) waves = 4;
   return ssd_gemm_wf_cfg(x_frag, w_frag, bias, y, M, N, K, ldy, epilogue, nt, waves, stream);

@@ -96,11 +96,15 @@ class HipDecoder:
         self.buf_lastf = z(H.frag_numel(self.max_logit_rows, self.h))
         # split-K partial slabs of o_proj / down_proj for models whose hidden size gives too few 16-row groups to fill
         # the chip (csrc/gemm_sk.hip gemm_sp_kernel): fp32 [S][T][h], summed by the consumer's prologue / ssd_rmsnorm_parts
-        self.use_parts = os.environ.get("SSD_PARTS", "1") != "0" and (self.h // 16) < 256
+        # (< 256 row groups: the 1B / 0.6B drafts; 256 < groups < 512: a quarter-empty second round of workgroups --
+        # Qwen3-32B o_proj 20.6 -> 15.6 us, down_proj 58.1 -> 48.1 us at 16 splits, profiles/r02_parts_probe.txt; at exactly
+        # 256 or >= 512 groups the rows kernels are as fast or faster)
+        g_ = self.h // 16
+        self.use_parts = os.environ.get("SSD_PARTS", "1") != "0" and (g_ < 256 or 256 < g_ < 512)
         self._last_parts = False        # set by forward() for the compute_logits that follows it
         pt = min(T, 32)
-        self.buf_parts_o = z(4 * pt * self.h, dtype=torch.float32) if self.use_parts else None
-        self.buf_parts_d = z(4 * pt * self.h, dtype=torch.float32) if self.use_parts else None
+        self.buf_parts_o = z(16 * pt * self.h, dtype=torch.float32) if self.use_parts else None
+        self.buf_parts_d = z(16 * pt * self.h, dtype=torch.float32) if self.use_parts else None
         self.logits = z(self.max_logit_rows, self.V)
         self.max_splits = 16
         self._ws_pf = None           # fp32 split-K partials of the prefill GEMM, allocated by the first prefill
@@ -238,9 +242,9 @@ class HipDecoder:
         norm + GEMM prologue (every workgroup of the NEXT kernel re-reads the slabs) two slabs are the optimum: a third
         and fourth cost the consumers more than they save here."""
         groups, KT = N // 16, K // 32
-        smax = 2 if fused_consumer else 4
+        smax = 2 if fused_consumer else (16 if groups > 256 else 4)
         S = 1
-        while groups * S < 512 and S < smax and KT // (S * 2) >= 8:
+        while groups * S < (5120 if groups > 256 else 512) and S < smax and KT // (S * 2) >= 8:
             S *= 2
         per = -(-KT // S)
         waves = 16 if fused_consumer else 8
