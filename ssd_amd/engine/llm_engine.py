@@ -132,7 +132,11 @@ class LLMEngine:
                                             memory_utilization=0.75, num_kvcache_blocks=config.num_draft_kvcache_blocks)
                 # co-located draft: its own stream, next-round work parked until the target's verify is in flight
                 on_gpu = self.topo.device.type == "cuda"
-                side = torch.cuda.Stream(self.topo.device) if on_gpu and os.environ.get("SSD_COLOCATED_OVERLAP", "1") != "0" else None
+                # (stream priority: -1 = high.  The draft's ~900 small dependent kernels per round are latency chains; with
+                # priority they are dispatched as soon as a CU has room beside the target's 8-wave workgroups)
+                prio = int(os.environ.get("SSD_COLOCATED_PRIORITY", "0"))
+                side = (torch.cuda.Stream(self.topo.device, priority=prio)
+                        if on_gpu and os.environ.get("SSD_COLOCATED_OVERLAP", "1") != "0" else None)
                 # SSD_COLOCATED_CUS = n (experimental, default off): partition the chip -- the draft server's stream gets n
                 # compute units, the target's steps run on a stream confined to the others (ssd_stream_create_cu_mask) -- so
                 # that the speculation tree is decoded WHILE the verify streams its weights instead of in the gaps between
