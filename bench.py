@@ -159,7 +159,7 @@ def gemm_roofline(legs):
                 t = json.load(f)
             out["traffic"] = int(tot_bytes / tot_launch * t["gemm_traffic_over_algorithmic"])
             out["traffic_source"] = t.get("source", fn)
-            if "mfma_util" in t and "per_kernel" in t["mfma_util"]:
+            if "mfma_util" in t and "per_kernel" in t["mfma_util"] and any(r.cfg.hidden_size == 8192 for r, _, _ in legs if r is not None):
                 # north_star: "rocprof HBM GB/s and MFMA utilisation against gfx950 peak" -- the separate counter pass of
                 # profiles/collect_r02.sh (MfmaUtil / VALUBusy per kernel); the dominant kernel = the 70B gate_up GEMM
                 pk = t["mfma_util"]["per_kernel"]

@@ -198,7 +198,7 @@ def test_correlated_pair_recipe_gives_partial_acceptance():
     assert 0.0 < sum(m2["cache_hits"]) / len(m2["cache_hits"]) <= 1.0
 
 
-def _worker_draft_dp(rank, world, port, q, temperature):
+def _worker_draft_dp(rank, world, port, q, temperature, extra=None):
     """1 target rank + (world - 1) draft ranks (draft data-parallel): branches and speculation cache sharded."""
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -210,7 +210,7 @@ def _worker_draft_dp(rank, world, port, q, temperature):
     t, d = cfgs()
     eng = LLMEngine("t", hf_config=t, runner_factory=oracle_runner_factory(), num_gpus=world, num_draft_gpus=world - 1, draft="d",
                     draft_hf_config=t, draft_weights_seed=0, speculate=True, speculate_k=3, draft_async=True, async_fan_out=2,
-                    jit_speculate=True, max_num_seqs=2, **KW)
+                    max_num_seqs=2, **dict(dict(jit_speculate=True), **(extra or {})), **KW)
     out, m = eng.generate(PROMPTS, SamplingParams(temperature=temperature, max_new_tokens=14, ignore_eos=True), use_tqdm=False)
     stats = eng.draft_server.stats if eng.draft_server is not None else None
     eng.exit()
@@ -220,11 +220,11 @@ def _worker_draft_dp(rank, world, port, q, temperature):
     dist.destroy_process_group()
 
 
-def _run_draft_dp(world, temperature=0.0):
+def _run_draft_dp(world, temperature=0.0, extra=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + (os.getpid() % 90) + world
-    ps = [ctx.Process(target=_worker_draft_dp, args=(r, world, port, q, temperature)) for r in range(world)]
+    port = 29700 + (os.getpid() % 90) + world + (7 if extra else 0)
+    ps = [ctx.Process(target=_worker_draft_dp, args=(r, world, port, q, temperature, extra)) for r in range(world)]
     for p in ps:
         p.start()
     got = {}
@@ -260,3 +260,16 @@ def test_draft_data_parallel_with_sampling():
     lens = got[0][2]
     assert all(len(t) == 14 for t in got[0][0])
     assert all(n == 4 for n in lens[:-2]), lens
+
+
+def test_draft_data_parallel_uneven_shards_and_fast_backup():
+    """Non-uniform fan-out lists whose branch count (9) does not divide over the 2 draft ranks (5 + 4 branches), and the
+    "fast" backup (no JIT chain on a miss): still the exact autoregressive stream, same hits as a single draft rank."""
+    fan = dict(fan_out_list=[1, 2, 2, 4], fan_out_list_miss=[3, 2, 2, 2])
+    ar, _, _ = run("ar", bs=2)
+    for extra in (fan, dict(fan, jit_speculate=False)):
+        single, m1, _ = run("async", bs=2, same=True, fan=fan["fan_out_list"], fan_miss=fan["fan_out_list_miss"],
+                            jit=extra.get("jit_speculate", True))
+        got = _run_draft_dp(3, extra=extra)
+        assert got[0][0] == ar == single
+        assert got[0][1] == m1["cache_hits"], (got[0][1], m1["cache_hits"])
