@@ -74,6 +74,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--ttft-samples", type=int, default=3)
+    ap.add_argument("--ref-seqs", type=int, default=2, help="sequences of the reference-protocol run (512 output tokens each); 0 = skip")
+    ap.add_argument("--ref-output-len", type=int, default=512)
     return ap.parse_args(argv)
 
 
@@ -332,13 +334,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=tp_group)
         dt = float(t.item())
         dist.barrier(group=tp_group)
-    lens = METRICS["accepted_suffix_lens_with_recovery"][n0:]
-    hits = METRICS["cache_hits"][h0:]
-    tokens = sum(lens)
-    ms_step = dt / args.steps * 1e3
+    lens = list(METRICS["accepted_suffix_lens_with_recovery"][n0:])
+    hits = list(METRICS["cache_hits"][h0:])
     seq = engine.scheduler.running[0] if engine.scheduler.running else None
     ctx = len(seq) if seq is not None else args.input_len
-
+    # ---- the reference's own protocol (bench/bench.py:34-51,233-235,351-352): random 128-token prompts, 512 output tokens,
+    #      b = 1, temp 0; throughput = output tokens / wall clock of generate() (prefill included) and the decode-only rate
+    #      (llm_engine.py:215-223).  Context grows 128 -> 640 here, where the timed steps above sit at ~130-300. ----
+    ref = None
+    if args.ref_seqs > 0:
+        engine.abort_all()                       # the timed request is not run to its end
+        random.seed(1)
+        rp = [[random.randint(0, 10000) for _ in range(args.input_len)] for _ in range(args.ref_seqs)]
+        sync_all()
+        t1 = time.perf_counter()
+        outs, m = engine.generate(rp, SamplingParams(temperature=0, ignore_eos=True, max_new_tokens=args.ref_output_len), use_tqdm=False)
+        torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t1
+        rl = m["accepted_suffix_lens_with_recovery"]
+        rh = m["cache_hits"]
+        ntok = sum(len(o["token_ids"]) for o in outs)
+        ref = {"protocol": f"reference bench/bench.py: {args.ref_seqs} x ({args.input_len}-token random prompt -> {args.ref_output_len} output tokens), b=1, temp 0",
+               "tokens_per_s_total": round(ntok / wall, 2),
+               "tokens_per_s_decode": round(m["decode_total_tokens"] / m["decode_total_time"], 2) if m["decode_total_time"] else None,
+               "mean_accepted_len": round(sum(rl) / max(1, len(rl)), 4),
+               "cache_hit_rate": round(sum(rh) / len(rh), 4) if rh else None,
+               "ms_per_step": round(1e3 * m["decode_total_time"] / max(1, len(rl)), 4), "final_context": args.input_len + args.ref_output_len}
+    tokens = sum(lens)
+    ms_step = dt / args.steps * 1e3
     tm = engine.model_runner.model
     dr = engine.draft_runner                # None on ranks that do not host the draft
     tb = tm.weight_bytes()
@@ -379,6 +402,7 @@ def main():
         "step_hbm_bytes_per_gpu": int(step_bytes),
         "step_roofline_frac": round(step_bytes / (dt / args.steps) / HBM_PEAK, 4),
         "tokens_per_s_at_accepted_len": {str(a): round(a / (dt / args.steps), 1) for a in (1, 2, 4, K + 1)},
+        "reference_protocol": ref,
     }
     if not args.no_roofline:          # every rank launches the same sequence (shard shapes); rank 0 reports
         with torch.inference_mode():      # the engine's buffers are inference tensors (ModelRunner runs under inference_mode)

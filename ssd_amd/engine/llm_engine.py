@@ -192,6 +192,16 @@ class LLMEngine:
     def is_finished(self) -> bool:
         return self.scheduler.is_finished()
 
+    def abort_all(self) -> None:
+        """Drop every queued / running request and return its KV blocks (benchmarks that stop a request mid-generation)."""
+        sch = self.scheduler
+        for seq in list(sch.running):
+            sch.block_manager.deallocate(seq)
+            if sch.draft_block_manager is not None:
+                sch.draft_block_manager.deallocate(seq)
+        sch.running.clear()
+        sch.waiting.clear()
+
     def create_inference_step(self, config: Config) -> InferenceStep:
         if not config.speculate:
             return AutoRegressiveStep(self.scheduler, self.model_runner, self.tokenizer)

@@ -14,7 +14,7 @@ import torch
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-        "dtype", "data", "config", "mean_accepted_len", "cache_hit_rate", "ttft_p50_ms", "roofline", "cpu_baseline"}
+        "dtype", "data", "config", "mean_accepted_len", "cache_hit_rate", "ttft_p50_ms", "roofline", "cpu_baseline", "reference_protocol"}
 
 
 def bench(*flags, shared_gpu=False):
@@ -38,6 +38,9 @@ def check(line, n):
     assert r["bound"] == "hbm" and 0 < r["frac"] < 1.0 and r["achieved"] > 0 and r["peak"] == 8000.0
     assert line["cpu_baseline"]["value"] and line["cpu_baseline"]["cores"] >= 1, line["cpu_baseline"]
     assert "workload" in line["config"]
+    rp = line["reference_protocol"]          # the reference's own bench protocol: 128-token prompts -> 512 output tokens
+    assert rp["tokens_per_s_total"] > 0 and rp["tokens_per_s_decode"] >= rp["tokens_per_s_total"] and rp["final_context"] == 640
+    assert 1.0 <= rp["mean_accepted_len"] <= 8.0
 
 
 def test_bench_self_launches_at_every_n():
