@@ -138,3 +138,28 @@ def test_temperature_mixed_batch_and_greedy_draft():
     assert got[0]["token_ids"] == ref[0]["token_ids"]
     assert all(len(o["token_ids"]) == 12 for o in got)
     assert all(0 <= t < cfg.vocab_size for o in got for t in o["token_ids"])
+
+
+def test_abort_all_returns_blocks_and_engine_stays_usable():
+    """LLMEngine.abort_all (used by bench.py between its step timing and the reference-protocol run): every KV block of the
+    dropped request returns to both pools and a following generate() is unaffected."""
+    from oracle.runner import oracle_runner_factory
+    from ssd_amd.engine.llm_engine import LLMEngine
+    from ssd_amd.model_config import ModelConfig
+    from ssd_amd.sampling_params import SamplingParams
+    t = ModelConfig("llama", 64, 2, 4, 2, 32, 128, 256, 1e-5, 5e5, 1024, False)
+    kw = dict(hf_config=t, max_model_len=512, max_num_batched_tokens=512, kvcache_block_size=32, num_kvcache_blocks=48, weights_std=0.1)
+    sp = SamplingParams(temperature=0, ignore_eos=True, max_new_tokens=12)
+    ref, _ = LLMEngine("t", runner_factory=oracle_runner_factory(), **kw).generate([[1, 2, 3, 4, 5]], sp, use_tqdm=False)
+    eng = LLMEngine("t", runner_factory=oracle_runner_factory(), draft="d", draft_hf_config=t, draft_weights_seed=0, speculate=True,
+                    speculate_k=3, num_draft_kvcache_blocks=48, **kw)
+    eng.add_request([9, 8, 7, 6, 5, 4], SamplingParams(temperature=0, ignore_eos=True, max_new_tokens=100))
+    step = eng.create_inference_step(eng.config)
+    for _ in range(4):
+        eng.step(step)
+    assert not eng.is_finished()
+    eng.abort_all()
+    assert eng.is_finished()
+    assert len(eng.scheduler.block_manager.free_block_ids) == 48 and len(eng.scheduler.draft_block_manager.free_block_ids) == 48
+    out, _ = eng.generate([[1, 2, 3, 4, 5]], sp, use_tqdm=False)
+    assert out[0]["token_ids"] == ref[0]["token_ids"]
