@@ -12,12 +12,12 @@ Workload (``--workload``):
   c4   (default; the configuration BASELINE.json's metric is quoted on) Llama-3.1-70B shapes as target + Llama-3.2-1B
        shapes as draft, ASYNCHRONOUS speculation ("SSD") k = 7, fan-out f = 3, b = 1, temp 0, 128-token prompt, KV block
        256, max_model_len 8192, jit backup on a speculation-cache miss (reference README.md:96-97, bench/bench.py:34-51).
-       Placement: ``colocated`` (default) -- the target is tensor-parallel over all N GPUs (139 GB of bf16 weights fit
-       one 288 GB MI355X, so N = 1 is the same model) and the draft server shares TP rank 0's GPU on its own HIP stream,
-       pre-computing the next round's speculation tree while the verify runs; ``dedicated`` (``--placement dedicated``,
-       N - 1 a power of two) -- the draft has the last GPU to itself and talks to TP rank 0 over RCCL p2p (the
-       reference's 4 + 1 GPU layout is ``--gpus 5 --placement dedicated``); ``--draft-dp D`` gives the draft D GPUs that
-       shard the speculation tree (``--gpus 8 --placement dedicated --draft-dp 4`` = BASELINE.json configs[4]'s layout).
+       Placement: ``colocated`` -- the target is tensor-parallel over all N GPUs (139 GB of bf16 weights fit one 288 GB
+       MI355X, so N = 1 is the same model) and the draft server shares TP rank 0's GPU on its own HIP stream, pre-computing
+       the next round's speculation tree while the verify runs; ``dedicated`` -- the last D GPUs (``--draft-dp D``; default:
+       all beyond the largest power-of-two target) are a draft group that talks to TP rank 0 over RCCL p2p and shards the
+       speculation tree D ways.  Default ``auto``: co-located for N <= 4, dedicated from N = 5 (N = 5: TP 4 + 1 draft GPU =
+       BASELINE.json configs[3], the reference's layout; N = 8: TP 4 + draft x4 data-parallel = configs[4]'s layout).
        Same total work at every N -> "strong".
   c3   the same pair, SYNCHRONOUS speculation k = 6 (BASELINE.json configs[2]); draft replicated on every rank.
   c2   Llama-3.1-8B target + 1B draft, sync k = 6 on one GPU (configs[1]).
@@ -64,8 +64,8 @@ def parse(argv=None):
     ap.add_argument("--workload", default="c4", choices=["c4", "c3", "c2", "c5t", "tiny", "tiny-async"])
     ap.add_argument("--k", type=int, default=None, help="speculation length (default: 7 async, 6 sync)")
     ap.add_argument("--f", type=int, default=3, help="async fan-out")
-    ap.add_argument("--placement", default="colocated", choices=["colocated", "dedicated"])
-    ap.add_argument("--draft-dp", type=int, default=1, help="dedicated placement: draft ranks (data-parallel tree shards)")
+    ap.add_argument("--placement", default="auto", choices=["auto", "colocated", "dedicated"])
+    ap.add_argument("--draft-dp", type=int, default=0, help="dedicated placement: draft ranks (data-parallel tree shards); 0 = all ranks beyond the target's")
     ap.add_argument("--pair", default="correlated", choices=["correlated", "random"])
     ap.add_argument("--pair-snr", type=float, default=8.0)
     ap.add_argument("--input-len", type=int, default=128)
@@ -275,8 +275,19 @@ def main():
         # LM-head GEMM streams a [V, h] matrix either way, so bytes and kernels are unchanged
         dcfg = dataclasses.replace(dcfg, tie_word_embeddings=False)
         recipe = {"kind": "pair", "shared": min(dcfg.hidden_size, tcfg.hidden_size), "snr": args.pair_snr, "layer_gain": 0.005}
-    dedicated = is_async and args.placement == "dedicated" and world > 1
-    ndraft = max(1, args.draft_dp) if dedicated else 1
+    # placement of the async draft.  auto: up to 4 GPUs every GPU is worth more as a tensor-parallel target rank (the draft
+    # server shares rank 0's GPU); from 5 GPUs on the reference's layout pays -- a 4-way tensor-parallel target + the remaining
+    # GPUs as a draft group (N = 5: BASELINE.json configs[3]; N = 8: configs[4]'s "draft x4 data-parallel"), whose tree round
+    # (MQ_LEN / D rows per step) then hides behind the verify instead of lengthening rank 0's step.
+    placement = args.placement
+    if placement == "auto":
+        placement = "dedicated" if (is_async and world >= 5) else "colocated"
+    dedicated = is_async and placement == "dedicated" and world > 1
+    if dedicated:
+        ndraft = args.draft_dp if args.draft_dp > 0 else max(1, world - (1 << ((world - 1).bit_length() - 1)))
+        ndraft = min(ndraft, world - 1)
+    else:
+        ndraft = 1
     tp = world - ndraft if dedicated else world
     assert tp >= 1 and tp & (tp - 1) == 0, f"target tensor-parallel degree {tp} must be a power of two" 
     kw = dict(hf_config=tcfg, draft=dname, draft_hf_config=dcfg, speculate=True, speculate_k=K, num_gpus=args.gpus,
