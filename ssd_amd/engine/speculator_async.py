@@ -49,6 +49,12 @@ class AsyncLink:
         payload = P.pack_prefill(token_lists, block_tables, self.max_blocks)
         self.tx.send_ints([P.CMD_PREFILL, len(token_lists), len(payload), 0])
         self.tx.send_ints(payload)
+        # co-located draft server (loopback transport): let it take the command NOW, so that its prefill is enqueued on the
+        # draft stream before the target's prefill starts (step.py:75-79: "draft and target prefill overlap") instead of
+        # at the first speculation request
+        pump = getattr(self.tx, "pump", None)
+        if pump is not None:
+            pump()
 
     def speculate(self, keys, num_tokens, block_tables, temps, want_logits: bool = False):
         """-> (hits, tokens, logits_q or None).  logits_q bf16 [B, K, V] is requested only when some temperature is
