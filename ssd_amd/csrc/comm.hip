@@ -99,9 +99,9 @@ allreduce_bf16_kernel(const unsigned long long* __restrict__ in, unsigned long l
 // (layernorm.py:76-88) cost per half layer become one.  A workgroup owns whole rows (the norm needs the full row), so
 // at most AR_BLOCKS workgroups read the peers' staged rows; per row the arithmetic and the reduction order are exactly
 // those of allreduce_bf16_kernel followed by rmsnorm_kernel (norm.hip) -- results are bit-identical to the unfused pair.
-constexpr int ARN_THREADS = 256;   // = NORM_THREADS: same chunk -> thread mapping, same sum-of-squares order
-constexpr int ARN_MAXC = 8;
-
+constexpr int ARN_MAXH = 16384;    // = NORM_MAXH; ARN_THREADS = ssd_norm_threads(H): same chunk -> thread mapping, same
+                                   // sum-of-squares order as rmsnorm_kernel<THREADS> (norm.hip)
+template <int ARN_THREADS>
 __global__ void __launch_bounds__(ARN_THREADS)
 allreduce_add_rmsnorm_kernel(const unsigned long long* __restrict__ in, const u32x4_t* __restrict__ res_in,
                              u32x4_t* __restrict__ res_out, const u32x4_t* __restrict__ w, float eps,
@@ -143,6 +143,7 @@ allreduce_add_rmsnorm_kernel(const unsigned long long* __restrict__ in, const u3
   __syncthreads();
   if (s_fail) return;
   for (int row = r0; row < r1; ++row) {
+    constexpr int ARN_MAXC = ARN_MAXH / 8 / ARN_THREADS;
     float v[ARN_MAXC][8];
     float ss = 0.f;
 #pragma unroll
@@ -271,7 +272,7 @@ extern "C" int ssd_allreduce_add_rmsnorm_bf16(const void* in, const void* res_in
                                               void* const* slots, void* const* flags, long slot_elems, void* counters,
                                               void* err, long spin_budget, void* stream) {
   if (world < 1 || world > AR_MAX_RANKS || rank < 0 || rank >= world || T <= 0 || H <= 0 || (H & 31) ||
-      H > ARN_THREADS * ARN_MAXC * 8 || (long)T * H > slot_elems)
+      H > ARN_MAXH || (long)T * H > slot_elems)
     return SSD_ERR_SHAPE;
   if (!in || !res_in || !res_out || !weight) return SSD_ERR_ARG;
   ArPeers peers;
@@ -279,9 +280,16 @@ extern "C" int ssd_allreduce_add_rmsnorm_bf16(const void* in, const void* res_in
     peers.slot[r] = (unsigned long long*)(r < world ? slots[r] : nullptr);
     peers.flags[r] = (unsigned int*)(r < world ? flags[r] : nullptr);
   }
-  hipLaunchKernelGGL(allreduce_add_rmsnorm_kernel, dim3(AR_BLOCKS), dim3(ARN_THREADS), 0, (hipStream_t)stream,
-                     (const unsigned long long*)in, (const u32x4_t*)res_in, (u32x4_t*)res_out, (const u32x4_t*)weight, eps,
-                     (u32x4_t*)out_rows, (u32x4_t*)out_frag, T, H, slot_elems / 4, peers, rank, world,
-                     (unsigned int*)counters, (unsigned int*)err, spin_budget);
+  if (ssd_norm_threads(H) == 1024) {
+    hipLaunchKernelGGL(allreduce_add_rmsnorm_kernel<1024>, dim3(AR_BLOCKS), dim3(1024), 0, (hipStream_t)stream,
+                       (const unsigned long long*)in, (const u32x4_t*)res_in, (u32x4_t*)res_out, (const u32x4_t*)weight, eps,
+                       (u32x4_t*)out_rows, (u32x4_t*)out_frag, T, H, slot_elems / 4, peers, rank, world,
+                       (unsigned int*)counters, (unsigned int*)err, spin_budget);
+  } else {
+    hipLaunchKernelGGL(allreduce_add_rmsnorm_kernel<256>, dim3(AR_BLOCKS), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned long long*)in, (const u32x4_t*)res_in, (u32x4_t*)res_out, (const u32x4_t*)weight, eps,
+                       (u32x4_t*)out_rows, (u32x4_t*)out_frag, T, H, slot_elems / 4, peers, rank, world,
+                       (unsigned int*)counters, (unsigned int*)err, spin_budget);
+  }
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }

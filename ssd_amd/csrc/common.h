@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits (row-major tensors are passed as plain pointers)
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -55,6 +56,16 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
+}
+
+// Threads per row of the RMSNorm kernels (norm.hip rmsnorm_kernel and comm.hip allreduce_add_rmsnorm_kernel MUST agree: the
+// chunk -> thread mapping fixes the fp32 summation order, and the fused all-reduce + norm is bit-identical to the unfused
+// pair).  A row is a latency chain (load, reduce, scale, store): hidden sizes >= 4096 get 1024 threads, i.e. at most two
+// 8-element chunks per thread instead of four to eight (profiles/r02_norm_probe.txt).
+static inline int ssd_norm_threads(int H) {
+  static const int forced = [] { const char* e = getenv("SSD_NORM_THREADS"); return e ? atoi(e) : 0; }();   // tuning override
+  if (forced == 256 || forced == 1024) return forced;
+  return H >= 4096 ? 1024 : 256;
 }
 
 // Default decomposition of the skinny (M <= 16 token rows) weight-streaming GEMMs, from the MI355X sweep in

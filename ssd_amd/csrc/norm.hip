@@ -29,9 +29,9 @@ extern "C" int ssd_embedding(const int64_t* ids, const void* table, void* out_ro
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
-constexpr int NORM_THREADS = 256;
-constexpr int NORM_MAXC = 8;  // chunks of 8 elements per thread -> H <= 256*8*8 = 16384
+constexpr int NORM_MAXH = 16384;   // chunks of 8 elements: 256 threads x 8 chunks, or 1024 x 2
 
+template <int NORM_THREADS>
 __global__ void __launch_bounds__(NORM_THREADS)
 rmsnorm_kernel(const u32x4_t* __restrict__ x, const u32x4_t* __restrict__ res_in, u32x4_t* __restrict__ res_out,
                const u32x4_t* __restrict__ w, float eps, u32x4_t* __restrict__ out_rows,
@@ -42,6 +42,7 @@ rmsnorm_kernel(const u32x4_t* __restrict__ x, const u32x4_t* __restrict__ res_in
   const int row_in = gather ? gather[row_out] : row_out;
   const int H8 = H >> 3;
   const int KT = H >> 5;
+  constexpr int NORM_MAXC = NORM_MAXH / 8 / NORM_THREADS;
   float v[NORM_MAXC][8];
   float ss = 0.f;
 #pragma unroll
@@ -101,10 +102,15 @@ rmsnorm_kernel(const u32x4_t* __restrict__ x, const u32x4_t* __restrict__ res_in
 
 extern "C" int ssd_rmsnorm(const void* x_rows, const void* res_in, void* res_out, const void* weight, float eps,
                            void* out_rows, void* out_frag, const int32_t* gather_rows, int T, int H, void* stream) {
-  if (T <= 0 || H <= 0 || (H & 31) || H > NORM_THREADS * NORM_MAXC * 8) return SSD_ERR_SHAPE;
-  hipLaunchKernelGGL(rmsnorm_kernel, dim3(T), dim3(NORM_THREADS), 0, (hipStream_t)stream, (const u32x4_t*)x_rows,
-                     (const u32x4_t*)res_in, (u32x4_t*)res_out, (const u32x4_t*)weight, eps, (u32x4_t*)out_rows,
-                     (u32x4_t*)out_frag, gather_rows, H, (const float*)nullptr, 0, 0);
+  if (T <= 0 || H <= 0 || (H & 31) || H > NORM_MAXH) return SSD_ERR_SHAPE;
+  if (ssd_norm_threads(H) == 1024)
+    hipLaunchKernelGGL(rmsnorm_kernel<1024>, dim3(T), dim3(1024), 0, (hipStream_t)stream, (const u32x4_t*)x_rows,
+                       (const u32x4_t*)res_in, (u32x4_t*)res_out, (const u32x4_t*)weight, eps, (u32x4_t*)out_rows,
+                       (u32x4_t*)out_frag, gather_rows, H, (const float*)nullptr, 0, 0);
+  else
+    hipLaunchKernelGGL(rmsnorm_kernel<256>, dim3(T), dim3(256), 0, (hipStream_t)stream, (const u32x4_t*)x_rows,
+                       (const u32x4_t*)res_in, (u32x4_t*)res_out, (const u32x4_t*)weight, eps, (u32x4_t*)out_rows,
+                       (u32x4_t*)out_frag, gather_rows, H, (const float*)nullptr, 0, 0);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
@@ -112,10 +118,15 @@ extern "C" int ssd_rmsnorm(const void* x_rows, const void* res_in, void* res_out
 // x = bf16(sum over the slabs in order), then exactly ssd_rmsnorm.
 extern "C" int ssd_rmsnorm_parts(const void* parts, int splits, int slab_rows, const void* res_in, void* res_out,
                                  const void* weight, float eps, void* out_rows, void* out_frag, int T, int H, void* stream) {
-  if (T <= 0 || H <= 0 || (H & 31) || H > NORM_THREADS * NORM_MAXC * 8 || splits < 1 || splits > 16 || slab_rows < T) return SSD_ERR_SHAPE;
+  if (T <= 0 || H <= 0 || (H & 31) || H > NORM_MAXH || splits < 1 || splits > 16 || slab_rows < T) return SSD_ERR_SHAPE;
   if (!parts) return SSD_ERR_ARG;
-  hipLaunchKernelGGL(rmsnorm_kernel, dim3(T), dim3(NORM_THREADS), 0, (hipStream_t)stream, (const u32x4_t*)nullptr,
-                     (const u32x4_t*)res_in, (u32x4_t*)res_out, (const u32x4_t*)weight, eps, (u32x4_t*)out_rows,
-                     (u32x4_t*)out_frag, (const int32_t*)nullptr, H, (const float*)parts, splits, slab_rows);
+  if (ssd_norm_threads(H) == 1024)
+    hipLaunchKernelGGL(rmsnorm_kernel<1024>, dim3(T), dim3(1024), 0, (hipStream_t)stream, (const u32x4_t*)nullptr,
+                       (const u32x4_t*)res_in, (u32x4_t*)res_out, (const u32x4_t*)weight, eps, (u32x4_t*)out_rows,
+                       (u32x4_t*)out_frag, (const int32_t*)nullptr, H, (const float*)parts, splits, slab_rows);
+  else
+    hipLaunchKernelGGL(rmsnorm_kernel<256>, dim3(T), dim3(256), 0, (hipStream_t)stream, (const u32x4_t*)nullptr,
+                       (const u32x4_t*)res_in, (u32x4_t*)res_out, (const u32x4_t*)weight, eps, (u32x4_t*)out_rows,
+                       (u32x4_t*)out_frag, (const int32_t*)nullptr, H, (const float*)parts, splits, slab_rows);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
