@@ -21,6 +21,7 @@ from __future__ import annotations
 import torch
 
 from ssd_amd.engine import async_proto as P
+from ssd_amd.utils import profiling as prof
 
 
 def branch_positions(fan_out: list[int]) -> list[int]:
@@ -88,6 +89,9 @@ class DraftServer:
         self.pending_forks = None           # device tensor [B, MQ] of the round whose keys are not mirrored yet
         self.pending_meta = None
         self.stats = {"requests": 0, "hits": 0, "rounds": 0}
+        # SSD_PROFILE_DRAFT=1: device events around the reply and the two halves of the next round, printed at the NEXT
+        # request (reference draft_runner.py:880-915): the round itself gets no extra synchronisation
+        self._trace = prof.EventLog("draft") if prof.enabled("SSD_PROFILE_DRAFT") else None
 
     # ---- one command ----
     def run_deferred(self) -> None:
@@ -156,6 +160,9 @@ class DraftServer:
         dp = self.dp
         lead = dp is None or dp.rank == 0
         keys, num_tokens, tables, temps = P.unpack_speculate(payload, B, self.max_blocks)
+        if self._trace is not None:
+            self._trace.flush(f"round={self.stats['rounds']} hits={self.stats['hits']}/{self.stats['requests']}")
+            t_req = self._trace.mark()
         want_logits = bool(flags & P.FLAG_WANT_LOGITS)
         sample = any(t > 0 for t in temps)
         self._mirror_keys()
@@ -221,12 +228,16 @@ class DraftServer:
                 if logits_q is None:
                     logits_q = torch.zeros(B, K, self.runner.cfg.vocab_size, dtype=torch.bfloat16, device=tokens.device)
                 self.tx.send_tensor(logits_q)
+        if self._trace is not None:
+            self._trace.span("lookup_reply" if serve_from_cache or not jit else "jit_reply", t_req, self._trace.mark())
         # ---- from here on the target is verifying; pre-compute the next round's cache ----
         def next_round():
+            t_a = self._trace.mark() if self._trace is not None else None
             fan = [self.config.fan_out_list if h else self.config.fan_out_list_miss for h in hits]
             jl = [self.j_hit if h else self.j_miss for h in hits]
             glue_ids = torch.cat([torch.tensor(rec, dtype=torch.int64, device=tokens.device).unsqueeze(1), tokens], dim=1)
             forks = self.runner.draft_glue_fork(glue_ids, num_tokens, tables, fan)          # [B, MQ] (replicated under DP)
+            t_b = self._trace.mark() if self._trace is not None else None
             if dp is not None:          # my slice of the branches: K tree steps of MQ/D rows instead of MQ
                 lo, hi = dp.shard(self.mq)
                 forks = forks[:, lo:hi].contiguous()
@@ -236,6 +247,9 @@ class DraftServer:
             self.pending_forks = forks
             self.pending_meta = ([k[0] for k in keys], jl)
             self.stats["rounds"] += 1
+            if self._trace is not None:
+                self._trace.span("glue_fork", t_a, t_b)
+                self._trace.span(f"tree[{forks.shape[1]}x{self.K}]", t_b, self._trace.mark())
         self.cache_keys = {}
         self.cache_tokens = None
         if self.deferred:

@@ -4,6 +4,7 @@ from __future__ import annotations
 from abc import ABC, abstractmethod
 
 from ssd_amd.engine.speculate_types import SpeculatorBase, VerifierBase, VerifyResult
+from ssd_amd.utils import profiling as prof
 
 
 class InferenceStep(ABC):
@@ -57,10 +58,22 @@ class SpecDecodeStep(InferenceStep):
         return sum(len(s) for s in seqs)
 
     def decode(self, seqs) -> int:
+        trace = prof.enabled("SSD_PROFILE")           # reference step.py:92-161
+        t0 = prof.sync_now() if trace else 0.0
         saved = [seq.snapshot() for seq in seqs]
         spec = self.speculator.speculate(seqs, VerifyResult([], [], None))
+        t1 = prof.sync_now() if trace else 0.0
         out = self.verifier.verify(seqs, spec)
+        t2 = prof.sync_now() if trace else 0.0
         for seq, snap in zip(seqs, saved):      # undo the lookahead applied by speculate + verify
             seq.restore(snap)
         self.scheduler.postprocess_speculate(seqs, out.new_suffixes, out.recovery_tokens)
-        return sum(len(s) for s in out.new_suffixes)
+        toks = sum(len(s) for s in out.new_suffixes)
+        if trace:
+            t3 = prof.sync_now()
+            hits = spec.cache_hits
+            hl = None if hits is None else (hits if isinstance(hits, list) else hits.tolist())
+            hs = f"hits={sum(hl)}/{len(hl)} " if hl is not None else ""
+            print(f"[PROFILE target] handshake={(t1 - t0) * 1e3:.2f}ms verify={(t2 - t1) * 1e3:.2f}ms "
+                  f"postprocess={(t3 - t2) * 1e3:.2f}ms total={(t3 - t0) * 1e3:.2f}ms {hs}toks={toks}", flush=True)
+        return toks

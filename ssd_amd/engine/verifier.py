@@ -6,6 +6,7 @@ from __future__ import annotations
 from time import perf_counter
 
 from ssd_amd.engine.speculate_types import SpeculateResult, VerifierBase, VerifyResult
+from ssd_amd.utils import profiling as prof
 
 
 class Verifier(VerifierBase):
@@ -39,6 +40,10 @@ class Verifier(VerifierBase):
             new_suffixes, recovery = self.target_model_runner.verify_chain(seqs, speculate_result.speculations)
         for seq in seqs:
             seq.num_cached_tokens += self.lookahead + 1
+        if prof.enabled("SSD_PROFILE_TARGET") or prof.enabled("SSD_PROFILE"):     # reference verifier.py:63-74,111-113
+            # forward + accept/reject are ONE device graph here and its result read is the step's only host sync, so
+            # the reference's separate target_fwd / verify_compute spans collapse into a single span
+            print(f"[PROFILE verifier] target_call={(prof.sync_now() - t0) * 1e3:.2f}ms eagle=False bs={len(seqs)}", flush=True)
         self.metrics.setdefault("target_verify_times", []).append(perf_counter() - t0)
         self.metrics.setdefault("accepted_suffix_lens_with_recovery", []).extend(len(s) for s in new_suffixes)
         hits = speculate_result.cache_hits

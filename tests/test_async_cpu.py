@@ -273,3 +273,18 @@ def test_draft_data_parallel_uneven_shards_and_fast_backup():
         got = _run_draft_dp(3, extra=extra)
         assert got[0][0] == ar == single
         assert got[0][1] == m1["cache_hits"], (got[0][1], m1["cache_hits"])
+
+
+def test_profile_flags_print_the_reference_trace_lines(capfd, monkeypatch):
+    """SSD_PROFILE / SSD_PROFILE_TARGET / SSD_PROFILE_DRAFT (reference step.py:92-161, verifier.py:63-74,
+    draft_runner.py:880-915): same switches, same line prefixes; the stream is unchanged by tracing."""
+    ar, _, _ = run("ar")
+    for flag in ("SSD_PROFILE", "SSD_PROFILE_TARGET", "SSD_PROFILE_DRAFT"):
+        monkeypatch.setenv(flag, "1")
+    asy, m, _ = run("async", same=True)
+    out = capfd.readouterr().out
+    assert asy == ar
+    steps = len(m["accepted_suffix_lens_with_recovery"])
+    assert out.count("[PROFILE target] handshake=") == steps and "hits=1/1 toks=4" in out
+    assert out.count("[PROFILE verifier] target_call=") == steps
+    assert out.count("[PROFILE draft] ") >= steps - 1 and "glue_fork=" in out and "tree[" in out
