@@ -43,12 +43,12 @@ def main():
             wsb = torch.zeros(H.gemm_pf_workspace_bytes(M, N, K) // 4 + 16 * M * N, dtype=torch.float32, device="cuda")
             t_old = graph_time(lambda: [H.gemm(xf, ws_[i % C], y, M, N, K, N) for i in range(8)], 8)
             res = [f"wf:{t_old:7.1f}us {N * K * 2 / t_old / 1e6:5.2f}TB/s"]
-            for nt, sp in ((4, 1), (4, 2), (4, 4), (4, 8), (2, 1), (2, 2), (2, 4), (2, 8)):
+            for nt, sp in ((4, 1), (4, 2), (4, 4), (4, 8), (2, 1), (2, 2), (2, 4), (2, 8), (2 | 8 << 8, 1), (2 | 8 << 8, 2), (2 | 8 << 8, 4), (2 | 8 << 8, 8)):
                 try:
                     t = graph_time(lambda: [H.gemm_pf(xf, ws_[i % C], y, M, N, K, N, wsb, splits=sp, nt=nt) for i in range(8)], 8)
-                    res.append(f"n{nt}s{sp}:{t:6.1f} {N * K * 2 / t / 1e6:4.2f}")
+                    res.append(f"n{nt & 255}{'w8' if nt >> 8 else ''}s{sp}:{t:6.1f} {N * K * 2 / t / 1e6:4.2f}")
                 except RuntimeError:
-                    res.append(f"n{nt}s{sp}: n/a")
+                    res.append(f"n{nt & 255}{'w8' if nt >> 8 else ''}s{sp}: n/a")
             print(f"{name:16s} M={M:3d} " + " | ".join(res), flush=True)
         del ws_
 

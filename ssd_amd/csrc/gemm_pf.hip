@@ -18,13 +18,14 @@
 
 enum { PF_EPI_ROWS = 0, PF_EPI_SILU_FRAG = 1 };
 
-constexpr int PF_WAVES = 4;
+constexpr int PF_WAVES_DEFAULT = 4;   // waves per workgroup; the 8-wave form (NT = 2, same 16 row groups per workgroup) halves each
+                                      // wave's accumulators and doubles the weight tiles in flight per workgroup
 constexpr int PF_U = 4;      // k-steps of W in flight per wave; every K split is a multiple of this many k-steps
 
 // direct: 0 = write fp32 partials for the epilogue kernel; 1 / 2 = the K range is not split, finish in place
 // (1: rows bf16 + bias, 2: SiLU(gate) * up -> fragment-major) and skip the workspace round trip.
-template <int MT, int NT, int UU, int DIRECT>
-__global__ void __launch_bounds__(256, 2)
+template <int MT, int NT, int UU, int DIRECT, int PF_WAVES>
+__global__ void __launch_bounds__(64 * PF_WAVES, PF_WAVES == 4 ? 2 : 1)
 gemm_pf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, float* __restrict__ ws,
                int M, int N, int K, int kt_per_split, int mt_valid, const bf16_t* __restrict__ bias,
                void* __restrict__ Yv, int ldy) {
@@ -212,26 +213,31 @@ gemm_pf_epilogue_kernel(const float* __restrict__ ws, const bf16_t* __restrict__
 
 template <int MT, int NT, int DIRECT>
 static int pf_launch_d(const void* x, const void* w, float* ws, int M, int N, int K, int splits, const void* bias, void* y,
-                       int ldy, hipStream_t st) {
+                       int ldy, int waves, hipStream_t st) {
   const int KT = K >> 5;
-  dim3 grid(N / (16 * NT * PF_WAVES), splits);
+  dim3 grid(N / (16 * NT * waves), splits);
   const int nk = KT / splits;
+#define PF_GO(UU, WV)                                                                                                    \
+  hipLaunchKernelGGL((gemm_pf_kernel<MT, NT, UU, DIRECT, WV>), grid, dim3(64 * WV), 0, st, (const u32x4_t*)w,            \
+                     (const u32x4_t*)x, ws, M, N, K, nk, (M + 15) / 16, (const bf16_t*)bias, y, ldy)
   // the narrow tile (NT = 2) has the registers to keep 8 k-steps of W in flight per wave
-  if (NT == 2 && nk % 8 == 0)
-    hipLaunchKernelGGL((gemm_pf_kernel<MT, NT, (NT == 2 ? 8 : PF_U), DIRECT>), grid, dim3(64 * PF_WAVES), 0, st,
-                       (const u32x4_t*)w, (const u32x4_t*)x, ws, M, N, K, nk, (M + 15) / 16, (const bf16_t*)bias, y, ldy);
-  else
-    hipLaunchKernelGGL((gemm_pf_kernel<MT, NT, PF_U, DIRECT>), grid, dim3(64 * PF_WAVES), 0, st, (const u32x4_t*)w,
-                       (const u32x4_t*)x, ws, M, N, K, nk, (M + 15) / 16, (const bf16_t*)bias, y, ldy);
+  if constexpr (NT == 2) {
+    if (waves == 8) { if (nk % 8 == 0) PF_GO(8, 8); else PF_GO(PF_U, 8); }
+    else if (nk % 8 == 0) PF_GO(8, 4);
+    else PF_GO(PF_U, 4);
+  } else {
+    PF_GO(PF_U, 4);
+  }
+#undef PF_GO
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
 template <int MT, int NT>
 static int pf_launch(const void* x, const void* w, float* ws, int M, int N, int K, int splits, int direct, const void* bias,
-                     void* y, int ldy, hipStream_t st) {
-  if (direct == 1) return pf_launch_d<MT, NT, 1>(x, w, ws, M, N, K, splits, bias, y, ldy, st);
-  if (direct == 2) return pf_launch_d<MT, NT, 2>(x, w, ws, M, N, K, splits, bias, y, ldy, st);
-  return pf_launch_d<MT, NT, 0>(x, w, ws, M, N, K, splits, bias, y, ldy, st);
+                     void* y, int ldy, int waves, hipStream_t st) {
+  if (direct == 1) return pf_launch_d<MT, NT, 1>(x, w, ws, M, N, K, splits, bias, y, ldy, waves, st);
+  if (direct == 2) return pf_launch_d<MT, NT, 2>(x, w, ws, M, N, K, splits, bias, y, ldy, waves, st);
+  return pf_launch_d<MT, NT, 0>(x, w, ws, M, N, K, splits, bias, y, ldy, waves, st);
 }
 
 // Default decomposition (measured on MI355X, profiles/micro/prefill_gemm_probe.py): about 160-256 workgroups fill the
@@ -240,8 +246,8 @@ static int pf_launch(const void* x, const void* w, float* ws, int M, int N, int 
 static void pf_pick(int N, int K, int* nt_out, int* splits_out) {
   const int KT = K >> 5;
   auto fit = [&](int nt) {
-    if (N % (16 * nt * PF_WAVES) != 0) return 0;
-    const int blocks = N / (16 * nt * PF_WAVES);
+    if (N % (16 * nt * PF_WAVES_DEFAULT) != 0) return 0;
+    const int blocks = N / (16 * nt * PF_WAVES_DEFAULT);
     int s = 1;
     while (s < 16 && blocks * s < 160) s *= 2;
     while (s > 1 && KT % (s * PF_U) != 0) s /= 2;
@@ -256,7 +262,7 @@ static void pf_pick(int N, int K, int* nt_out, int* splits_out) {
 }
 
 extern "C" int ssd_gemm_pf_workspace_bytes(int M, int N, int K, int64_t* bytes) {
-  if (!bytes || M <= 0 || N <= 0 || K <= 0 || N % (16 * 2 * PF_WAVES) != 0) return SSD_ERR_ARG;
+  if (!bytes || M <= 0 || N <= 0 || K <= 0 || N % (16 * 2 * PF_WAVES_DEFAULT) != 0) return SSD_ERR_ARG;
   int nt, splits;
   pf_pick(N, K, &nt, &splits);
   *bytes = (int64_t)splits * M * N * 4;
@@ -268,8 +274,13 @@ extern "C" int ssd_gemm_pf_cfg(const void* x_frag, const void* w_frag, const voi
                                void* stream) {
   if (M <= 16 || M > 128 || N <= 0 || K <= 0 || (K % (32 * PF_U))) return SSD_ERR_SHAPE;
   if (epilogue != PF_EPI_ROWS && epilogue != PF_EPI_SILU_FRAG) return SSD_ERR_ARG;
+  // nt may carry the waves per workgroup in bits 8.. (0 = 4): 8 waves only with nt = 2 (same 16 row groups per workgroup)
+  int waves = (nt >> 8) & 0xff;
+  nt &= 0xff;
+  if (waves == 0) waves = PF_WAVES_DEFAULT;
   if (nt != 2 && nt != 4) return SSD_ERR_ARG;
-  if (N % (16 * nt * PF_WAVES) != 0) return SSD_ERR_SHAPE;
+  if (waves != 4 && !(waves == 8 && nt == 2)) return SSD_ERR_ARG;
+  if (N % (16 * nt * waves) != 0) return SSD_ERR_SHAPE;
   const int KT = K >> 5;
   if (splits <= 0) { int nt_d; pf_pick(N, K, &nt_d, &splits); if (nt_d != nt) splits = 1; }
   if (KT % (splits * PF_U) != 0) return SSD_ERR_ARG;
@@ -279,7 +290,7 @@ extern "C" int ssd_gemm_pf_cfg(const void* x_frag, const void* w_frag, const voi
   float* ws = (float*)workspace;
   const int mt = (M + 15) / 16;
   int rc;
-#define PF_ARGS x_frag, w_frag, ws, M, N, K, splits, direct, bias, y, ldy, st
+#define PF_ARGS x_frag, w_frag, ws, M, N, K, splits, direct, bias, y, ldy, waves, st
   if (mt <= 4) rc = nt == 4 ? pf_launch<4, 4>(PF_ARGS) : pf_launch<4, 2>(PF_ARGS);
   else rc = nt == 4 ? pf_launch<8, 4>(PF_ARGS) : pf_launch<8, 2>(PF_ARGS);
 #undef PF_ARGS
@@ -298,7 +309,7 @@ extern "C" int ssd_gemm_pf_cfg(const void* x_frag, const void* w_frag, const voi
 
 extern "C" int ssd_gemm_pf(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K,
                            int ldy, int epilogue, void* workspace, int64_t workspace_bytes, int splits, void* stream) {
-  if (N <= 0 || K <= 0 || N % (16 * 2 * PF_WAVES) != 0) return SSD_ERR_SHAPE;
+  if (N <= 0 || K <= 0 || N % (16 * 2 * PF_WAVES_DEFAULT) != 0) return SSD_ERR_SHAPE;
   int nt, s;
   pf_pick(N, K, &nt, &s);
   if (splits > 0) s = splits;
