@@ -240,25 +240,25 @@ static int pf_launch(const void* x, const void* w, float* ws, int M, int N, int 
   return pf_launch_d<MT, NT, 0>(x, w, ws, M, N, K, splits, bias, y, ldy, waves, st);
 }
 
-// Default decomposition (measured on MI355X, profiles/micro/prefill_gemm_probe.py): about 160-256 workgroups fill the
-// chip; prefer the wide tile (nt = 4: half the x traffic) unless it needs more than 8 K-splits to get there, and the
-// fewest splits that do (each split costs M*N*8 bytes of partial traffic).
-static void pf_pick(int N, int K, int* nt_out, int* splits_out) {
+// Default decomposition, from profiles/r02_pf_probe.txt (MI355X, M = 128, us): the narrow tile (nt = 2) everywhere --
+// 70B gate_up 57344x8192: nt4 176.8, nt2 185.1, nt2 with 8 waves 160.4 (unsplit); qkv 10240x8192: nt4 s4 54.2, nt2w8 s4 51.0;
+// o 8192x8192: nt4 s8 44.7, nt2 s4 40.7; down 8192x28672: nt4 s8 100.0, nt2w8 s8 96.5; 8B gate_up: nt2 s1 58.4; 8B down: nt2 s8 37.1.
+//  * K splits: none when N alone gives >= 160 workgroups; otherwise enough for >= 160 workgroups AND <= ~96 k-steps per split
+//    (each split costs M*N*8 bytes of partial traffic, but a long serial K walk by few workgroups costs more);
+//  * 8 waves per workgroup (same 16 row groups, half the accumulators per wave, twice the weight tiles in flight) whenever
+//    that still leaves >= 160 workgroups.
+static void pf_pick(int N, int K, int* nt_out, int* splits_out, int* waves_out = nullptr) {
   const int KT = K >> 5;
-  auto fit = [&](int nt) {
-    if (N % (16 * nt * PF_WAVES_DEFAULT) != 0) return 0;
-    const int blocks = N / (16 * nt * PF_WAVES_DEFAULT);
-    int s = 1;
-    while (s < 16 && blocks * s < 160) s *= 2;
+  int nt = 2, waves = 4, s = 1;
+  if (N % (16 * 2 * 4) != 0) { *nt_out = 4; *splits_out = 1; if (waves_out) *waves_out = 4; return; }   // caller rejects the shape
+  const int blocks4 = N / (16 * 2 * 4);
+  if (blocks4 < 160) {
+    while (s < 8 && (blocks4 * s < 160 || KT / s > 96)) s *= 2;
     while (s > 1 && KT % (s * PF_U) != 0) s /= 2;
-    return s;
-  };
-  const int s4 = fit(4), s2 = fit(2);
-  // an unsplit K finishes inside the GEMM kernel (no partial tiles, no epilogue launch): take it when the narrow tile
-  // alone fills the chip (8B gate_up: nt2 s1 58.7 us vs nt4 s2 62.1)
-  if (s2 == 1 && s4 > 1) { *nt_out = 2; *splits_out = 1; }
-  else if (s4 > 0 && (s4 <= 8 || s2 == 0)) { *nt_out = 4; *splits_out = s4; }
-  else { *nt_out = 2; *splits_out = s2; }
+  }
+  if (N % (16 * 2 * 8) == 0 && (N / (16 * 2 * 8)) * s >= 160) waves = 8;
+  *nt_out = nt; *splits_out = s;
+  if (waves_out) *waves_out = waves;
 }
 
 extern "C" int ssd_gemm_pf_workspace_bytes(int M, int N, int K, int64_t* bytes) {
@@ -283,6 +283,7 @@ extern "C" int ssd_gemm_pf_cfg(const void* x_frag, const void* w_frag, const voi
   if (N % (16 * nt * waves) != 0) return SSD_ERR_SHAPE;
   const int KT = K >> 5;
   if (splits <= 0) { int nt_d; pf_pick(N, K, &nt_d, &splits); if (nt_d != nt) splits = 1; }
+  if (splits > 16) return SSD_ERR_ARG;
   if (KT % (splits * PF_U) != 0) return SSD_ERR_ARG;
   const int direct = splits == 1 ? (epilogue == PF_EPI_ROWS ? 1 : 2) : 0;     // unsplit K: finish inside the GEMM kernel
   if (!direct && (!workspace || workspace_bytes < (int64_t)splits * M * N * 4)) return SSD_ERR_ARG;
@@ -310,8 +311,8 @@ extern "C" int ssd_gemm_pf_cfg(const void* x_frag, const void* w_frag, const voi
 extern "C" int ssd_gemm_pf(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K,
                            int ldy, int epilogue, void* workspace, int64_t workspace_bytes, int splits, void* stream) {
   if (N <= 0 || K <= 0 || N % (16 * 2 * PF_WAVES_DEFAULT) != 0) return SSD_ERR_SHAPE;
-  int nt, s;
-  pf_pick(N, K, &nt, &s);
-  if (splits > 0) s = splits;
-  return ssd_gemm_pf_cfg(x_frag, w_frag, bias, y, M, N, K, ldy, epilogue, workspace, workspace_bytes, nt, s, stream);
+  int nt, s, waves;
+  pf_pick(N, K, &nt, &s, &waves);
+  if (splits > 0) { s = splits; waves = 4; }
+  return ssd_gemm_pf_cfg(x_frag, w_frag, bias, y, M, N, K, ldy, epilogue, workspace, workspace_bytes, nt | (waves << 8), s, stream);
 }
