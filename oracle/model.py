@@ -96,14 +96,19 @@ class OracleModel:
             o = O.attn_paged(q, kc, vc, ctx.context_lens, ctx.block_tables, scale)
         return o.reshape(T, self.nh * cfg.head_dim)
 
-    def forward(self, input_ids: torch.Tensor, positions: torch.Tensor, ctx: Ctx) -> torch.Tensor:
+    def forward(self, input_ids: torch.Tensor, positions: torch.Tensor, ctx: Ctx, taps=None):
+        """taps (EAGLE-3 target, llama3.py:256-271): layer indices whose INPUT residual stream (hidden + residual, bf16) is
+        collected; returns (hidden, acts [T, len(set(taps)) * h]) in ascending layer order, as the reference's loop does."""
         cfg, w = self.cfg, self.w
+        collected = []
         h = O.embedding(input_ids, w["model.embed_tokens.weight"], self.vocab_per_rank * self.tp_rank if self.tp_size > 1 else 0)
         h = self._allreduce(h)
         residual = None
         qs, kvs = self.nh * cfg.head_dim, self.nkv * cfg.head_dim
         for li in range(cfg.num_layers):
             p = f"model.layers.{li}."
+            if taps is not None and li in taps:
+                collected.append(h if residual is None else h + residual)
             if residual is None:
                 x, residual = O.rmsnorm(h, w[p + "input_layernorm.weight"], cfg.rms_norm_eps), h
             else:
@@ -120,6 +125,8 @@ class OracleModel:
             a = O.silu_mul(O.linear(x, w[p + "mlp.gate_up_proj.weight"]))
             h = self._allreduce(O.linear(a, w[p + "mlp.down_proj.weight"]))
         h, _ = O.rmsnorm(h, w["model.norm.weight"], cfg.rms_norm_eps, residual)
+        if taps is not None:
+            return h, torch.cat(collected, dim=-1)
         return h
 
     def compute_logits(self, hidden: torch.Tensor) -> torch.Tensor | None:

@@ -10,7 +10,7 @@ from dataclasses import dataclass, asdict
 
 @dataclass
 class ModelConfig:
-    family: str                 # "llama" | "qwen3"
+    family: str                 # "llama" | "qwen3" | "eagle3" (the one-layer EAGLE-3 draft, eagle3_draft_llama3.py)
     hidden_size: int
     num_layers: int
     num_heads: int
@@ -24,6 +24,12 @@ class ModelConfig:
     tie_word_embeddings: bool = False
     qk_norm: bool = False       # Qwen3: per-head RMSNorm on q and k before RoPE (qwen3.py:96-104)
     attention_bias: bool = False
+    # EAGLE-3 draft only (ssd/models/eagle3_draft_llama3.py:209-262): the LM head covers draft_vocab_size tokens that d2t maps
+    # into the target vocabulary (vocab_size), and fc projects eagle_taps concatenated target activations of width
+    # d_model_target each
+    draft_vocab_size: int = 0
+    d_model_target: int = 0
+    eagle_taps: int = 3
 
     @property
     def q_size(self) -> int:
@@ -41,6 +47,8 @@ class ModelConfig:
         """From a transformers config object (or anything with the same attributes)."""
         mt = getattr(hf, "model_type", "llama")
         family = "qwen3" if "qwen" in mt else "llama"
+        if getattr(hf, "draft_vocab_size", None) and hf.num_hidden_layers == 1:
+            family = "eagle3"       # EAGLE-3 checkpoints: a Llama config.json with one layer + draft_vocab_size
         nh = hf.num_attention_heads
         hd = getattr(hf, "head_dim", None) or hf.hidden_size // nh
         # transformers >= 5 moved rope_theta into rope_parameters; the reference's getattr(config,
@@ -66,6 +74,7 @@ class ModelConfig:
             tie_word_embeddings=bool(getattr(hf, "tie_word_embeddings", False)),
             qk_norm=(family == "qwen3"),
             attention_bias=bool(getattr(hf, "attention_bias", False)),
+            draft_vocab_size=int(getattr(hf, "draft_vocab_size", 0) or 0),
         )
 
 
@@ -82,4 +91,9 @@ PRESETS = {
     "qwen3-4b": ModelConfig("qwen3", 2560, 36, 32, 8, 128, 9728, 151936, 1e-6, 1e6, 40960, True, True),
     "qwen3-8b": ModelConfig("qwen3", 4096, 36, 32, 8, 128, 12288, 151936, 1e-6, 1e6, 40960, False, True),
     "qwen3-14b": ModelConfig("qwen3", 5120, 40, 40, 8, 128, 17408, 151936, 1e-6, 1e6, 40960, False, True),
+    # EAGLE-3 drafts the reference's bench.py --eagle selects (bench_helpers.py:50-63, bench_paths.py:33-44); public config.json shapes
+    "eagle3-llama-3.1-8b": ModelConfig("eagle3", 4096, 1, 32, 8, 128, 14336, 128256, 1e-5, 5e5, 131072, False,
+                                       draft_vocab_size=32000, d_model_target=4096),
+    "eagle3-llama-3.3-70b": ModelConfig("eagle3", 6144, 1, 48, 8, 128, 16384, 128256, 1e-5, 5e5, 131072, False,
+                                        draft_vocab_size=32000, d_model_target=8192),
 }

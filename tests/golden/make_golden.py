@@ -12,6 +12,8 @@ Fixtures written next to this file:
   tiny_llama.npz     tiny LlamaForCausalLM: weights, prefill / decode / verify / tree-decode logits
   tiny_qwen3.npz     tiny Qwen3ForCausalLM: weights, prefill / verify logits
   engine_golden.npz  greedy AR token stream and sync-SD accepted-suffix trace driven by reference modules
+  tiny_eagle3.npz    tiny LlamaForCausalLM(use_eagle) + Eagle3DraftForCausalLM: weights, d2t, target activations, draft
+                     prefill / JIT decode / variable-length glue / tree-decode logits and prenorms
 """
 from __future__ import annotations
 
@@ -40,6 +42,7 @@ from ssd.utils.async_helpers.async_spec_helpers import get_forked_recovery_token
 from ssd.engine.helpers.mask_helpers import get_custom_mask  # noqa: E402
 from ssd.models.llama3 import LlamaForCausalLM  # noqa: E402
 from ssd.models.qwen3 import Qwen3ForCausalLM  # noqa: E402
+from ssd.models.eagle3_draft_llama3 import Eagle3DraftForCausalLM  # noqa: E402
 import ssd.layers.rotary_embedding as rope_mod  # noqa: E402
 
 BF = torch.bfloat16
@@ -321,6 +324,140 @@ def gen_tiny_qwen():
     print("tiny_qwen3.npz written")
 
 
+def gen_tiny_eagle():
+    """EAGLE-3: the target's activation taps and every forward flavour of the draft (draft_runner.py:51-101 prefill with
+    the one-token shift, :124-184 JIT with self-conditioning, :530-620 variable-length glue over [extend | recovery | spec]
+    rows, :734-760 tree step), each driven through the reference's own modules."""
+    K, F = 2, 2
+    MQ = F * (K + 1)
+    taps = [0, 1, 3]
+    tcfg = tiny_llama_cfg(h=256, L=4, nh=4, nkv=2, I=512, V=512)
+    tm = build(LlamaForCausalLM, tcfg, 21, 0.06, speculate=True, spec_k=K, use_eagle=True, eagle_layers=taps)
+    dcfg = tiny_llama_cfg(h=128, L=1, nh=2, nkv=1, I=256, V=512)
+    dcfg.draft_vocab_size = 256
+    dm = build(Eagle3DraftForCausalLM, dcfg, 22, 0.08, draft=True, speculate=True, use_eagle=True, eagle_layers=taps,
+               d_model_target=tcfg.hidden_size, spec_k=K, async_fan_out=F, draft_async=True)
+    g = torch.Generator().manual_seed(23)
+    tgt_idx = torch.randperm(tcfg.vocab_size, generator=g)[:dcfg.draft_vocab_size].sort().values
+    dm.d2t_tensor = (tgt_idx - torch.arange(dcfg.draft_vocab_size)).long()
+    mcfg = types.SimpleNamespace(speculate_k=K, fan_out_list=[F] * (K + 1), fan_out_list_miss=[F] * (K + 1), max_model_len=512,
+                                 async_fan_out=F)
+    tree = TreeShim(mcfg, K, F, get_context, get_custom_mask)
+    tree.cache_hits = torch.tensor([1])
+    td = RefDriver(tm, tcfg)
+    dd = RefDriver(dm, dcfg, table=[4, 8, 1, 6, 10, 2, 12, 14, 16, 18, 20, 0], tree=tree)
+    out = {"t." + k: v.data.clone() for k, v in tm.state_dict().items()}
+    out.update({"d." + k: v.data.clone() for k, v in dm.state_dict().items()})
+    out["d.d2t"] = dm.d2t_tensor.clone()
+    out["t_cfg_i"], out["t_cfg_f"] = cfg_fields(tcfg, "llama")
+    out["d_cfg_i"], out["d_cfg_f"] = cfg_fields(dcfg, "llama")
+    out["taps"], out["K_F"] = torch.tensor(taps), torch.tensor([K, F])
+    out["t_block_table"], out["d_block_table"] = td.bt.clone(), dd.bt.clone()
+    prompt = torch.randint(0, tcfg.vocab_size, (21,), generator=g).tolist()
+    out["prompt"] = torch.tensor(prompt)
+    P = len(prompt)
+
+    @torch.inference_mode()
+    def target(tokens, pos0, prefill):
+        n = len(tokens)
+        cu = torch.tensor([0, n], dtype=torch.int32)
+        if prefill:
+            set_context(True, cu_seqlens_q=cu, cu_seqlens_k=cu, max_seqlen_q=n, max_seqlen_k=n, slot_mapping=td.slots(range(n)))
+        else:
+            set_context(False, cu_seqlens_q=cu, max_seqlen_q=n, slot_mapping=td.slots(range(pos0, pos0 + n)),
+                        context_lens=torch.tensor([pos0 + n], dtype=torch.int32), block_tables=td.bt)
+        h, acts = tm(torch.tensor(tokens, dtype=torch.int64), torch.arange(pos0, pos0 + n, dtype=torch.int64))
+        lg = tm.compute_logits(h, last_only=False)
+        reset_context()
+        return lg.view(n, -1).clone(), acts.clone()
+
+    @torch.inference_mode()
+    def draft(tokens, positions, hidden, kind, slots_pos=None, ctx_len=None, step=0):
+        n = len(tokens)
+        cu = torch.tensor([0, n], dtype=torch.int32)
+        sp = positions if slots_pos is None else slots_pos
+        if kind == "prefill":
+            set_context(True, cu_seqlens_q=cu, cu_seqlens_k=cu, max_seqlen_q=n, max_seqlen_k=n, slot_mapping=dd.slots(sp))
+        elif kind == "decode":
+            set_context(False, slot_mapping=dd.slots(sp), context_lens=torch.tensor([positions[-1] + 1], dtype=torch.int32),
+                        block_tables=dd.bt, is_jit=True)
+        elif kind == "glue":
+            set_context(False, cu_seqlens_q=cu, max_seqlen_q=n, slot_mapping=dd.slots(sp),
+                        context_lens=torch.tensor([ctx_len], dtype=torch.int32), block_tables=dd.bt)
+        else:
+            tree.step = step
+            set_context(False, slot_mapping=dd.slots(sp), context_lens=torch.tensor([ctx_len], dtype=torch.int32),
+                        block_tables=dd.bt, is_jit=False)
+        pre = dm(torch.tensor(tokens, dtype=torch.int64), torch.tensor(list(positions), dtype=torch.int64), hidden)
+        lg = dm.compute_logits(pre, last_only=False)
+        reset_context()
+        return lg.view(n, -1).clone(), pre.clone()
+
+    # target prefill: logits + the three taps for every prompt token
+    t_logits, t_acts = target(prompt, 0, True)
+    out["t_prefill_logits"], out["t_prefill_acts"] = t_logits, t_acts
+    # draft prefill: token j is conditioned on the target activation of position j-1 (speculator_async.py:66-77)
+    d_lg, d_pre = draft(prompt[1:], range(P - 1), t_acts[:-1], "prefill")
+    out["d_prefill_logits"], out["d_prefill_prenorm"] = d_lg, d_pre
+    # round 1, cache miss: JIT chain from the recovery token at draft position P-1 (pos_offset -1, draft_runner.py:133-135)
+    t0 = int(t_logits[-1].float().argmax())
+    chain_tok, chain_lg, chain_pre = [], [], []
+    tok, hid = t0, t_acts[-1:].clone()
+    for i in range(K):
+        lg, pre = draft([tok], [P - 1 + i], hid, "decode")
+        chain_lg.append(lg); chain_pre.append(pre)
+        tok, hid = int(lg[0].float().argmax()), pre
+        chain_tok.append(tok)
+    out["rec0"], out["jit1_tokens"] = torch.tensor([t0]), torch.tensor(chain_tok)
+    out["jit1_logits"], out["jit1_prenorm"] = torch.cat(chain_lg), torch.cat(chain_pre)
+    # the target verifies [t0, s1, s2] at P..P+K; the golden then PRETENDS every draft token was accepted (the numerics of
+    # the extend path do not depend on whether the target agreed), so the text becomes prompt + [t0, s1, s2, t_new]
+    v_lg, v_acts = target([t0] + chain_tok, P, False)
+    out["t_verify_logits"], out["t_verify_acts"] = v_lg, v_acts
+    t_new = int(v_lg[-1].float().argmax())
+    N = P + K + 2                                   # num_tokens after the new recovery token is appended
+    # round 2 JIT from (t_new, target act of the last accepted row) at draft position N-2
+    chain2_tok, chain2_pre, chain2_lg = [], [], []
+    tok, hid = t_new, v_acts[K:K + 1].clone()
+    for i in range(K):
+        lg, pre = draft([tok], [N - 2 + i], hid, "decode")
+        chain2_lg.append(lg); chain2_pre.append(pre)
+        tok, hid = int(lg[0].float().argmax()), pre
+        chain2_tok.append(tok)
+    out["rec1"], out["jit2_tokens"] = torch.tensor([t_new]), torch.tensor(chain2_tok)
+    out["jit2_logits"], out["jit2_prenorm"] = torch.cat(chain2_lg), torch.cat(chain2_pre)
+    # glue with n_ext = K extend rows: [s1, s2 | t_new | y1, y2] at N-2-n_ext .. N-2+K; extend + recovery rows carry
+    # fc(target acts), spec rows the chain's prenorms (draft_runner.py:548-612)
+    n_ext = K
+    fused_ids = chain_tok + [t_new] + chain2_tok
+    with torch.inference_mode():
+        tc = dm.fc(v_acts[:K + 1].to(dm.fc.weight.dtype))
+    fused_hs = torch.cat([tc, torch.cat(chain2_pre)], dim=0)
+    base = N - 2 - n_ext
+    g_lg, g_pre = draft(fused_ids, range(base, base + n_ext + K + 1), fused_hs, "glue", ctx_len=N - 1 + K)
+    out["glue_ids"], out["glue_hs"], out["glue_n_ext"] = torch.tensor(fused_ids), fused_hs.clone(), torch.tensor([n_ext])
+    out["glue_logits"], out["glue_prenorm"] = g_lg, g_pre
+    # fork + tree decode from the K+1 [recovery | spec] rows; branch i starts from the glue prenorm of its position
+    kp1_lg, kp1_pre = g_lg[n_ext:], g_pre[n_ext:]
+    returned = torch.tensor([[t_new] + chain2_tok])
+    forks = get_forked_recovery_tokens_from_logits(mcfg, kp1_lg.view(1, K + 1, -1), torch.tensor([1]), returned, None)
+    out["tree_forks"] = forks.clone()
+    jidx = [i // F for i in range(MQ)]
+    hid = kp1_pre[torch.tensor(jidx)]
+    toks = forks[0].tolist()
+    Pb = N - 2                                      # (num_tokens - 1 + pos_offset), draft_runner.py:497-499
+    tl, tp = [], []
+    for step in range(K):
+        rope_pos = [Pb + j + 1 + step for j in jidx]
+        cache_pos = [Pb + K + 1 + step * MQ + i for i in range(MQ)]
+        lg, pre = draft(toks, rope_pos, hid, "tree", slots_pos=cache_pos, ctx_len=cache_pos[-1] + 1, step=step)
+        tl.append(lg); tp.append(pre)
+        toks, hid = lg.float().argmax(-1).tolist(), pre
+    out["tree_logits"], out["tree_prenorm"] = torch.stack(tl), torch.stack(tp)
+    save_npz(os.path.join(HERE, "tiny_eagle3.npz"), out)
+    print("tiny_eagle3.npz written")
+
+
 def _top2_margin(row):
     t = row.float().topk(2).values
     return float(t[0] - t[1])
@@ -528,7 +665,7 @@ def gen_stochastic():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "logic", "llama", "qwen", "engine", "scheduler", "stochastic"]
+    which = sys.argv[1:] or ["ops", "logic", "llama", "qwen", "eagle", "engine", "scheduler", "stochastic"]
     if "ops" in which:
         gen_ops()
     if "logic" in which:
@@ -537,6 +674,8 @@ if __name__ == "__main__":
         gen_tiny_llama()
     if "qwen" in which:
         gen_tiny_qwen()
+    if "eagle" in which:
+        gen_tiny_eagle()
     if "engine" in which:
         gen_engine()
     if "scheduler" in which:

@@ -115,3 +115,21 @@ def truth_forward(cfg, w: dict, tokens: list[int]) -> torch.Tensor:
     x = norm(h + res, w["model.norm.weight"], cfg.rms_norm_eps)
     head = w["model.embed_tokens.weight"] if cfg.tie_word_embeddings else w["lm_head.weight"]
     return x @ head.to(D).t()
+
+
+def eagle_models_from_golden(g):
+    """(target ModelConfig, target weights, draft ModelConfig (family eagle3), draft weights incl. d2t, taps, K, F) of
+    tests/golden/tiny_eagle3.npz (written by the reference's own LlamaForCausalLM / Eagle3DraftForCausalLM)."""
+    from ssd_amd.model_config import ModelConfig
+
+    def cfg(prefix, family, **kw):
+        ci, cf = g[prefix + "cfg_i"].tolist(), g[prefix + "cfg_f"].tolist()
+        return ModelConfig(family, ci[0], ci[1], ci[2], ci[3], ci[4], ci[5], ci[6], cf[0], cf[1], ci[7], False, **kw)
+
+    tcfg = cfg("t_", "llama")
+    tw = {k[2:]: v for k, v in g.items() if k.startswith("t.")}
+    dw = {k[2:]: v for k, v in g.items() if k.startswith("d.")}
+    dcfg = cfg("d_", "eagle3", draft_vocab_size=int(dw["lm_head.weight"].shape[0]), d_model_target=tcfg.hidden_size,
+               eagle_taps=int(g["taps"].numel()))
+    K, F = g["K_F"].tolist()
+    return tcfg, tw, dcfg, dw, g["taps"].tolist(), K, F
