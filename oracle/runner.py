@@ -29,8 +29,16 @@ class OracleRunner:
             seed = config.draft_weights_seed if is_draft else config.weights_seed
             weights = W.synthetic_state_dict(model_cfg, seed, config.weights_std, recipe=getattr(config, "weights_recipe", None))
         self.num_kvcache_blocks = num_kvcache_blocks if num_kvcache_blocks > 0 else 64
-        self.model = OracleModel(model_cfg, shard_weights(model_cfg, weights, tp_rank, tp_size), self.num_kvcache_blocks,
-                                 self.block_size, tp_rank, tp_size, tp_group)
+        self.eagle = model_cfg.family == "eagle3"
+        # EAGLE-3 target: tap the residual stream entering these layers on every forward (llama3.py:256-271)
+        self.taps = sorted(set(config.eagle_layers)) if (getattr(config, "use_eagle", False) and not is_draft) else None
+        self._acts = None
+        if self.eagle:
+            from oracle.eagle import OracleEagleDraft
+            self.model = OracleEagleDraft(model_cfg, weights, self.num_kvcache_blocks, self.block_size)
+        else:
+            self.model = OracleModel(model_cfg, shard_weights(model_cfg, weights, tp_rank, tp_size), self.num_kvcache_blocks,
+                                     self.block_size, tp_rank, tp_size, tp_group)
         self.tp_rank, self.tp_size, self.tp_group = tp_rank, tp_size, tp_group
         # (seq_id, absolute position of the decided token) -> top-2 logit margin of that greedy decision; tests use it
         # to tell a legitimate near-tie flip from a real divergence of the HIP engine
@@ -65,6 +73,18 @@ class OracleRunner:
     def call(self, method, *args):
         return getattr(self, method)(*args)
 
+    def _forward(self, ids, pos, ctx):
+        """Target forward; under EAGLE-3 also keeps the tapped activations of this call for `eagle_acts`."""
+        if self.taps is None:
+            return self.model.forward(ids, pos, ctx)
+        h, self._acts = self.model.forward(ids, pos, ctx, taps=self.taps)
+        return h
+
+    def eagle_acts(self, n: int) -> torch.Tensor:
+        """[n, taps * h] activations of the last prefill / verify forward (reference model_runner.py:613-616)."""
+        assert self._acts is not None and self._acts.shape[0] == n
+        return self._acts
+
     def _temps(self, seqs):
         return torch.tensor([float(s.draft_temperature) if (self.is_draft and s.draft_temperature is not None) else float(s.temperature)
                              for s in seqs])
@@ -90,7 +110,7 @@ class OracleRunner:
             paged = cu_k[-1] > cu_q[-1]
             ctx = Ctx("prefill", slot_mapping=torch.tensor(slots, dtype=torch.int32), cu_q=cu_q_t, cu_k=cu_k_t,
                       block_tables=self._bt(seqs) if paged else None)
-            h = self.model.forward(torch.tensor(ids), torch.tensor(pos), ctx)
+            h = self._forward(torch.tensor(ids), torch.tensor(pos), ctx)
             lg = self._logits(h[(cu_q_t[1:] - 1).long()])
             self._log_margins(lg, [(s.seq_id, len(s)) for s in seqs])
             toks = self._pick(lg, seqs)
@@ -127,7 +147,7 @@ class OracleRunner:
         ctx = Ctx("verify", slot_mapping=torch.tensor(slots, dtype=torch.int32),
                   context_lens=torch.tensor(ctx_lens, dtype=torch.int32), block_tables=self._bt(seqs),
                   cu_q=torch.arange(B + 1, dtype=torch.int32) * (K + 1))
-        return self._logits(self.model.forward(torch.tensor(ids), torch.tensor(pos), ctx))
+        return self._logits(self._forward(torch.tensor(ids), torch.tensor(pos), ctx))
 
     @torch.inference_mode()
     def speculate_chain(self, seqs, recovery_tokens):
@@ -180,8 +200,9 @@ class OracleRunner:
         return torch.tensor(tables, dtype=torch.int32)
 
     @torch.inference_mode()
-    def draft_prefill(self, token_lists, tables):
-        """draft_async_prefill (draft_runner.py:51-101): trunk KV for the whole prompt."""
+    def draft_prefill(self, token_lists, tables, acts=None):
+        """draft_async_prefill (draft_runner.py:51-101): trunk KV for the whole prompt.  EAGLE-3: `acts` holds one target
+        activation row per token (the caller already applied the one-token shift)."""
         ids, pos, slots, cu = [], [], [], [0]
         for toks, tb in zip(token_lists, tables):
             n = len(toks)
@@ -190,31 +211,80 @@ class OracleRunner:
             slots.extend(self._slot(tb, p) for p in range(n))
             cu.append(cu[-1] + n)
         cu_t = torch.tensor(cu, dtype=torch.int32)
-        self.model.forward(torch.tensor(ids), torch.tensor(pos), Ctx("prefill", slot_mapping=torch.tensor(slots, dtype=torch.int32),
-                                                                    cu_q=cu_t, cu_k=cu_t))
+        ctx = Ctx("prefill", slot_mapping=torch.tensor(slots, dtype=torch.int32), cu_q=cu_t, cu_k=cu_t)
+        if self.eagle:
+            self.model.forward(torch.tensor(ids), torch.tensor(pos), acts, ctx)
+        else:
+            self.model.forward(torch.tensor(ids), torch.tensor(pos), ctx)
+
+    def _eagle_logits(self, ids, pos, cond, ctx):
+        """(full-vocabulary logits, prenorm) of one EAGLE draft forward (reference model_runner.py:606-612)."""
+        pre = self.model.forward(ids, pos, cond, ctx)
+        return self.model.compute_logits(pre), pre
 
     @torch.inference_mode()
-    def draft_jit(self, rec, num_tokens, tables, temps=None):
-        """jit_speculate (draft_runner.py:124-184): K single-token decodes from the recovery token at P = n - 1."""
+    def draft_jit(self, rec, num_tokens, tables, temps=None, cond=None):
+        """jit_speculate (draft_runner.py:124-184): K single-token decodes from the recovery token at P = n - 1.  EAGLE-3:
+        the first step is conditioned on fc(cond) (the recovery token's target activation), every later one on the
+        previous step's prenorm; the K prenorms are kept for `jit_acts`."""
         B, K = len(rec), self.K
         bt = self._bt_from(tables)
         out = torch.zeros(B, K, dtype=torch.int64)
         cur = list(rec)
         t = None if temps is None or not any(x > 0 for x in temps) else torch.tensor(temps, dtype=torch.float32)
-        lq = []
+        lq, pres = [], []
         for i in range(K):
             pos = [n - 1 + i for n in num_tokens]
             slots = [self._slot(tb, p) for tb, p in zip(tables, pos)]
-            lg = self._decode(cur, pos, slots, [p + 1 for p in pos], bt)
+            if self.eagle:
+                ctx = Ctx("decode", slot_mapping=torch.tensor(slots, dtype=torch.int32),
+                          context_lens=torch.tensor([p + 1 for p in pos], dtype=torch.int32), block_tables=bt)
+                lg, cond = self._eagle_logits(torch.tensor(cur), torch.tensor(pos), cond, ctx)
+                pres.append(cond)
+            else:
+                lg = self._decode(cur, pos, slots, [p + 1 for p in pos], bt)
             lq.append(lg)
             cur = (O.argmax_rows(lg) if t is None else O.sample(lg, t)).tolist()
             out[:, i] = torch.tensor(cur)
         self._lq = torch.stack(lq, dim=1)
+        self._jit_acts = torch.stack(pres, dim=1) if pres else None
         return out
 
+    def jit_acts(self, B):
+        return self._jit_acts[:B]
+
+    def tree_acts(self, T):
+        return self._tree_acts[:T]
+
+    def _eagle_glue_fork(self, glue_ids, num_tokens, tables, fan_lists, eagle):
+        """_build_tree_batch, EAGLE branch (draft_runner.py:538-612,660-700): per sequence the packed rows
+        [extend_0..extend_{n-1} | recovery | spec_1..spec_K] at positions P-n .. P+K (P = num_tokens - 1, already shifted);
+        extend + recovery rows are conditioned on fc(target activation), spec rows on the previous round's prenorms."""
+        B, K = glue_ids.shape[0], self.K
+        acts, counts, ext_ids, prev = eagle["acts"], eagle["ext_counts"], eagle["ext_ids"], eagle["prev_acts"]
+        ids, pos, slots, cu, conds = [], [], [], [0], []
+        for b, (n, tb) in enumerate(zip(num_tokens, tables)):
+            ne = counts[b]
+            tc = self.model.project(torch.cat([acts[b, :ne], acts[b, K:K + 1]], dim=0))         # one fc call for extend + recovery
+            conds.extend([tc, prev[b]])
+            ids.extend(list(ext_ids[b][:ne]) + glue_ids[b].tolist())
+            for p in range(n - 1 - ne, n + K):
+                pos.append(p)
+                slots.append(self._slot(tb, p))
+            cu.append(cu[-1] + ne + K + 1)
+        ctx = Ctx("verify", slot_mapping=torch.tensor(slots, dtype=torch.int32),
+                  context_lens=torch.tensor([n + K for n in num_tokens], dtype=torch.int32), block_tables=self._bt_from(tables),
+                  cu_q=torch.tensor(cu, dtype=torch.int32))
+        lg, pre = self._eagle_logits(torch.tensor(ids), torch.tensor(pos), torch.cat(conds, dim=0), ctx)
+        rows = torch.tensor([cu[b] + counts[b] + j for b in range(B) for j in range(K + 1)])    # the K+1 [recovery | spec] rows
+        self._glue_pre = pre[rows].view(B, K + 1, -1)
+        return O.fork_topf(lg[rows].view(B, K + 1, -1), glue_ids, fan_lists)
+
     @torch.inference_mode()
-    def draft_glue_fork(self, glue_ids, num_tokens, tables, fan_lists):
+    def draft_glue_fork(self, glue_ids, num_tokens, tables, fan_lists, eagle=None):
         """Glue decode + fork (draft_runner.py:620-700; async_spec_helpers.py:26-78)."""
+        if eagle is not None:
+            return self._eagle_glue_fork(glue_ids, num_tokens, tables, fan_lists, eagle)
         B, K = glue_ids.shape[0], self.K
         pos, slots = [], []
         for n, tb in zip(num_tokens, tables):
@@ -228,7 +298,7 @@ class OracleRunner:
         return O.fork_topf(lg, glue_ids, fan_lists)
 
     @torch.inference_mode()
-    def draft_tree(self, forks, num_tokens, tables, jlists, temps=None):
+    def draft_tree(self, forks, num_tokens, tables, jlists, temps=None, eagle=False):
         """K tree-decode steps (draft_runner.py:713-812): returns tokens [B*MQ, K] (and keeps the per-branch logits
         for `tree_logits` when some temperature is > 0)."""
         B, K = forks.shape[0], self.K
@@ -237,7 +307,9 @@ class OracleRunner:
         toks = forks.reshape(-1)
         out = torch.zeros(B * mq, K, dtype=torch.int64)
         t = None if temps is None or not any(x > 0 for x in temps) else torch.tensor(temps, dtype=torch.float32).repeat_interleave(mq)
-        tl = []
+        tl, pres = [], []
+        if eagle:       # branch i starts from the glue prenorm of its position j_i (draft_runner.py:660-676), then conditions on itself
+            cond = torch.cat([self._glue_pre[b, torch.tensor(jlists[b])] for b in range(B)], dim=0)
         for d in range(K):
             pos, slots, ctx_lens = [], [], []
             for b, (n, tb) in enumerate(zip(num_tokens, tables)):
@@ -248,11 +320,16 @@ class OracleRunner:
                 ctx_lens.append(Pb + K + 1 + (d + 1) * mq)
             ctx = Ctx("tree", slot_mapping=torch.tensor(slots, dtype=torch.int32), context_lens=torch.tensor(ctx_lens, dtype=torch.int32),
                       block_tables=bt, tree_step=d, tree_K=K, tree_jidx=jlists)
-            lg = self._logits(self.model.forward(toks, torch.tensor(pos), ctx))
+            if eagle:
+                lg, cond = self._eagle_logits(toks, torch.tensor(pos), cond, ctx)
+                pres.append(cond)
+            else:
+                lg = self._logits(self.model.forward(toks, torch.tensor(pos), ctx))
             toks = O.argmax_rows(lg) if t is None else O.sample(lg, t, self.config.sampler_x, self.config.async_fan_out)
             tl.append(lg)
             out[:, d] = toks
         self._tree_lq = torch.stack(tl, dim=1) if t is not None else None
+        self._tree_acts = torch.stack(pres, dim=1) if pres else None
         return out
 
     def tree_logits(self, T):

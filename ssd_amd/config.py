@@ -56,7 +56,8 @@ class Config:
     # branches and the speculation cache are sharded over the members (engine/draft_runner.py)
     num_draft_gpus: int = 1
 
-    # EAGLE-3 (out of scope: no BASELINE config uses it; accepted so reference kwargs do not break)
+    # EAGLE-3 draft (reference config.py:36-40,72-92): a one-layer draft conditioned on target activations tapped at
+    # eagle_layers; asynchronous + greedy + jit_speculate only, as in the reference (bench.py:83-87, draft_runner.py:42-44)
     use_eagle: bool = False
     eagle_layers: list[int] | None = None
     d_model_target: int | None = None
@@ -85,7 +86,6 @@ class Config:
         assert 1 <= self.num_gpus <= 8, "single node only (reference ssd/config.py:55)"
         assert self.num_draft_gpus >= 1 and (self.num_draft_gpus == 1 or (self.speculate and self.draft_async)), \
             "num_draft_gpus > 1 needs draft_async"
-        assert not self.use_eagle, "EAGLE-3 drafts are out of scope for this engine (SURVEY.md section 2, row 19)"
         if self.hf_config is None:
             self.hf_config = resolve_model_config(self.model)
         self.max_model_len = min(self.max_model_len, self.hf_config.max_position_embeddings)
@@ -95,6 +95,24 @@ class Config:
                 self.draft_hf_config = resolve_model_config(self.draft)
             self.max_model_len = min(self.max_model_len, self.draft_hf_config.max_position_embeddings)
             assert self.draft_hf_config.vocab_size == self.hf_config.vocab_size, "draft and target vocab must match"
+            if self.use_eagle:
+                from dataclasses import replace
+                assert self.draft_async, "EAGLE-3 drafts are asynchronous-only (reference bench.py:87, speculator_sync.py:15)"
+                assert self.jit_speculate, "EAGLE requires jit_speculate=True (cache misses need draft activations; draft_runner.py:42-44)"
+                assert self.num_draft_gpus == 1, "EAGLE-3 drafts are not data-parallel"
+                if self.eagle_layers is None:
+                    L = self.hf_config.num_layers
+                    self.eagle_layers = [2, L // 2, L - 3]          # config.py:73-77
+                taps = sorted(set(self.eagle_layers))               # llama3.py:259-262 collects in layer order, once per layer
+                assert taps and 0 <= taps[0] and taps[-1] < self.hf_config.num_layers
+                self.d_model_target = self.hf_config.hidden_size
+                d = self.draft_hf_config
+                assert d.num_layers == 1, "an EAGLE-3 draft has exactly one decoder layer (eagle3_draft_llama3.py:192)"
+                # the draft takes the target's rope_theta and position range (config.py:78-92)
+                self.draft_hf_config = replace(d, family="eagle3", d_model_target=self.d_model_target, eagle_taps=len(taps),
+                                               draft_vocab_size=d.draft_vocab_size or d.vocab_size, rope_theta=self.hf_config.rope_theta,
+                                               max_position_embeddings=self.hf_config.max_position_embeddings)
+                self.max_model_len = min(self.max_model_len, self.hf_config.max_position_embeddings)
             if self.draft_async:
                 if self.fan_out_list is None:
                     self.fan_out_list = [self.async_fan_out] * (self.speculate_k + 1)

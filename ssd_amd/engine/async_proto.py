@@ -14,6 +14,11 @@ three-plus-logits:
        never reads logits_q (ssd/utils/verify.py:50-64,130), so the reference's 1.8 MB per-step transfer is skipped.
   hello reply int64[1] = number of draft KV blocks (the reference passes this through an mp.Queue,
        llm_engine.py:96-105).
+  EAGLE-3 (flags & FLAG_EAGLE; reference speculator_async.py:66-89,158-179, draft_runner.py:72-78,312-331): the target's
+     tapped activations ride ONE bf16 tensor after the payload instead of the reference's three messages --
+     prefill:   acts [sum of tokens, A]   (token j of the shifted prompt with the activation of position j-1)
+     speculate: payload += extend_counts[B] | extend_token_ids[B, K];  acts [B, K+1, A] = K extend rows (zero padded)
+                followed by the recovery token's activation
 
 Transports: torch.distributed p2p on the 2-rank async group (RCCL over one xGMI hop on the GPU path, gloo in the
 CPU tests), or an in-process loopback used by single-GPU tests.
@@ -28,6 +33,7 @@ import torch.distributed as dist
 
 CMD_SPECULATE, CMD_PREFILL, CMD_EXIT, CMD_HELLO = 0, 1, 2, 3
 FLAG_WANT_LOGITS = 1
+FLAG_EAGLE = 2
 HEADER_LEN = 4
 
 
@@ -40,7 +46,8 @@ def bits_temp(b: int) -> float:
 
 
 def pack_speculate(keys: list[tuple[int, int, int]], num_tokens: list[int], block_tables: list[list[int]],
-                   temps: list[float], max_blocks: int) -> list[int]:
+                   temps: list[float], max_blocks: int, extend_counts: list[int] | None = None,
+                   extend_ids: list[list[int]] | None = None) -> list[int]:
     out: list[int] = []
     for k in keys:
         out.extend(k)
@@ -49,10 +56,15 @@ def pack_speculate(keys: list[tuple[int, int, int]], num_tokens: list[int], bloc
         assert len(bt) <= max_blocks
         out.extend(bt + [-1] * (max_blocks - len(bt)))
     out.extend(temp_bits(t) for t in temps)
+    if extend_counts is not None:
+        out.extend(extend_counts)
+        for row in extend_ids:
+            out.extend(row)
     return out
 
 
-def unpack_speculate(payload: list[int], B: int, max_blocks: int):
+def unpack_speculate(payload: list[int], B: int, max_blocks: int, K: int | None = None):
+    """K given: the payload carries the EAGLE extend block; returns two more values (counts [B], ids [B][K])."""
     off = 0
     keys = [tuple(payload[off + 3 * b: off + 3 * b + 3]) for b in range(B)]
     off += 3 * B
@@ -62,6 +74,13 @@ def unpack_speculate(payload: list[int], B: int, max_blocks: int):
     off += B * max_blocks
     temps = [bits_temp(x) for x in payload[off:off + B]]
     off += B
+    if K is not None:
+        counts = payload[off:off + B]
+        off += B
+        ids = [payload[off + b * K: off + (b + 1) * K] for b in range(B)]
+        off += B * K
+        assert off == len(payload)
+        return keys, num_tokens, tables, temps, counts, ids
     assert off == len(payload)
     return keys, num_tokens, tables, temps
 

@@ -31,8 +31,11 @@ class Block:
 
 class BlockManager:
     def __init__(self, num_blocks: int, block_size: int, is_draft: bool = False, speculate_k: int = -1,
-                 max_model_len: int = -1, verbose: bool = False):
+                 max_model_len: int = -1, verbose: bool = False, prefix_cache: bool = True):
+        """prefix_cache=False: every allocation takes fresh blocks (EAGLE-3: the draft's KV row p belongs to token p+1 and
+        is conditioned on the target activation of position p, which a prefix hit would neither compute nor align)."""
         assert num_blocks > 0
+        self.prefix_cache = prefix_cache
         self.block_size = block_size
         self.is_draft = is_draft
         self.speculate_k = speculate_k
@@ -82,7 +85,7 @@ class BlockManager:
     def allocate(self, seq) -> None:
         table = self._table(seq)
         assert not table
-        h, missed = -1, False
+        h, missed = -1, not self.prefix_cache
         for i in range(seq.num_blocks):
             toks = seq.block(i)
             h = self.compute_hash(toks, h) if len(toks) == self.block_size else -1

@@ -15,6 +15,13 @@ Geometry, with P = num_tokens - 1 = position of the recovery tok
   cache             key (seq_id, j_i, fork token_i) -> K continuation tokens of branch i
 The speculation cache lives on the draft device (tokens) with its keys mirrored on the host; a request is
 answered before the glue/tree work of the new round starts, so that work overlaps the target's verify.
+
+EAGLE-3 drafts (config.use_eagle; reference branches at draft_runner.py:133-177,230-285,312-331,530-612,660-711):
+every draft position is shifted by -1 (KV row p holds token p+1, conditioned on the target's activation of position
+p), the request carries the recovery token's target activation plus the accepted draft tokens of the last round with
+THEIR target activations ("extend" rows, re-deposited by the glue in place of the self-conditioned rows the tree
+wrote), and the cache keeps each branch's K prenorm vectors next to its K tokens: they condition the spec rows of the
+next glue.
 """
 from __future__ import annotations
 
@@ -86,6 +93,9 @@ class DraftServer:
         self.cache_keys: dict[tuple[int, int, int], int] = {}
         self.cache_tokens = None            # device tensor [N, K]
         self.cache_logits = None            # device tensor [N, K, V] when the last tree was sampled (temperature > 0)
+        self.eagle = bool(getattr(config, "use_eagle", False))
+        self.cache_acts = None              # EAGLE: device tensor [N, K, h] of the branches' prenorm vectors
+        assert not (self.eagle and dp is not None), "EAGLE-3 drafts are not data-parallel"
         self.pending_forks = None           # device tensor [B, MQ] of the round whose keys are not mirrored yet
         self.pending_meta = None
         self.stats = {"requests": 0, "hits": 0, "rounds": 0}
@@ -130,7 +140,12 @@ class DraftServer:
             payload = dp.bcast_ints(payload, n)
         if cmd == P.CMD_PREFILL:
             toks, tables = P.unpack_prefill(payload, B, self.max_blocks)
-            self.runner.draft_prefill(toks, tables)
+            if flags & P.FLAG_EAGLE:        # draft_runner.py:72-78: one activation row per (shifted) prompt token
+                acts = self.tx.recv_tensor((sum(len(t) for t in toks), self.runner.cfg.eagle_taps * self.runner.cfg.d_model_target),
+                                           torch.bfloat16)
+                self.runner.draft_prefill(toks, tables, acts)
+            else:
+                self.runner.draft_prefill(toks, tables)
             return True
         if cmd == P.CMD_SPECULATE:
             self._speculate(B, payload, flags)
@@ -159,7 +174,17 @@ class DraftServer:
         K = self.K
         dp = self.dp
         lead = dp is None or dp.rank == 0
-        keys, num_tokens, tables, temps = P.unpack_speculate(payload, B, self.max_blocks)
+        eagle = None
+        if flags & P.FLAG_EAGLE:
+            keys, num_tokens, tables, temps, ext_counts, ext_ids = P.unpack_speculate(payload, B, self.max_blocks, K)
+            cfg = self.runner.cfg
+            acts = self.tx.recv_tensor((B, K + 1, cfg.eagle_taps * cfg.d_model_target), torch.bfloat16)
+            # every draft position is one behind the sequence (pos_offset = -1, draft_runner.py:133-135,409,497): the
+            # runner's geometry P = num_tokens - 1 becomes num_tokens - 2 by handing it num_tokens - 1
+            num_tokens = [n - 1 for n in num_tokens]
+            eagle = dict(acts=acts, ext_counts=ext_counts, ext_ids=ext_ids)
+        else:
+            keys, num_tokens, tables, temps = P.unpack_speculate(payload, B, self.max_blocks)
         if self._trace is not None:
             self._trace.flush(f"round={self.stats['rounds']} hits={self.stats['hits']}/{self.stats['requests']}")
             t_req = self._trace.mark()
@@ -199,6 +224,8 @@ class DraftServer:
                     tokens = tokens * torch.tensor(hits, dtype=torch.int64, device=tokens.device).unsqueeze(1)
                 if want_logits and self.cache_logits is not None:
                     logits_q = self.cache_logits[rows]          # [B, K, V]: the q the hit branch was sampled from
+                if eagle is not None:
+                    eagle["prev_acts"] = self.cache_acts[rows]  # [B, K, h]: the hit branches' prenorms (draft_runner.py:248-249)
             else:
                 tokens = torch.tensor(merged, dtype=torch.int64, device=dev)
                 if want_logits and sample:      # the owner's branch logits travel to the leader (and on to the target)
@@ -210,7 +237,10 @@ class DraftServer:
                         src = self.cache_logits[idx[b]] if (owner[b] == dp.rank and self.cache_logits is not None) else logits_q[b]
                         logits_q[b] = dp.bcast_tensor(src.contiguous(), owner[b])
         elif jit:
-            if lead:
+            if eagle is not None:       # the chain starts from fc(recovery activation) and conditions on itself (:133-177)
+                tokens = self.runner.draft_jit(rec, num_tokens, tables, temps, cond=eagle["acts"][:, K])
+                eagle["prev_acts"] = self.runner.jit_acts(B)
+            elif lead:
                 tokens = self.runner.draft_jit(rec, num_tokens, tables, temps)  # [B, K] on the draft device
                 if want_logits and sample:
                     logits_q = self.runner.logits_q(B)
@@ -236,13 +266,20 @@ class DraftServer:
             fan = [self.config.fan_out_list if h else self.config.fan_out_list_miss for h in hits]
             jl = [self.j_hit if h else self.j_miss for h in hits]
             glue_ids = torch.cat([torch.tensor(rec, dtype=torch.int64, device=tokens.device).unsqueeze(1), tokens], dim=1)
-            forks = self.runner.draft_glue_fork(glue_ids, num_tokens, tables, fan)          # [B, MQ] (replicated under DP)
+            if eagle is not None:
+                forks = self.runner.draft_glue_fork(glue_ids, num_tokens, tables, fan, eagle=eagle)
+            else:
+                forks = self.runner.draft_glue_fork(glue_ids, num_tokens, tables, fan)      # [B, MQ] (replicated under DP)
             t_b = self._trace.mark() if self._trace is not None else None
             if dp is not None:          # my slice of the branches: K tree steps of MQ/D rows instead of MQ
                 lo, hi = dp.shard(self.mq)
                 forks = forks[:, lo:hi].contiguous()
                 jl = [j[lo:hi] for j in jl]
-            self.cache_tokens = self.runner.draft_tree(forks, num_tokens, tables, jl, temps)  # [B*mq', K]
+            if eagle is not None:
+                self.cache_tokens = self.runner.draft_tree(forks, num_tokens, tables, jl, temps, eagle=True)
+                self.cache_acts = self.runner.tree_acts(forks.numel())
+            else:
+                self.cache_tokens = self.runner.draft_tree(forks, num_tokens, tables, jl, temps)  # [B*mq', K]
             self.cache_logits = self.runner.tree_logits(forks.numel()) if sample else None
             self.pending_forks = forks
             self.pending_meta = ([k[0] for k in keys], jl)
@@ -252,6 +289,7 @@ class DraftServer:
                 self._trace.span(f"tree[{forks.shape[1]}x{self.K}]", t_b, self._trace.mark())
         self.cache_keys = {}
         self.cache_tokens = None
+        self.cache_acts = None
         if self.deferred:
             self._parked = next_round
         else:

@@ -213,7 +213,7 @@ class LLMEngine:
         verifier = Verifier(config.speculate_k, self.topo.device, self.model_runner, sampler_x=config.sampler_x,
                             async_fan_out=config.async_fan_out, jit_speculate=config.jit_speculate,
                             tokenizer=self.tokenizer, metrics=METRICS)
-        return SpecDecodeStep(self.scheduler, speculator, verifier, eagle=False, tokenizer=self.tokenizer,
+        return SpecDecodeStep(self.scheduler, speculator, verifier, eagle=config.use_eagle, tokenizer=self.tokenizer,
                               async_spec=config.draft_async)
 
     def log_metrics(self) -> None:

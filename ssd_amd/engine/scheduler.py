@@ -32,13 +32,14 @@ class Scheduler:
         self.K = config.speculate_k
         self.block_size = config.kvcache_block_size
         self.MQ_LEN = sum(config.fan_out_list) if (config.speculate and config.draft_async) else 0
+        pc = not getattr(config, "use_eagle", False)
         self.block_manager = BlockManager(config.num_kvcache_blocks, self.block_size, is_draft=False,
-                                          max_model_len=self.max_model_len)
+                                          max_model_len=self.max_model_len, prefix_cache=pc)
         self.draft_block_manager = None
         if self.speculate:
             assert draft_num_blocks is not None and draft_num_blocks > 0
             self.draft_block_manager = BlockManager(draft_num_blocks, self.block_size, is_draft=True,
-                                                    speculate_k=self.K, max_model_len=self.max_model_len)
+                                                    speculate_k=self.K, max_model_len=self.max_model_len, prefix_cache=pc)
         self.waiting: deque[Sequence] = deque()
         self.running: deque[Sequence] = deque()
 
@@ -113,6 +114,7 @@ class Scheduler:
         self.waiting.appendleft(seq)
         seq.num_prompt_tokens = seq.num_tokens      # completions so far are re-prefilled as prompt
         seq.last_spec_step_accepted_len = -1
+        seq.extend_count, seq.extend_eagle_acts, seq.extend_token_ids = 0, None, None     # scheduler.py:143-146
 
     # ---- autoregressive post-step (reference scheduler.py:149-170) ----
     def postprocess(self, seqs: list[Sequence], token_ids: list[int], is_prefill: bool) -> None:
@@ -179,10 +181,17 @@ class Scheduler:
 
     def postprocess_speculate(self, seqs: list[Sequence], new_suffixes: list[list[int]], next_recovery_tokens: list[int],
                               eagle_acts=None) -> None:
-        for seq, suffix, rec in zip(seqs, new_suffixes, next_recovery_tokens):
+        for i, (seq, suffix, rec) in enumerate(zip(seqs, new_suffixes, next_recovery_tokens)):
             suffix, finished = self._clip_suffix(seq, suffix)
             self._return_excess_blocks(seq, len(suffix))
             self._commit_suffix(seq, suffix, rec)
+            if eagle_acts is not None:          # scheduler.py:303-320; eagle_acts [B, K+1, taps * h_target]
+                n = len(suffix)                 # suffix = [recovery, accepted draft tokens...]
+                seq.last_target_hidden_state = eagle_acts[i, min(n - 1, eagle_acts.shape[1] - 1)]
+                n_ext = min(n - 1, self.K)
+                seq.extend_count = n_ext
+                seq.extend_eagle_acts = eagle_acts[i, :n_ext].clone() if n_ext > 0 else None
+                seq.extend_token_ids = list(suffix[1:1 + n_ext]) if n_ext > 0 else None
             if finished:
                 seq.status = SequenceStatus.FINISHED
                 self.block_manager.deallocate(seq)

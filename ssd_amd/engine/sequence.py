@@ -39,6 +39,12 @@ class Sequence:
         self.draft_temperature = sp.draft_temperature
         self.max_new_tokens = sp.max_new_tokens
         self.ignore_eos = sp.ignore_eos
+        # EAGLE-3 (reference sequence.py:23-24,47-51): the target activation that conditions the next recovery token, and
+        # the accepted draft tokens + their target activations that the draft re-deposits ("extends") at the next glue
+        self.last_target_hidden_state = None
+        self.extend_eagle_acts = None
+        self.extend_token_ids: list[int] | None = None
+        self.extend_count = 0
 
     def __len__(self) -> int:
         return self.num_tokens

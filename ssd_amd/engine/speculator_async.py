@@ -43,12 +43,14 @@ class AsyncLink:
             v = self.tx.recv_ints(1)
         return self._bcast_ints(v, 1)[0]
 
-    def prefill(self, token_lists, block_tables) -> None:
+    def prefill(self, token_lists, block_tables, eagle_acts=None) -> None:
         if not self.is_head:
             return
         payload = P.pack_prefill(token_lists, block_tables, self.max_blocks)
-        self.tx.send_ints([P.CMD_PREFILL, len(token_lists), len(payload), 0])
+        self.tx.send_ints([P.CMD_PREFILL, len(token_lists), len(payload), P.FLAG_EAGLE if eagle_acts is not None else 0])
         self.tx.send_ints(payload)
+        if eagle_acts is not None:
+            self.tx.send_tensor(eagle_acts)
         # co-located draft server (loopback transport): let it take the command NOW, so that its prefill is enqueued on the
         # draft stream before the target's prefill starts (step.py:75-79: "draft and target prefill overlap") instead of
         # at the first speculation request
@@ -56,16 +58,23 @@ class AsyncLink:
         if pump is not None:
             pump()
 
-    def speculate(self, keys, num_tokens, block_tables, temps, want_logits: bool = False):
+    def speculate(self, keys, num_tokens, block_tables, temps, want_logits: bool = False, eagle=None):
         """-> (hits, tokens, logits_q or None).  logits_q bf16 [B, K, V] is requested only when some temperature is
         > 0 (FLAG_WANT_LOGITS) and reaches every TP rank: each rank runs the ratio test on its own device."""
         B, K = len(keys), self.K
         resp, lq = None, None
         V = self.config.hf_config.vocab_size
         if self.is_head:
-            payload = P.pack_speculate(keys, num_tokens, block_tables, temps, self.max_blocks)
-            self.tx.send_ints([P.CMD_SPECULATE, B, len(payload), P.FLAG_WANT_LOGITS if want_logits else 0])
+            flags = P.FLAG_WANT_LOGITS if want_logits else 0
+            if eagle is not None:       # (extend_counts [B], extend_ids [B][K], acts [B, K+1, A])
+                payload = P.pack_speculate(keys, num_tokens, block_tables, temps, self.max_blocks, eagle[0], eagle[1])
+                flags |= P.FLAG_EAGLE
+            else:
+                payload = P.pack_speculate(keys, num_tokens, block_tables, temps, self.max_blocks)
+            self.tx.send_ints([P.CMD_SPECULATE, B, len(payload), flags])
             self.tx.send_ints(payload)
+            if eagle is not None:
+                self.tx.send_tensor(eagle[2])
             resp = self.tx.recv_tensor((B + B * K,), torch.int64).tolist()
             if want_logits:
                 lq = self.tx.recv_tensor((B, K, V), torch.bfloat16).to(self.topo.device)
@@ -90,7 +99,18 @@ class SpeculatorAsync(SpeculatorBase):
         self.link, self.config = link, config
 
     def prefill(self, seqs, verify_result: VerifyResult) -> SpeculateResult:
-        self.link.prefill([list(s.token_ids) for s in seqs], [list(s.draft_block_table) for s in seqs])
+        token_lists = [list(s.token_ids) for s in seqs]
+        acts = verify_result.eagle_acts
+        if acts is not None:
+            # EAGLE token-conditioning shift (speculator_async.py:66-77): token j is conditioned on the target activation of
+            # position j-1 -- drop every sequence's first token and its last activation
+            rows, off = [], 0
+            for ids in token_lists:
+                rows.append(acts[off:off + len(ids) - 1])
+                off += len(ids)
+            acts = torch.cat(rows, dim=0)
+            token_lists = [ids[1:] for ids in token_lists]
+        self.link.prefill(token_lists, [list(s.draft_block_table) for s in seqs], eagle_acts=acts)
         return SpeculateResult([], [])
 
     def speculate(self, seqs, verify_result: VerifyResult) -> SpeculateResult:
@@ -106,7 +126,20 @@ class SpeculatorAsync(SpeculatorBase):
             temps.append(seq.draft_temperature if seq.draft_temperature is not None else seq.temperature)
         # the target's temperature matters too: a greedy draft under a sampling target still takes the ratio path
         want = any(t > 0 for t in temps) or any(s.temperature > 0 for s in seqs)
-        hits, tokens, logits_q = self.link.speculate(keys, nts, tables, temps, want_logits=want)
+        eagle = None
+        if verify_result.eagle_acts is not None:       # speculator_async.py:158-179
+            first = seqs[0].last_target_hidden_state
+            acts = first.new_zeros(len(seqs), K + 1, first.shape[-1])
+            counts, ext_ids = [], []
+            for i, seq in enumerate(seqs):
+                n = seq.extend_count if seq.extend_eagle_acts is not None else 0
+                counts.append(n)
+                ext_ids.append((list(seq.extend_token_ids[:n]) if n else []) + [0] * (K - n))
+                if n:
+                    acts[i, :n] = seq.extend_eagle_acts[:n]
+                acts[i, K] = seq.last_target_hidden_state
+            eagle = (counts, ext_ids, acts)
+        hits, tokens, logits_q = self.link.speculate(keys, nts, tables, temps, want_logits=want, eagle=eagle)
         rows = []
         for seq, toks in zip(seqs, tokens):
             rows.append([seq.recovery_token_id] + toks)

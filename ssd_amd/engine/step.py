@@ -44,11 +44,11 @@ class SpecDecodeStep(InferenceStep):
         self.eagle, self.tokenizer, self.async_spec = eagle, tokenizer, async_spec
 
     def prefill(self, seqs) -> int:
-        if self.async_spec:       # draft (other GPU) and target prefill overlap (step.py:75-79)
+        if self.async_spec and not self.eagle:       # draft (other GPU) and target prefill overlap (step.py:75-79)
             self.speculator.prefill(seqs, VerifyResult([], [], None))
             self.verifier.prefill(seqs)
-        else:
-            vr = self.verifier.prefill(seqs)
+        else:                      # an EAGLE draft prefills from the target's activations: target first (step.py:80-82)
+            vr = self.verifier.prefill(seqs, eagle=self.eagle)
             self.speculator.prefill(seqs, vr)
         for seq in seqs:
             assert seq.recovery_token_id is not None
@@ -61,13 +61,14 @@ class SpecDecodeStep(InferenceStep):
         trace = prof.enabled("SSD_PROFILE")           # reference step.py:92-161
         t0 = prof.sync_now() if trace else 0.0
         saved = [seq.snapshot() for seq in seqs]
-        spec = self.speculator.speculate(seqs, VerifyResult([], [], None))
+        spec = self.speculator.speculate(seqs, VerifyResult([], [], True if self.eagle else None))
         t1 = prof.sync_now() if trace else 0.0
-        out = self.verifier.verify(seqs, spec)
+        out = self.verifier.verify(seqs, spec, eagle=self.eagle)
         t2 = prof.sync_now() if trace else 0.0
         for seq, snap in zip(seqs, saved):      # undo the lookahead applied by speculate + verify
             seq.restore(snap)
-        self.scheduler.postprocess_speculate(seqs, out.new_suffixes, out.recovery_tokens)
+        self.scheduler.postprocess_speculate(seqs, out.new_suffixes, out.recovery_tokens,
+                                             eagle_acts=out.eagle_acts if self.eagle else None)
         toks = sum(len(s) for s in out.new_suffixes)
         if trace:
             t3 = prof.sync_now()

@@ -20,9 +20,18 @@ class Verifier(VerifierBase):
 
     def prefill(self, seqs, eagle: bool = False) -> VerifyResult:
         token_ids = self.target_model_runner.call("run", seqs, True)
+        acts = None
+        if eagle:       # verifier.py:34-46: the tapped activations of every prompt token; the last one conditions the recovery token
+            for s in seqs:
+                assert s.num_cached_tokens == 0, "EAGLE-3 needs the activations of the whole prompt (no prefix-cache hits)"
+            acts = self.target_model_runner.eagle_acts(sum(len(s) for s in seqs)).clone()
+        off = 0
         for seq, tok in zip(seqs, token_ids):
             seq.recovery_token_id = tok
-        return VerifyResult([], [seq.recovery_token_id for seq in seqs], None)
+            if eagle:
+                off += len(seq)
+                seq.last_target_hidden_state = acts[off - 1]
+        return VerifyResult([], [seq.recovery_token_id for seq in seqs], acts)
 
     def verify(self, seqs, speculate_result: SpeculateResult, eagle: bool = False) -> VerifyResult:
         temps_t = [float(s.temperature) for s in seqs]
@@ -43,7 +52,7 @@ class Verifier(VerifierBase):
         if prof.enabled("SSD_PROFILE_TARGET") or prof.enabled("SSD_PROFILE"):     # reference verifier.py:63-74,111-113
             # forward + accept/reject are ONE device graph here and its result read is the step's only host sync, so
             # the reference's separate target_fwd / verify_compute spans collapse into a single span
-            print(f"[PROFILE verifier] target_call={(prof.sync_now() - t0) * 1e3:.2f}ms eagle=False bs={len(seqs)}", flush=True)
+            print(f"[PROFILE verifier] target_call={(prof.sync_now() - t0) * 1e3:.2f}ms eagle={eagle} bs={len(seqs)}", flush=True)
         self.metrics.setdefault("target_verify_times", []).append(perf_counter() - t0)
         self.metrics.setdefault("accepted_suffix_lens_with_recovery", []).extend(len(s) for s in new_suffixes)
         hits = speculate_result.cache_hits
@@ -52,4 +61,8 @@ class Verifier(VerifierBase):
             self.metrics.setdefault("cache_hits", []).append(sum(hl) / max(1, len(hl)))
             for h, s in zip(hl, new_suffixes):
                 self.metrics.setdefault("accepted_suffix_lens_on_hit" if h == 1 else "accepted_suffix_lens_on_miss", []).append(len(s))
-        return VerifyResult(new_suffixes, recovery, None)
+        acts = None
+        if eagle:       # verifier.py:145-147
+            B = len(seqs)
+            acts = self.target_model_runner.eagle_acts(B * (self.lookahead + 1)).clone().view(B, self.lookahead + 1, -1)
+        return VerifyResult(new_suffixes, recovery, acts)

@@ -25,7 +25,29 @@ from ssd_amd.model_config import ModelConfig
 BF16 = torch.bfloat16
 
 
+def eagle_param_shapes(cfg: ModelConfig) -> list[tuple[str, tuple[int, ...]]]:
+    """Eagle3DraftForCausalLM's parameters under the reference's module names (eagle3_draft_llama3.py:101-140,159-194,
+    209-262): QKV reads the 2h-wide [token | conditioning] concatenation, the LM head covers draft_vocab_size tokens and
+    ``d2t`` (int64, target id = draft id + d2t[draft id], :325-327) places them in the target vocabulary."""
+    h, hd, nh, nkv, I = cfg.hidden_size, cfg.head_dim, cfg.num_heads, cfg.num_kv_heads, cfg.intermediate_size
+    p = "model.layer."
+    return [("model.embed_tokens.weight", (cfg.vocab_size, h)),
+            ("fc.weight", (h, cfg.eagle_taps * cfg.d_model_target)),
+            (p + "input_layernorm.weight", (h,)),
+            (p + "conditioning_feature_ln.weight", (h,)),
+            (p + "self_attn.qkv_proj.weight", ((nh + 2 * nkv) * hd, 2 * h)),
+            (p + "self_attn.o_proj.weight", (h, nh * hd)),
+            (p + "post_attention_layernorm.weight", (h,)),
+            (p + "mlp.gate_up_proj.weight", (2 * I, h)),
+            (p + "mlp.down_proj.weight", (h, I)),
+            ("final_norm.weight", (h,)),
+            ("lm_head.weight", (cfg.draft_vocab_size, h)),
+            ("d2t", (cfg.draft_vocab_size,))]
+
+
 def param_shapes(cfg: ModelConfig) -> list[tuple[str, tuple[int, ...]]]:
+    if cfg.family == "eagle3":
+        return eagle_param_shapes(cfg)
     h, hd, nh, nkv, I, V = cfg.hidden_size, cfg.head_dim, cfg.num_heads, cfg.num_kv_heads, cfg.intermediate_size, cfg.vocab_size
     out = [("model.embed_tokens.weight", (V, h))]
     for i in range(cfg.num_layers):
@@ -97,7 +119,14 @@ def synthetic_tensor(name: str, shape, seed: int, std: float, gen_device: str, n
             return t
     g = torch.Generator(device=gen_device)
     g.manual_seed(_name_seed(seed, name))
-    if "norm" in name:
+    if name == "d2t":       # an increasing map of the draft vocabulary into the target's (like the frequency-sorted real ones)
+        V = int(recipe["target_vocab"]) if recipe and "target_vocab" in recipe else None
+        assert V is not None and V >= shape[0], "d2t needs recipe['target_vocab']"
+        gc = torch.Generator()
+        gc.manual_seed(_name_seed(seed, name))
+        idx = torch.randperm(V, generator=gc)[:shape[0]].sort().values
+        return (idx - torch.arange(shape[0])).to(torch.int64).to(gen_device)
+    if "norm" in name or name.endswith("_ln.weight"):
         if norm_jitter == 0.0:
             return torch.ones(shape, dtype=BF16, device=gen_device)
         return (1.0 + norm_jitter * torch.randn(shape, generator=g, device=gen_device, dtype=torch.float32)).to(BF16)
@@ -125,6 +154,9 @@ def synthetic_weights(cfg: ModelConfig, seed: int, std: float, rank: int = 0, tp
                       out_device: str | None = None, norm_jitter: float = 0.0,
                       recipe: dict | None = None) -> Iterator[tuple[str, torch.Tensor]]:
     """Yields (name, this rank's shard) one tensor at a time (bounded transient memory for 70B)."""
+    if cfg.family == "eagle3":          # d2t needs the target vocabulary size; the draft is never tensor-parallel
+        assert tp == 1
+        recipe = dict(recipe or {}, target_vocab=cfg.vocab_size)
     for name, shape in param_shapes(cfg):
         w = shard_param(cfg, name, synthetic_tensor(name, shape, seed, std, gen_device, norm_jitter, recipe), rank, tp)
         yield name, (w.to(out_device) if out_device is not None else w)
@@ -141,6 +173,48 @@ def synthetic_state_dict(cfg: ModelConfig, seed: int, std: float, norm_jitter: f
 
 def has_safetensors(model_dir: str) -> bool:
     return os.path.isdir(model_dir) and bool(glob.glob(os.path.join(model_dir, "*.safetensors")))
+
+
+def load_eagle_safetensors(cfg: ModelConfig, model_dir: str, target_dir: str | None = None,
+                           out_device: str | None = None) -> Iterator[tuple[str, torch.Tensor]]:
+    """EAGLE-3 checkpoints (reference load_eagle_model, ssd/utils/loader.py:64-183): a flat state dict with
+    midlayer.* (q/k/v and gate/up unpacked, hidden_norm = the conditioning-feature norm), norm.weight (final norm),
+    fc.weight, lm_head.weight, d2t / t2d, and embed_tokens.weight -- taken from the TARGET checkpoint when the draft
+    ships none (:118-125, load_embedding_from_target :9-61)."""
+    from safetensors import safe_open
+    sd: dict[str, torch.Tensor] = {}
+    for f in sorted(glob.glob(os.path.join(model_dir, "*.safetensors"))):
+        with safe_open(f, "pt", "cpu") as sf:
+            for k in sf.keys():
+                sd[k] = sf.get_tensor(k)
+    if "embed_tokens.weight" not in sd:
+        assert target_dir is not None and has_safetensors(target_dir), "EAGLE-3 draft without embed_tokens needs the target checkpoint"
+        for f in sorted(glob.glob(os.path.join(target_dir, "*.safetensors"))):
+            with safe_open(f, "pt", "cpu") as sf:
+                for k in sf.keys():
+                    if k.endswith("embed_tokens.weight"):
+                        sd["embed_tokens.weight"] = sf.get_tensor(k)
+        assert "embed_tokens.weight" in sd, f"no embed_tokens.weight under {target_dir}"
+    ml = "midlayer."
+    src = {
+        "model.embed_tokens.weight": lambda: sd["embed_tokens.weight"],
+        "fc.weight": lambda: sd["fc.weight"],
+        "model.layer.input_layernorm.weight": lambda: sd[ml + "input_layernorm.weight"],
+        "model.layer.conditioning_feature_ln.weight": lambda: sd[ml + "hidden_norm.weight"],
+        "model.layer.self_attn.qkv_proj.weight": lambda: torch.cat([sd[ml + f"self_attn.{x}_proj.weight"] for x in "qkv"], 0),
+        "model.layer.self_attn.o_proj.weight": lambda: sd[ml + "self_attn.o_proj.weight"],
+        "model.layer.post_attention_layernorm.weight": lambda: sd[ml + "post_attention_layernorm.weight"],
+        "model.layer.mlp.gate_up_proj.weight": lambda: torch.cat([sd[ml + "mlp.gate_proj.weight"], sd[ml + "mlp.up_proj.weight"]], 0),
+        "model.layer.mlp.down_proj.weight": lambda: sd[ml + "mlp.down_proj.weight"],
+        "final_norm.weight": lambda: sd["norm.weight"],
+        "lm_head.weight": lambda: sd["lm_head.weight"],
+        "d2t": lambda: sd["d2t"],
+    }
+    for name, shape in eagle_param_shapes(cfg):
+        w = src[name]()
+        w = w.to(torch.int64) if name == "d2t" else w.to(BF16)
+        assert tuple(w.shape) == tuple(shape), f"{name}: {tuple(w.shape)} != {shape}"
+        yield name, (w.to(out_device) if out_device is not None else w)
 
 
 def load_safetensors(cfg: ModelConfig, model_dir: str, rank: int = 0, tp: int = 1,

@@ -1,0 +1,101 @@
+"""EAGLE-3 through the real engine on CPU (oracle runners): scheduler bookkeeping, the wire protocol with activation
+tensors, the draft server's hit / JIT / extend paths.  The output must be the target's own greedy stream whatever the
+draft proposes; the peaky weight pair (tests/eagle_util.py) makes it propose acceptable tokens often enough that cache
+hits, multi-token acceptance and the extend rows all occur."""
+import os
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+from tests.eagle_util import eagle_cfgs, peaky_weights, eagle_kwargs, ENGINE_KW, PROMPTS, K
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def generate(mode, bs=1, new_tokens=40, **extra):
+    from oracle.runner import oracle_runner_factory
+    from ssd_amd.engine.llm_engine import LLMEngine
+    from ssd_amd.sampling_params import SamplingParams
+    t, d = eagle_cfgs()
+    tw, dw = peaky_weights(t, d)
+    factory = oracle_runner_factory(weights_target=tw, weights_draft=dw)
+    if mode == "ar":
+        eng = LLMEngine("t", runner_factory=factory, **dict(ENGINE_KW, hf_config=t, max_num_seqs=bs))
+    else:
+        eng = LLMEngine("t", runner_factory=factory, inprocess_draft="num_gpus" not in extra, **eagle_kwargs(t, d, bs=bs, **extra))
+    out, m = eng.generate(PROMPTS[:bs], SamplingParams(temperature=0, max_new_tokens=new_tokens, ignore_eos=True), use_tqdm=False)
+    stats = eng.draft_server.stats if eng.draft_server is not None else None
+    eng.exit()
+    return [o["token_ids"] for o in out], m, stats
+
+
+def test_eagle_async_stream_is_exact_and_uses_hit_and_extend_paths():
+    ar, _, _ = generate("ar")
+    asy, m, stats = generate("eagle")
+    assert asy == ar
+    lens = m["accepted_suffix_lens_with_recovery"]
+    assert max(lens) >= 2, lens                     # some draft token was accepted -> the next request carried extend rows
+    assert stats["hits"] >= 1                       # some request was answered from the speculation cache (with its prenorms)
+    assert stats["requests"] == len(lens)
+
+
+def test_eagle_async_batch():
+    ar, _, _ = generate("ar", bs=3, new_tokens=24)
+    asy, m, stats = generate("eagle", bs=3, new_tokens=24)
+    assert asy == ar
+
+
+def test_eagle_config_rules():
+    import pytest
+    from ssd_amd.config import Config
+    t, d = eagle_cfgs()
+    base = dict(hf_config=t, draft="d", draft_hf_config=d, speculate=True, speculate_k=K, use_eagle=True)
+    with pytest.raises(AssertionError):
+        Config("t", **base)                                                     # synchronous speculation
+    with pytest.raises(AssertionError):
+        Config("t", draft_async=True, num_gpus=2, **base)                       # jit_speculate is mandatory
+    c = Config("t", draft_async=True, num_gpus=2, jit_speculate=True, **base)
+    assert c.eagle_layers == [2, 2, 1] and c.draft_hf_config.eagle_taps == 2    # the reference's default taps, de-duplicated
+    assert c.draft_hf_config.family == "eagle3" and c.draft_hf_config.d_model_target == t.hidden_size
+
+
+def test_proto_roundtrip_with_extend_block():
+    from ssd_amd.engine import async_proto as P
+    keys, nts, tabs, temps = [(3, 1, 9), (4, -2, 7)], [20, 31], [[1, 2], [5]], [0.0, 0.0]
+    payload = P.pack_speculate(keys, nts, tabs, temps, 4, [2, 0], [[11, 12, 0], [0, 0, 0]])
+    k2, n2, t2, tm2, counts, ids = P.unpack_speculate(payload, 2, 4, 3)
+    assert k2 == keys and n2 == nts and counts == [2, 0] and ids == [[11, 12, 0], [0, 0, 0]]
+    assert t2 == [[1, 2, -1, -1], [5, -1, -1, -1]]
+
+
+def _worker(rank, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    toks, m, _ = generate("eagle", num_gpus=2)
+    q.put((rank, toks, m["accepted_suffix_lens_with_recovery"]))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eagle_two_processes_gloo():
+    """Target on rank 0, the EAGLE draft server on rank 1: the activation tensors cross the process boundary."""
+    ar, _, _ = generate("ar")
+    _, m_loop, _ = generate("eagle")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 90)
+    ps = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r, toks, lens = q.get(timeout=300)
+        got[r] = (toks, lens)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][0] == ar and got[1][0] == []
+    assert got[0][1] == m_loop["accepted_suffix_lens_with_recovery"]      # same acceptance trace as the in-process server
