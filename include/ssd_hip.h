@@ -67,6 +67,12 @@ int ssd_rmsnorm(const void* x_rows, const void* res_in, void* res_out, const voi
 int ssd_rmsnorm_parts(const void* parts, int splits, int slab_rows, const void* res_in, void* res_out, const void* weight,
                       float eps, void* out_rows, void* out_frag, int T, int H, void* stream);
 
+/* The EAGLE-3 draft layer's QKV input, torch.cat([input_layernorm(token_embeddings), conditioning_feature_ln(features)], -1)
+ * -- ssd/models/eagle3_draft_llama3.py:148-150 -- written directly as ONE fragment-major [T][2H] activation (each half is
+ * RMSDNorm.norm_forward as in ssd_rmsnorm). */
+int ssd_rmsnorm_pair(const void* x0_rows, const void* weight0, const void* x1_rows, const void* weight1, float eps,
+                     void* out_frag, int T, int H, void* stream);
+
 /* F.linear(x, W, b) -- ssd/layers/linear.py:65,98,196; ssd/layers/embed_head.py:88,95,111.
  * x_frag [M][K] frag, w_frag [N][K] frag, bias bf16[N] or NULL.  M <= 128 per call.
  * SSD_EPI_SILU_FRAG additionally fuses SiluAndMul.forward -- ssd/layers/activation.py:11-14. */

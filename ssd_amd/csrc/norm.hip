@@ -114,6 +114,73 @@ extern "C" int ssd_rmsnorm(const void* x_rows, const void* res_in, void* res_out
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
+// Two independent RMSNorms written side by side into ONE [T][2H] fragment-major activation: the input of the EAGLE-3
+// draft layer's QKV projection, cat([input_layernorm(token embeddings), conditioning_feature_ln(features)], -1)
+// (ssd/models/eagle3_draft_llama3.py:148-150).  blockIdx.y selects the half; each half is exactly ssd_rmsnorm's
+// norm_forward (fp32 math, one rounding at the store), so the concatenation costs no extra pass over the rows.
+template <int NORM_THREADS>
+__global__ void __launch_bounds__(NORM_THREADS)
+rmsnorm_pair_kernel(const u32x4_t* __restrict__ x0, const u32x4_t* __restrict__ w0, const u32x4_t* __restrict__ x1,
+                    const u32x4_t* __restrict__ w1, float eps, u32x4_t* __restrict__ out_frag, int H) {
+  __shared__ float red[NORM_THREADS / 64];
+  const int row = blockIdx.x, half = blockIdx.y;
+  const u32x4_t* x = half ? x1 : x0;
+  const u32x4_t* w = half ? w1 : w0;
+  const int H8 = H >> 3;
+  const int KT2 = H >> 4;                 // k-tiles of the 2H-wide output
+  constexpr int NORM_MAXC = NORM_MAXH / 8 / NORM_THREADS;
+  float v[NORM_MAXC][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_MAXC; ++i) {
+    const int c = threadIdx.x + i * NORM_THREADS;
+    if (c < H8) {
+      const u32x4_t xv = x[(size_t)row * H8 + c];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float lo = bf2f(xv[j] & 0xffffu), hi = bf2f(xv[j] >> 16);
+        v[i][2 * j] = lo; v[i][2 * j + 1] = hi;
+        ss += lo * lo; ss += hi * hi;
+      }
+    }
+  }
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_THREADS / 64; ++i) tot += red[i];
+  const float rs = 1.0f / sqrtf(tot / (float)H + eps);
+#pragma unroll
+  for (int i = 0; i < NORM_MAXC; ++i) {
+    const int c = threadIdx.x + i * NORM_THREADS;
+    if (c < H8) {
+      const u32x4_t wv = w[c];
+      u32x4_t o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float lo = (v[i][2 * j] * rs) * bf2f(wv[j] & 0xffffu);
+        const float hi = (v[i][2 * j + 1] * rs) * bf2f(wv[j] >> 16);
+        o[j] = pack_bf2(lo, hi);
+      }
+      out_frag[frag_chunk(row, c + half * H8, KT2)] = o;
+    }
+  }
+}
+
+extern "C" int ssd_rmsnorm_pair(const void* x0_rows, const void* weight0, const void* x1_rows, const void* weight1, float eps,
+                                void* out_frag, int T, int H, void* stream) {
+  if (T <= 0 || H <= 0 || (H & 31) || H > NORM_MAXH) return SSD_ERR_SHAPE;
+  if (!x0_rows || !x1_rows || !weight0 || !weight1 || !out_frag) return SSD_ERR_ARG;
+  if (ssd_norm_threads(H) == 1024)
+    hipLaunchKernelGGL(rmsnorm_pair_kernel<1024>, dim3(T, 2), dim3(1024), 0, (hipStream_t)stream, (const u32x4_t*)x0_rows,
+                       (const u32x4_t*)weight0, (const u32x4_t*)x1_rows, (const u32x4_t*)weight1, eps, (u32x4_t*)out_frag, H);
+  else
+    hipLaunchKernelGGL(rmsnorm_pair_kernel<256>, dim3(T, 2), dim3(256), 0, (hipStream_t)stream, (const u32x4_t*)x0_rows,
+                       (const u32x4_t*)weight0, (const u32x4_t*)x1_rows, (const u32x4_t*)weight1, eps, (u32x4_t*)out_frag, H);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
 // Same with x given as `splits` fp32 partial slabs [splits][slab_rows][H] of the producing split-K GEMM (ssd_gemm_parts):
 // x = bf16(sum over the slabs in order), then exactly ssd_rmsnorm.
 extern "C" int ssd_rmsnorm_parts(const void* parts, int splits, int slab_rows, const void* res_in, void* res_out,

@@ -54,6 +54,8 @@ def _load_tokenizer(path: str):
 
 def hip_runner_factory(config, model_cfg, *, is_draft: bool, topo, **kw):
     from ssd_amd.engine.model_runner import ModelRunner
+    if model_cfg.family == "eagle3":
+        from ssd_amd.engine.eagle_runner import EagleDraftRunner as ModelRunner
     path = config.draft if is_draft else config.model
     return ModelRunner(config, model_cfg, is_draft=is_draft, device=topo.device, tp_rank=topo.tp_rank,
                        tp_size=topo.tp_size, tp_group=topo.tp_group, model_path=path if os.path.isdir(path or "") else None,

@@ -51,13 +51,23 @@ class ModelRunner:
         dec_tokens = self.max_bs * max(1, self.K + 1, mq)
         self.max_decode_tokens = max_decode_tokens or dec_tokens
         max_tokens = max(config.max_num_batched_tokens, self.max_decode_tokens)
-        self.model = HipDecoder(model_cfg, max_tokens=max_tokens, max_seqs=self.max_bs, max_blocks=self.max_blocks,
-                                block_size=self.block_size, max_model_len=config.max_model_len, device=device,
-                                tp_rank=tp_rank, tp_size=tp_size, tp_group=tp_group,
-                                max_logit_rows=max(self.max_decode_tokens, self.seq_cap),
-                                max_split_tokens=max(256, self.max_decode_tokens), force_collectives=force_collectives)
+        eagle = bool(getattr(config, "use_eagle", False))
+        model_cls = HipDecoder
+        if model_cfg.family == "eagle3":
+            from ssd_amd.eagle import HipEagleDraft as model_cls
+        # EAGLE-3 target: tap the residual stream entering config.eagle_layers on every forward (reference llama3.py:256-271)
+        taps = list(config.eagle_layers) if (eagle and not is_draft) else None
+        self.model = model_cls(model_cfg, max_tokens=max_tokens, max_seqs=self.max_bs, max_blocks=self.max_blocks,
+                               block_size=self.block_size, max_model_len=config.max_model_len, device=device,
+                               tp_rank=tp_rank, tp_size=tp_size, tp_group=tp_group,
+                               max_logit_rows=max(self.max_decode_tokens, self.seq_cap),
+                               max_split_tokens=max(256, self.max_decode_tokens), force_collectives=force_collectives, taps=taps)
         if weight_source is not None:
             src = weight_source
+        elif model_path is not None and W.has_safetensors(model_path) and model_cfg.family == "eagle3":
+            import os
+            src = W.load_eagle_safetensors(model_cfg, model_path, target_dir=config.model if os.path.isdir(config.model) else None,
+                                           out_device=str(device))
         elif model_path is not None and W.has_safetensors(model_path):
             src = W.load_safetensors(model_cfg, model_path, tp_rank, tp_size, out_device=str(device))
         else:
@@ -405,6 +415,12 @@ class ModelRunner:
         toks = self._read_tokens(B)
         return (toks, self.model.full_logits(B)) if draft_return_logits else toks
 
+    def eagle_acts(self, n: int) -> torch.Tensor:
+        """[n, taps * h] tapped activations of the last prefill / verify forward (reference model_runner.py:613-616); a view
+        of a static buffer -- callers clone what they keep."""
+        assert self.model.acts is not None, "activation taps are only collected under use_eagle"
+        return self.model.acts[:n]
+
     def _log_margins(self, rows: int, keys) -> None:
         """Debug aid of the parity tests (off unless margin_log is a dict): top-2 margin of logits[:rows]."""
         if self.margin_log is None or self.model.use_coll:
@@ -548,6 +564,10 @@ class ModelRunner:
             for i in range(0, len(token_lists), self.seq_cap):
                 self.draft_prefill(token_lists[i:i + self.seq_cap], tables[i:i + self.seq_cap])
             return
+        B, T, max_q = self._stage_draft_prefill(token_lists, tables)
+        self.model.forward(self.d_ids, self.d_pos, T, self._meta("prefill", B, max_q))
+
+    def _stage_draft_prefill(self, token_lists, tables) -> tuple[int, int, int]:
         ids, pos, slots, ctx, cu, gather = [], [], [], [], [0], []
         max_q = 0
         for toks, tb in zip(token_lists, tables):
@@ -568,7 +588,7 @@ class ModelRunner:
         self._upload(self.d_ctx, ctx, torch.int32)
         self._upload(self.d_cu_q, cu, torch.int32)
         self._upload_tables(tables)
-        self.model.forward(self.d_ids, self.d_pos, T, self._meta("prefill", B, max_q))
+        return B, T, max_q
 
     @torch.inference_mode()
     def draft_jit(self, rec, num_tokens, tables, temps=None) -> torch.Tensor:

@@ -74,6 +74,12 @@ def gemm_parts(x_frag, w_frag, M: int, N: int, K: int, *, parts=None, splits: in
                                          _stream()), "ssd_gemm_parts")
 
 
+def rmsnorm_pair(x0_rows, weight0, x1_rows, weight1, eps: float, T: int, H: int, out_frag):
+    """cat([norm(x0) * w0, norm(x1) * w1], -1) as one fragment-major [T][2H] activation (EAGLE-3 draft layer input)."""
+    _check(load_library().ssd_rmsnorm_pair(_p(x0_rows), _p(weight0), _p(x1_rows), _p(weight1), eps, _p(out_frag), T, H, _stream()),
+           "ssd_rmsnorm_pair")
+
+
 def rmsnorm_parts(parts, splits: int, slab_rows: int, weight, eps: float, T: int, H: int, res_in=None, res_out=None, out_rows=None,
                   out_frag=None):
     _check(load_library().ssd_rmsnorm_parts(_p(parts), splits, slab_rows, _p(res_in), _p(res_out), _p(weight), eps, _p(out_rows),

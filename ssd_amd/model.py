@@ -56,7 +56,8 @@ def make_cos_sin(head_dim: int, max_pos: int, theta: float, device) -> torch.Ten
 class HipDecoder:
     def __init__(self, cfg: ModelConfig, *, max_tokens: int, max_seqs: int, max_blocks: int, block_size: int,
                  max_model_len: int, device: torch.device, tp_rank: int = 0, tp_size: int = 1, tp_group=None,
-                 max_logit_rows: int | None = None, max_split_tokens: int = 256, force_collectives: bool = False):
+                 max_logit_rows: int | None = None, max_split_tokens: int = 256, force_collectives: bool = False,
+                 taps: list[int] | None = None):
         self.cfg, self.device = cfg, device
         self.tp_rank, self.tp_size, self.tp_group = tp_rank, tp_size, tp_group
         # force_collectives: issue the RCCL calls even at tp_size == 1 (lets a single-GPU box exercise the
@@ -106,6 +107,10 @@ class HipDecoder:
         self.buf_parts_o = z(16 * pt * self.h, dtype=torch.float32) if self.use_parts else None
         self.buf_parts_d = z(16 * pt * self.h, dtype=torch.float32) if self.use_parts else None
         self.logits = z(self.max_logit_rows, self.V)
+        # EAGLE-3 target (ssd/models/llama3.py:256-271): the residual stream ENTERING the tapped layers (bf16(hidden + residual),
+        # = the residual the layer's input add+norm writes anyway), concatenated in layer order for the draft's fc
+        self.taps = sorted(set(taps)) if taps else None
+        self.acts = z(T, len(self.taps) * self.h) if self.taps else None
         self.max_splits = 16
         self._ws_pf = None           # fp32 split-K partials of the prefill GEMM, allocated by the first prefill
         st = min(T, max_split_tokens)
@@ -370,6 +375,11 @@ class HipDecoder:
         L = cfg.num_layers
         for li in range(L):
             self.launch_qkv(li, T, positions, meta.slot_mapping, pre_normed=fuse and li > 0, parts=parts)
+            if self.taps is not None and li in self.taps:
+                # launch_qkv has just written x + residual: to buf_res2 on the fused-prologue path, to buf_res otherwise
+                src = self.buf_res2 if self.fusion_plan(T)[1] else res
+                i = self.taps.index(li)
+                self.acts[:T, i * self.h:(i + 1) * self.h].copy_(src[:T])
             H.attn_paged(self.buf_q, self.kv_cache[li, 0], self.kv_cache[li, 1], meta.block_tables, self.max_blocks,
                          meta.context_lens, meta.B, T, meta.max_q, self.nh, self.nkv, self.hd, self.block_size, scale,
                          cu_q=meta.cu_q, q_per_seq=meta.q_per_seq, mode=meta.mode, tree_K=meta.tree_K, tree_mq=meta.tree_mq,
