@@ -10,7 +10,9 @@ Differences, all forced by the environment rather than by design:
     the model is instantiated from its public config shapes with seeded synthetic weights and prompts are random token
     ids (the reference's own --random mode);
   * datasets: `$SSD_DATASET_DIR/<name>/<name>_data_10000.jsonl` as in ssd/paths.py:57-63 when present, else random ids;
-  * --eagle / --wandb are accepted and reported as unsupported (EAGLE-3 drafts are out of scope, no network for wandb);
+  * --eagle selects the EAGLE-3 draft of the model (bench_helpers.py:50-63: Llama 8B / 70B; async + greedy only, as in
+    the reference): its HF cache snapshot when present, else synthetic weights of its public shapes;
+  * --wandb is accepted and ignored (no network);
   * multi-GPU: `--gpus N` spawns the other ranks itself (ssd_amd/engine/launcher.py), like the reference.
 The driver-facing, roofline-reporting benchmark is ../bench.py; this file is the drop-in CLI.
 """
@@ -31,6 +33,8 @@ LLAMA = {"1": ("Llama-3.2-1B-Instruct", "llama-3.2-1b"), "3": ("Llama-3.2-3B-Ins
          "8": ("Llama-3.1-8B-Instruct", "llama-3.1-8b"), "70": ("Llama-3.1-70B-Instruct", "llama-3.1-70b")}
 QWEN = {"0.6": ("Qwen3-0.6B", "qwen3-0.6b"), "1.7": ("Qwen3-1.7B", "qwen3-1.7b"), "4": ("Qwen3-4B", "qwen3-4b"),
         "8": ("Qwen3-8B", "qwen3-8b"), "14": ("Qwen3-14B", "qwen3-14b"), "32": ("Qwen3-32B", "qwen3-32b")}
+EAGLE = {"8": ("models--yuhuili--EAGLE3-LLaMA3.1-Instruct-8B", "eagle3-llama-3.1-8b"),
+         "70": ("models--lmsys--SGLang-EAGLE3-Llama-3.3-70B-Instruct-SpecForge", "eagle3-llama-3.3-70b")}
 DATASETS = {"humaneval": "humaneval/humaneval_data_10000.jsonl", "alpaca": "alpaca/alpaca_data_10000.jsonl",
             "c4": "c4/c4_data_10000.jsonl", "gsm": "gsm8k/gsm8k_data_10000.jsonl",
             "ultrafeedback": "ultrafeedback/ultrafeedback_data_10000.jsonl"}
@@ -74,8 +78,11 @@ def parse_arguments():
     assert not (args.qwen and "--llama" in sys.argv), "--llama and --qwen are mutually exclusive"
     if args.qwen:
         args.llama = False
-    if args.eagle:
-        sys.exit("--eagle: EAGLE-3 drafts are not supported by this engine (no draft weights are reachable offline)")
+    if args.eagle:          # reference bench.py:83-87
+        args.spec = True
+        assert args.llama, "Eagle currently only supports llama models"
+        assert args.temp == 0.0 and args.dtemp is None, "Eagle currently only supports greedy decoding (temp=0)"
+        assert getattr(args, "async"), "Eagle currently only supports async speculative decoding"
     if args.wandb:
         print("note: --wandb ignored (no network); metrics are printed", flush=True)
     return args
@@ -104,6 +111,11 @@ def resolve_models(args):
     cache = os.environ.get("SSD_HF_CACHE", "")
     name, preset = table[args.size]
     model = snapshot(os.path.join(cache, f"models--{org}--{name}")) if cache else None
+    if args.eagle and args.draft is None:       # bench_helpers.py:50-63, bench_paths.py:33-40
+        if args.size not in EAGLE:
+            sys.exit(f"EAGLE draft not available for Llama size {args.size}")
+        ecache, epreset = EAGLE[args.size]
+        return name, model or preset, (snapshot(os.path.join(cache, ecache)) if cache else None) or epreset
     dsize = args.draft if args.draft is not None else ("1" if args.llama else "0.6")
     if os.path.isdir(dsize):
         draft = dsize
@@ -166,6 +178,8 @@ def main():
               kvcache_block_size=args.block_sz, max_num_seqs=args.b, max_model_len=args.max_model_len,
               max_num_batched_tokens=max(args.max_model_len, 8192), sampler_x=args.x, jit_speculate=(args.backup == "jit"),
               max_steps=args.max_steps)
+    if args.eagle:
+        kw["use_eagle"] = True
     if args.flh is not None or args.fl is not None:
         kw["fan_out_list"] = args.flh if args.flh is not None else args.fl
     if args.flm is not None:

@@ -21,16 +21,19 @@ def load_cli():
 def test_model_and_prompt_resolution(tmp_path, monkeypatch):
     cli = load_cli()
     monkeypatch.delenv("SSD_HF_CACHE", raising=False)
-    a = SimpleNamespace(llama=True, size="70", draft=None)
+    a = SimpleNamespace(llama=True, size="70", draft=None, eagle=False)
     assert cli.resolve_models(a) == ("Llama-3.1-70B-Instruct", "llama-3.1-70b", "llama-3.2-1b")
-    q = SimpleNamespace(llama=False, size="32", draft="0.6")
+    # --eagle picks the model's EAGLE-3 draft (bench_helpers.py:50-63)
+    assert cli.resolve_models(SimpleNamespace(llama=True, size="8", draft=None, eagle=True))[2] == "eagle3-llama-3.1-8b"
+    assert cli.resolve_models(SimpleNamespace(llama=True, size="70", draft=None, eagle=True))[2] == "eagle3-llama-3.3-70b"
+    q = SimpleNamespace(llama=False, size="32", draft="0.6", eagle=False)
     assert cli.resolve_models(q) == ("Qwen3-32B", "qwen3-32b", "qwen3-0.6b")
     # a HF-cache style tree is picked up (snapshots/<hash>/config.json), as in bench_helpers.py:14-43
     snap = tmp_path / "models--meta-llama--Llama-3.2-1B-Instruct" / "snapshots" / "abc"
     snap.mkdir(parents=True)
     (snap / "config.json").write_text("{}")
     monkeypatch.setenv("SSD_HF_CACHE", str(tmp_path))
-    name, model, draft = cli.resolve_models(SimpleNamespace(llama=True, size="1", draft=None))
+    name, model, draft = cli.resolve_models(SimpleNamespace(llama=True, size="1", draft=None, eagle=False))
     assert model == str(snap) and draft == str(snap)
     args = SimpleNamespace(random=True, input_len=12, numseqs=3)
     prompts, tok = cli.load_prompts(args, "llama-3.2-1b")

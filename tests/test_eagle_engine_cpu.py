@@ -99,3 +99,74 @@ def test_eagle_two_processes_gloo():
         assert p.exitcode == 0
     assert got[0][0] == ar and got[1][0] == []
     assert got[0][1] == m_loop["accepted_suffix_lens_with_recovery"]      # same acceptance trace as the in-process server
+
+
+def test_eagle_checkpoint_loader_maps_reference_names(tmp_path):
+    """An EAGLE-3 checkpoint as published (flat names, q/k/v and gate/up unpacked, midlayer.hidden_norm, no embedding)
+    + the target checkpoint that lends its embed_tokens (reference loader.py:64-183) -> this engine's parameter names."""
+    from safetensors.torch import save_file
+    from ssd_amd import weights as W
+    t, d = eagle_cfgs()
+    ref = W.synthetic_state_dict(d, 5, 0.05)
+    nh, nkv, hd, I = d.num_heads, d.num_kv_heads, d.head_dim, d.intermediate_size
+    q, k, v = ref["model.layer.self_attn.qkv_proj.weight"].split([nh * hd, nkv * hd, nkv * hd], dim=0)
+    gate, up = ref["model.layer.mlp.gate_up_proj.weight"].split([I, I], dim=0)
+    ckpt = {"midlayer.self_attn.q_proj.weight": q, "midlayer.self_attn.k_proj.weight": k, "midlayer.self_attn.v_proj.weight": v,
+            "midlayer.self_attn.o_proj.weight": ref["model.layer.self_attn.o_proj.weight"],
+            "midlayer.mlp.gate_proj.weight": gate, "midlayer.mlp.up_proj.weight": up,
+            "midlayer.mlp.down_proj.weight": ref["model.layer.mlp.down_proj.weight"],
+            "midlayer.input_layernorm.weight": ref["model.layer.input_layernorm.weight"],
+            "midlayer.hidden_norm.weight": ref["model.layer.conditioning_feature_ln.weight"],
+            "midlayer.post_attention_layernorm.weight": ref["model.layer.post_attention_layernorm.weight"],
+            "norm.weight": ref["final_norm.weight"], "fc.weight": ref["fc.weight"], "lm_head.weight": ref["lm_head.weight"],
+            "d2t": ref["d2t"], "t2d": torch.zeros(d.vocab_size, dtype=torch.bool)}
+    ddir, tdir = tmp_path / "eagle", tmp_path / "target"
+    ddir.mkdir()
+    tdir.mkdir()
+    save_file({k_: v_.contiguous() for k_, v_ in ckpt.items()}, str(ddir / "model.safetensors"))
+    save_file({"model.embed_tokens.weight": ref["model.embed_tokens.weight"].contiguous()}, str(tdir / "model-00001-of-00001.safetensors"))
+    got = dict(W.load_eagle_safetensors(d, str(ddir), target_dir=str(tdir)))
+    assert set(got) == set(ref)
+    for name in ref:
+        assert torch.equal(got[name], ref[name]), name
+    assert got["d2t"].dtype == torch.int64
+
+
+def _worker_tp(rank, port, q):
+    """TP = 2 target (taps are taken after the all-reduce: identical on both ranks) + the EAGLE draft co-located on rank 0."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from oracle.runner import oracle_runner_factory
+    from ssd_amd.engine.llm_engine import LLMEngine
+    from ssd_amd.sampling_params import SamplingParams
+    t, d = eagle_cfgs()
+    tw, dw = peaky_weights(t, d)
+    eng = LLMEngine("t", runner_factory=oracle_runner_factory(weights_target=tw, weights_draft=dw), inprocess_draft=True,
+                    **eagle_kwargs(t, d, num_gpus=2))
+    assert eng.topo.tp_size == 2 and (eng.draft_server is not None) == (rank == 0)
+    out, m = eng.generate(PROMPTS[:1], SamplingParams(temperature=0, max_new_tokens=40, ignore_eos=True), use_tqdm=False)
+    q.put((rank, [o["token_ids"] for o in out], m["accepted_suffix_lens_with_recovery"]))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eagle_under_tensor_parallel_target_gloo():
+    ar, _, _ = generate("ar")
+    _, m_loop, _ = generate("eagle")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 90)
+    ps = [ctx.Process(target=_worker_tp, args=(r, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r, toks, lens = q.get(timeout=300)
+        got[r] = (toks, lens)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][0] == ar and got[1][0] == ar
+    assert got[0][1] == got[1][1]
