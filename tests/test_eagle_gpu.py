@@ -234,3 +234,108 @@ def test_eagle_engine_hip_vs_oracle(gpu, bs):
     # the draft's own near-ties are not recorded, so the acceptance traces may differ slightly; the step counts must not
     assert abs(len(lens) - len(o_lens)) <= max(3, len(o_lens) // 3), (lens, o_lens)
     eng.exit()
+
+
+@pytest.mark.parametrize("preset", ["eagle3-llama-3.1-8b", "eagle3-llama-3.3-70b"])
+def test_eagle_draft_at_real_shapes_vs_oracle(gpu, preset):
+    """The published EAGLE-3 draft shapes (8B: h 4096, QKV over K = 8192, fc 12288 -> 4096, 32000-token head scattered into
+    128256; 70B: h 6144, fc 24576 -> 6144), default kernel dispatch: a shifted prefill, a decode row, a 15-row glue with
+    extend rows and a 24-row tree step, HIP vs the CPU oracle on the same synthetic weights."""
+    import random
+    from oracle.eagle import OracleEagleDraft
+    from oracle.model import Ctx
+    from ssd_amd import weights as W
+    from ssd_amd.eagle import HipEagleDraft
+    from ssd_amd.model import AttnMeta
+    from ssd_amd.model_config import PRESETS
+    from ssd_amd.hip import ops as H
+    cfg = PRESETS[preset]
+    full = W.synthetic_state_dict(cfg, seed=4, std=0.02)
+    bs, nblocks = 256, 3
+    m = HipEagleDraft(cfg, max_tokens=64, max_seqs=1, max_blocks=4, block_size=bs, max_model_len=1024, device=gpu)
+    m.load_weights(iter(full.items()))
+    m.alloc_kv(nblocks)
+    orc = OracleEagleDraft(cfg, full, nblocks, bs)
+    random.seed(2)
+    torch.manual_seed(2)
+    table = [2, 0, 1]
+    bt = torch.tensor([table + [-1]], dtype=torch.int32)
+    A = cfg.eagle_taps * cfg.d_model_target
+
+    def sl(ps):
+        return torch.tensor([table[p // bs] * bs + p % bs for p in ps], dtype=torch.int32)
+
+    def t64(x):
+        return torch.tensor(list(x), dtype=torch.int64)
+
+    def compare(pre_ref, n, what, rows=None):
+        lg_ref = orc.compute_logits(pre_ref if rows is None else pre_ref[rows])
+        got_pre = m.buf_pre[:n].float().cpu()
+        d = (got_pre - pre_ref.float()).abs()
+        scale = pre_ref.float().std().item()
+        print(f"{preset} {what}: prenorm std {scale:.3f} max |d| {d.max().item():.4f} mean {d.mean().item():.5f}")
+        assert d.max().item() <= 0.05 * max(1.0, scale) and d.mean().item() <= 0.01 * max(1.0, scale)
+        k = lg_ref.shape[0]
+        got = m.logits[:k].float().cpu()
+        fin = torch.isfinite(lg_ref.float())
+        assert torch.equal(torch.isfinite(got), fin)
+        dl = (got[fin] - lg_ref.float()[fin]).abs()
+        ls = lg_ref.float()[fin].std().item()
+        print(f"   logits std {ls:.3f} max |d| {dl.max().item():.4f} mean {dl.mean().item():.5f}")
+        assert dl.max().item() <= 0.05 * max(1.0, ls) and dl.mean().item() <= 0.01 * max(1.0, ls)
+        top2 = lg_ref.float().topk(2, dim=-1).values
+        assert bool(((got.argmax(-1) == lg_ref.float().argmax(-1)) | (top2[:, 0] - top2[:, 1] < 0.0625)).all())
+
+    # prefill of 40 shifted tokens from target activations (fc at M = 40: the prefill GEMM path)
+    P = 40
+    ids = [random.randint(0, 10000) for _ in range(P)]
+    acts = torch.randn(P, A).to(BF)
+    cu = torch.tensor([0, P], dtype=torch.int32)
+    ref = orc.forward(t64(ids), t64(range(P)), acts, Ctx("prefill", slot_mapping=sl(range(P)), cu_q=cu, cu_k=cu))
+    m.project(acts.cuda(), P, m.buf_cond)
+    m.forward(t64(ids).cuda(), t64(range(P)).cuda(), P,
+              AttnMeta(H.MODE_CAUSAL, 1, P, sl(range(P)).cuda(), torch.tensor([P], dtype=torch.int32).cuda(), bt.cuda(), cu_q=cu.cuda()))
+    m.compute_logits(P)
+    compare(ref, P, "prefill")
+    # one decode row conditioned on a draft-width row
+    cond = ref[-1:].clone()
+    tok = [random.randint(0, 10000)]
+    ref1 = orc.forward(t64(tok), t64([P]), cond, Ctx("decode", slot_mapping=sl([P]), context_lens=torch.tensor([P + 1], dtype=torch.int32), block_tables=bt))
+    m.buf_cond[:1].copy_(cond.cuda())
+    m.forward(t64(tok).cuda(), t64([P]).cuda(), 1, AttnMeta(H.MODE_CAUSAL, 1, 1, sl([P]).cuda(), torch.tensor([P + 1], dtype=torch.int32).cuda(), bt.cuda(), q_per_seq=1))
+    m.compute_logits(1)
+    compare(ref1, 1, "decode")
+    # glue: 7 extend + recovery + 7 spec rows at positions P-6 .. P+8 (K = 7), logits only for the last 8 rows
+    K = 7
+    n = 2 * K + 1
+    base = P + 1 - K
+    gids = [random.randint(0, 10000) for _ in range(n)]
+    tc = orc.project(torch.randn(K + 1, A).to(BF))
+    hs = torch.cat([tc, (0.5 * torch.randn(K, cfg.hidden_size)).to(BF)], dim=0)
+    ps = list(range(base, base + n))
+    refg = orc.forward(t64(gids), t64(ps), hs, Ctx("verify", slot_mapping=sl(ps), context_lens=torch.tensor([base + n], dtype=torch.int32),
+                                                 block_tables=bt, cu_q=torch.tensor([0, n], dtype=torch.int32)))
+    m.buf_cond[:n].copy_(hs.cuda())
+    m.forward(t64(gids).cuda(), t64(ps).cuda(), n,
+              AttnMeta(H.MODE_CAUSAL, 1, n, sl(ps).cuda(), torch.tensor([base + n], dtype=torch.int32).cuda(), bt.cuda(),
+                       cu_q=torch.tensor([0, n], dtype=torch.int32).cuda()))
+    rows = torch.arange(K, n)
+    m.compute_logits(n, gather=rows.to(torch.int32).cuda(), rows=K + 1)
+    compare(refg, n, "glue", rows=rows)
+    # one tree step: 24 branches (F = 3), step 0
+    F = 3
+    MQ = F * (K + 1)
+    Pb = base + K                      # position of the recovery row
+    jidx = [i // F for i in range(MQ)]
+    toks = [random.randint(0, 10000) for _ in range(MQ)]
+    hid = refg[K:][torch.tensor(jidx)].clone()
+    rope_pos = [Pb + j + 1 for j in jidx]
+    cache_pos = [Pb + K + 1 + i for i in range(MQ)]
+    reft = orc.forward(t64(toks), t64(rope_pos), hid, Ctx("tree", slot_mapping=sl(cache_pos), context_lens=torch.tensor([cache_pos[-1] + 1], dtype=torch.int32),
+                                                       block_tables=bt, tree_step=0, tree_K=K, tree_jidx=[jidx]))
+    m.buf_cond[:MQ].copy_(hid.cuda())
+    m.forward(t64(toks).cuda(), t64(rope_pos).cuda(), MQ,
+              AttnMeta(H.MODE_TREE, 1, MQ, sl(cache_pos).cuda(), torch.tensor([cache_pos[-1] + 1], dtype=torch.int32).cuda(), bt.cuda(),
+                       q_per_seq=MQ, tree_K=K, tree_mq=MQ, tree_step=0, tree_F=F))
+    m.compute_logits(MQ)
+    compare(reft, MQ, "tree step")
