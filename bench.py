@@ -22,6 +22,9 @@ Workload (``--workload``):
   c3   the same pair, SYNCHRONOUS speculation k = 6 (BASELINE.json configs[2]); draft replicated on every rank.
   c2   Llama-3.1-8B target + 1B draft, sync k = 6 on one GPU (configs[1]).
   c5t  Qwen3-32B target + Qwen3-0.6B draft, async k = 7 f = 3 (configs[4] without the draft data-parallelism).
+  c4e  Llama-3.1-70B target + its EAGLE-3 draft (one layer, h 6144, 32000-token head), async k = 7 f = 3 -- the reference's
+       `bench.py --eagle`.  Synthetic weights cannot make an EAGLE draft agree with its target, so the accepted length is 1.0:
+       the line reports the STEP (verify with activation taps + wire + JIT chain on the critical path), not a throughput.
   tiny 2-layer toy shapes (plumbing check).
 Weights are synthetic (no checkpoints exist offline).  ``--pair correlated`` (default) builds the two models with the
 "correlated pair" recipe of ssd_amd/weights.py: real shapes, every matrix streamed in full, values constructed so that
@@ -53,7 +56,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12   # B/s, MI355X spec (guide: 6.29e12 measured copy ceiling)
-ASYNC_WORKLOADS = ("c4", "c5t")
+ASYNC_WORKLOADS = ("c4", "c5t", "c4e")
+EAGLE_WORKLOADS = ("c4e", "tiny-eagle")
 
 
 def parse(argv=None):
@@ -61,7 +65,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c4", choices=["c4", "c3", "c2", "c5t", "tiny", "tiny-async"])
+    ap.add_argument("--workload", default="c4", choices=["c4", "c3", "c2", "c5t", "c4e", "tiny", "tiny-async", "tiny-eagle"])
     ap.add_argument("--k", type=int, default=None, help="speculation length (default: 7 async, 6 sync)")
     ap.add_argument("--f", type=int, default=3, help="async fan-out")
     ap.add_argument("--placement", default="auto", choices=["auto", "colocated", "dedicated"])
@@ -98,6 +102,12 @@ def workload_models(name):
         return "llama-3.1-8b", PRESETS["llama-3.1-8b"], "llama-3.2-1b", PRESETS["llama-3.2-1b"]
     if name == "c5t":
         return "qwen3-32b", PRESETS["qwen3-32b"], "qwen3-0.6b", PRESETS["qwen3-0.6b"]
+    if name == "c4e":
+        return "llama-3.1-70b", PRESETS["llama-3.1-70b"], "eagle3-llama-3.3-70b", PRESETS["eagle3-llama-3.3-70b"]
+    if name == "tiny-eagle":
+        t = ModelConfig("llama", 512, 4, 8, 8, 64, 1024, 4096, 1e-5, 5e5, 8192, False)
+        d = ModelConfig("eagle3", 256, 1, 4, 4, 64, 512, 4096, 1e-5, 5e5, 8192, False, draft_vocab_size=1024, d_model_target=512)
+        return "tiny-target", t, "tiny-eagle-draft", d
     t = ModelConfig("llama", 512, 2, 8, 8, 64, 1024, 4096, 1e-5, 5e5, 8192, False)
     d = ModelConfig("llama", 256, 1, 8, 8, 32 * 2, 512, 4096, 1e-5, 5e5, 8192, False)
     return "tiny-target", t, "tiny-draft", d
@@ -263,14 +273,15 @@ def main():
     from ssd_amd.engine.llm_engine import LLMEngine, METRICS
     from ssd_amd.sampling_params import SamplingParams
 
-    tname, tcfg, dname, dcfg = workload_models(args.workload.split("-")[0] if args.workload.startswith("tiny") else args.workload)
-    is_async = args.workload in ASYNC_WORKLOADS or args.workload == "tiny-async"
+    eagle = args.workload in EAGLE_WORKLOADS
+    tname, tcfg, dname, dcfg = workload_models("tiny" if args.workload in ("tiny", "tiny-async") else args.workload)
+    is_async = args.workload in ASYNC_WORKLOADS or args.workload in ("tiny-async", "tiny-eagle")
     K = args.k if args.k is not None else (7 if is_async else 6)
     max_len = args.max_model_len
     lookahead = (K + 1 + K * (K + 1) * args.f) if is_async else K + 1
     blocks = -(-(max_len + lookahead) // 256) + 2
     recipe = None
-    if args.pair == "correlated":
+    if args.pair == "correlated" and not eagle:
         # a tied draft would predict "repeat the token" (E.E^T is diagonal-dominant): the pair recipe unties the head; the
         # LM-head GEMM streams a [V, h] matrix either way, so bytes and kernels are unchanged
         dcfg = dataclasses.replace(dcfg, tie_word_embeddings=False)
@@ -283,7 +294,12 @@ def main():
     if placement == "auto":
         placement = "dedicated" if (is_async and world >= 5) else "colocated"
     dedicated = is_async and placement == "dedicated" and world > 1
-    if dedicated:
+    if eagle and placement == "dedicated" and args.placement == "auto" and (world - 1) & (world - 2):
+        placement = "colocated"         # the EAGLE draft is one rank: the target keeps a power-of-two degree only if N - 1 is one
+    dedicated = is_async and placement == "dedicated" and world > 1
+    if dedicated and eagle:
+        ndraft = 1
+    elif dedicated:
         ndraft = args.draft_dp if args.draft_dp > 0 else max(1, world - (1 << ((world - 1).bit_length() - 1)))
         ndraft = min(ndraft, world - 1)
     else:
@@ -295,6 +311,8 @@ def main():
               num_kvcache_blocks=blocks, num_draft_kvcache_blocks=blocks, enforce_eager=args.eager, weights_recipe=recipe)
     if is_async:
         kw.update(draft_async=True, async_fan_out=args.f, jit_speculate=True, inprocess_draft=not dedicated, num_draft_gpus=ndraft)
+    if eagle:
+        kw.update(use_eagle=True)
     engine = LLMEngine(tname, **kw)
     if engine.is_draft_process:             # dedicated draft GPU: serve until the target says EXIT, then join the barrier
         engine.serve()
@@ -384,6 +402,8 @@ def main():
         miss = 1.0 - (hit_rate or 0.0)
         draft_fwd = 1 + K + miss * K
         legs = [(engine.model_runner, K + 1, 1), (dr, K + 1, 1), (dr, engine.config.MQ_LEN, K), (dr, 1, miss * K)]
+        if eagle:       # the one-layer EAGLE draft has its own launch list (ssd_amd/eagle.py): the GEMM roofline covers the target
+            legs = legs[:1]
     else:
         # K chained forwards + the deferred KV-deposit forward, which only follows a fully accepted round
         draft_fwd = K + sum(1 for n in lens if n == K + 1) / max(1, len(lens))
@@ -405,7 +425,8 @@ def main():
                    if recipe else "(independent N(0,0.02): acceptance ~0)"),
         "config": {"workload": f"{args.workload}: {tname} target TP={tp} + {dname} draft, {mode}, b=1, temp=0, "
                                f"input_len={args.input_len}, kv block 256, max_model_len {max_len}",
-                   "parallelism": f"tp{tp}" + (f"+draft{ndraft}" if dedicated else ""), "hipgraph": not args.eager, "pair": args.pair},
+                   "parallelism": f"tp{tp}" + (f"+draft{ndraft}" if dedicated else ""), "hipgraph": not args.eager,
+                   "pair": "random" if eagle else args.pair, "eagle3": eagle},
         "mean_accepted_len": round(tokens / max(1, len(lens)), 4),
         "cache_hit_rate": None if hit_rate is None else round(hit_rate, 4),
         "ttft_p50_ms": round(ttft_p50, 3),

@@ -77,3 +77,16 @@ def test_bench_async_placements():
     check(d3, 3)
     assert d3["config"]["parallelism"] == "tp1+draft2"
     assert abs(a1["mean_accepted_len"] - d3["mean_accepted_len"]) < 1e-9 and abs(a1["cache_hit_rate"] - d3["cache_hit_rate"]) < 1e-9
+
+
+def test_bench_eagle_workload():
+    """bench.py --workload tiny-eagle: the EAGLE-3 path (activation taps, wire tensors, EAGLE draft runner) through the bench
+    harness, co-located at N = 1 and on a dedicated draft rank over the p2p transport at N = 2."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    e1 = bench("--gpus", "1", "--workload", "tiny-eagle", "--ref-seqs", "1", "--ref-output-len", "64")
+    assert e1["config"]["eagle3"] and e1["value"] > 0 and e1["roofline"]["frac"] > 0
+    assert 1.0 <= e1["mean_accepted_len"] <= 8.0 and e1["cache_hit_rate"] is not None
+    e2 = bench("--gpus", "2", "--workload", "tiny-eagle", "--placement", "dedicated", "--ref-seqs", "0", shared_gpu=True)
+    assert e2["config"]["parallelism"] == "tp1+draft1" and e2["value"] > 0
+    assert abs(e1["mean_accepted_len"] - e2["mean_accepted_len"]) < 1e-9
