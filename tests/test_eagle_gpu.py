@@ -339,3 +339,54 @@ def test_eagle_draft_at_real_shapes_vs_oracle(gpu, preset):
                        q_per_seq=MQ, tree_K=K, tree_mq=MQ, tree_step=0, tree_F=F))
     m.compute_logits(MQ)
     compare(reft, MQ, "tree step")
+
+
+def test_eagle_engine_at_real_8b_shapes_is_exact(gpu):
+    """Llama-3.1-8B + its EAGLE-3 draft (public shapes, synthetic weights with a few boosted head rows so that drafts get
+    accepted) through the product engine with hipGraphs: asynchronous EAGLE speculation must reproduce the same target's
+    autoregressive greedy stream (up to a recorded near-tie), with cache hits and multi-token acceptances along the way."""
+    import gc
+    from ssd_amd import weights as W
+    from ssd_amd.config import Config
+    from ssd_amd.engine.llm_engine import LLMEngine, hip_runner_factory
+    from ssd_amd.model_config import PRESETS
+    from ssd_amd.sampling_params import SamplingParams
+    tcfg, dcfg = PRESETS["llama-3.1-8b"], PRESETS["eagle3-llama-3.1-8b"]
+    d2t = W.synthetic_tensor("d2t", (dcfg.draft_vocab_size,), 1, 0.02, "cpu", recipe={"target_vocab": tcfg.vocab_size})
+    g = torch.Generator().manual_seed(7)
+    picks = torch.randperm(dcfg.draft_vocab_size, generator=g)[:3]
+    boost = {"t": [int(p + d2t[p]) for p in picks], "d": [int(p) for p in picks]}
+
+    def source(cfg, seed, which):
+        for name, w in W.synthetic_weights(cfg, seed, 0.02, gen_device="cuda", out_device="cuda:0"):
+            if name == "lm_head.weight":
+                rows = torch.tensor(boost[which], device=w.device)
+                w[rows] = (w[rows].float() * 6.0).to(w.dtype)
+            yield name, w
+
+    def factory(config, model_cfg, *, is_draft, topo, **kw):
+        src = source(model_cfg, 1 if is_draft else 0, "d" if is_draft else "t")
+        return hip_runner_factory(config, model_cfg, is_draft=is_draft, topo=topo, weight_source=src, **kw)
+
+    import random
+    random.seed(3)
+    prompt = [random.randint(0, 10000) for _ in range(96)]
+    sp = SamplingParams(temperature=0, max_new_tokens=48, ignore_eos=True)
+    common = dict(hf_config=tcfg, max_num_seqs=1, max_model_len=1024, max_num_batched_tokens=1024, kvcache_block_size=256,
+                  num_kvcache_blocks=6, runner_factory=factory)
+    ar = LLMEngine("llama-3.1-8b", **common)
+    ar.model_runner.margin_log = {}
+    want, _ = ar.generate([prompt], sp, use_tqdm=False)
+    margins = seq_margins(ar.model_runner.margin_log, 0)
+    del ar
+    gc.collect()
+    torch.cuda.empty_cache()
+    eng = LLMEngine("llama-3.1-8b", draft="eagle3-llama-3.1-8b", draft_hf_config=dcfg, speculate=True, speculate_k=7, draft_async=True,
+                    async_fan_out=3, jit_speculate=True, use_eagle=True, inprocess_draft=True, num_draft_kvcache_blocks=6, **common)
+    assert eng.config.eagle_layers == [2, 16, 29]
+    got, m = eng.generate([prompt], sp, use_tqdm=False)
+    lens, stats = m["accepted_suffix_lens_with_recovery"], eng.draft_server.stats
+    print(f"8B + EAGLE-3: accepted lens {lens}, server {stats}")
+    assert_stream_matches(got[0]["token_ids"], want[0]["token_ids"], margins, len(prompt), "8B EAGLE vs AR")
+    assert max(lens) >= 2 and stats["hits"] >= 1
+    eng.exit()
