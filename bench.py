@@ -120,6 +120,7 @@ def gemm_roofline(legs):
     as in the real forward; the L launches are captured in a hipGraph and the replay is timed (the real forward is a
     graph replay too; eager launches through ctypes are host-bound for the small shapes)."""
     import torch
+    from ssd_amd.utils.graphs import capture
     tot_bytes = tot_time = 0.0
     tot_launch = 0
     per_kind = {}
@@ -139,7 +140,7 @@ def gemm_roofline(legs):
             reps = max(2, 128 // L)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with capture(graph):
                 for li in range(L):
                     launch(li)
             graph.replay()
@@ -192,6 +193,7 @@ def collective_probe(engine, M):
     one hipGraph, every rank in lock step)."""
     import torch
     import torch.distributed as dist
+    from ssd_amd.utils.graphs import capture
     m = engine.model_runner.model
     if not m.use_coll:
         return None
@@ -204,7 +206,7 @@ def collective_probe(engine, M):
     body()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with capture(g):
         body()
     g.replay()
     torch.cuda.synchronize()

@@ -51,6 +51,7 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
   const int kt0 = wave * U;
   const int kmain = (KT / U) * U;                         // first k-tile of the left-over
   const u32x4_t* wp = Wf + ((size_t)t_begin * NT * KT << 6) + lane;
+  const int mt_last = (M - 1) >> 4;
   auto load = [&](Stage<MT, NT>(&s)[U], int kt) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -63,8 +64,10 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
         // at M = 7 this more than halves the L2 -> CU bytes of the B operand, at M = 1 it is 1/16)
         // (only where x is not amortised over several weight tiles: the predication costs the wider kernels more than
         // the saved bytes are worth)
+        // m-tiles past the last one that holds a token (MT is rounded up to 1/2/4/8) re-read that last tile: x_frag only
+        // has ceil(M/16) row groups, and their products are never stored
         u32x4_t b = {0u, 0u, 0u, 0u};
-        if (NT > 1 || mt * 16 + (lane & 15) < M) b = xp[mt * xstride + ((size_t)(kt + u) << 6)];
+        if (NT > 1 || mt * 16 + (lane & 15) < M) b = xp[(mt < mt_last ? mt : mt_last) * xstride + ((size_t)(kt + u) << 6)];
         s[u].b[mt] = b;
       }
     }

@@ -21,6 +21,7 @@ from ssd_amd.hip.lib import load_library
 from ssd_amd.model import HipDecoder, AttnMeta
 from ssd_amd.model_config import ModelConfig
 from ssd_amd import weights as W
+from ssd_amd.utils.graphs import capture
 
 
 class ModelRunner:
@@ -343,7 +344,7 @@ class ModelRunner:
             body()                                   # eager warm-up on the current stream
             torch.cuda.current_stream().synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self.graph_pool, stream=self.stream):
+            with capture(g, pool=self.graph_pool, stream=self.stream):
                 body()
             if self.graph_pool is None:
                 self.graph_pool = g.pool()

@@ -17,6 +17,7 @@ import torch
 import torch.distributed as dist
 
 from ssd_amd.hip.lib import load_library
+from ssd_amd.utils.graphs import capture
 
 SLOT_ELEMS = 1 << 19          # bf16 elements per staging slot (1 MiB); messages above this go to RCCL
 FLAG_BYTES = 4096
@@ -177,7 +178,7 @@ def _selftest_main() -> int:
             body()
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=s):
+        with capture(graph, stream=s):
             body()
         for it in range(20):
             xs = [torch.randn(n, generator=g).to(torch.bfloat16) for _ in range(world)]
