@@ -352,6 +352,13 @@ def main():
     engine.step(step)                       # prefill
     for _ in range(args.warmup):
         engine.step(step)
+    if not is_async and engine.draft_runner is not None:
+        # synchronous speculation defers the draft's (K+1)-th, KV-deposit-only forward to the step after a fully accepted round:
+        # its hipGraph would otherwise be captured (eager run + capture, tens of ms) by whichever TIMED step first needs it
+        dr_ = engine.draft_runner
+        with torch.inference_mode():
+            dr_.d_slots[:1].fill_(-1)           # slot -1 = store nothing
+            dr_._launch(("decode_deposit", 1), lambda: dr_._body_decode(1, False, head=False))
     n0 = len(METRICS["accepted_suffix_lens_with_recovery"])
     h0 = len(METRICS["cache_hits"])
     sync_all()
