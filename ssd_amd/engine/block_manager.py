@@ -90,7 +90,11 @@ class BlockManager:
             toks = seq.block(i)
             h = self.compute_hash(toks, h) if len(toks) == self.block_size else -1
             hit = self.hash_to_block_id.get(h, -1)
-            if hit == -1 or self.blocks[hit].token_ids != toks:
+            # a sequence whose EVERY block is cached (a preempted sequence of exactly n * block_size tokens coming back) would
+            # leave nothing to prefill and no logits to sample from -- the reference schedules that empty prefill
+            # (block_manager.py:99-127, scheduler.py:69-86); here the last full block is recomputed instead (same KV values)
+            whole_seq_cached = i == seq.num_blocks - 1 and len(toks) == self.block_size
+            if hit == -1 or self.blocks[hit].token_ids != toks or whole_seq_cached:
                 missed = True
             if missed:
                 blk = self._take(self.free_block_ids[0])

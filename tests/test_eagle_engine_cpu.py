@@ -170,3 +170,38 @@ def test_eagle_under_tensor_parallel_target_gloo():
         assert p.exitcode == 0
     assert got[0][0] == ar and got[1][0] == ar
     assert got[0][1] == got[1][1]
+
+
+def test_eagle_preemption_reprefills_with_fresh_activations():
+    """A KV pool too small for three growing sequences: the scheduler preempts, the victim is re-prefilled as a longer prompt
+    (target activations of ALL its tokens again, extend state dropped) and keeps following the target's greedy stream.  A
+    preempted sequence restarts its completion count (reference scheduler semantics), so its output is a later window of
+    the stream an unconstrained autoregressive run produces."""
+    from oracle.runner import oracle_runner_factory
+    from ssd_amd.engine.llm_engine import LLMEngine
+    from ssd_amd.sampling_params import SamplingParams
+    t, d = eagle_cfgs()
+    tw, dw = peaky_weights(t, d)
+    prompts = [[(5 * i + 3 * j + 2) % 256 for j in range(20 + 6 * i)] for i in range(3)]
+    base = dict(kvcache_block_size=16, max_model_len=256, max_num_batched_tokens=256)
+    ar = LLMEngine("t", runner_factory=oracle_runner_factory(weights_target=tw),
+                   **dict(ENGINE_KW, hf_config=t, max_num_seqs=3, num_kvcache_blocks=64, **base))
+    want, _ = ar.generate(prompts, SamplingParams(temperature=0, max_new_tokens=120, ignore_eos=True), use_tqdm=False)
+    eng = LLMEngine("t", runner_factory=oracle_runner_factory(weights_target=tw, weights_draft=dw), inprocess_draft=True,
+                    **eagle_kwargs(t, d, bs=3, num_kvcache_blocks=9, num_draft_kvcache_blocks=40, **base))
+    preempted = []
+    orig = eng.scheduler.preempt
+
+    def spy(seq):
+        preempted.append(seq.seq_id)
+        return orig(seq)
+    eng.scheduler.preempt = spy
+    got, m = eng.generate(prompts, SamplingParams(temperature=0, max_new_tokens=30, ignore_eos=True), use_tqdm=False)
+    assert preempted, "the pool was meant to be too small"
+    shifted = 0
+    for o, w in zip(got, want):
+        o, w = o["token_ids"], w["token_ids"]
+        starts = [k for k in range(len(w) - len(o) + 1) if w[k:k + len(o)] == o]
+        assert starts, "a preempted EAGLE sequence left the target's greedy stream"
+        shifted += starts[0] > 0
+    assert shifted >= 1

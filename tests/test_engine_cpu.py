@@ -163,3 +163,22 @@ def test_abort_all_returns_blocks_and_engine_stays_usable():
     assert len(eng.scheduler.block_manager.free_block_ids) == 48 and len(eng.scheduler.draft_block_manager.free_block_ids) == 48
     out, _ = eng.generate([[1, 2, 3, 4, 5]], sp, use_tqdm=False)
     assert out[0]["token_ids"] == ref[0]["token_ids"]
+
+
+def test_fully_cached_sequence_still_has_tokens_to_prefill():
+    """A sequence of exactly n * block_size tokens whose blocks are all in the prefix cache (a preempted sequence coming
+    back): the reference would schedule an empty prefill with no logits to sample from; here its last block is recomputed."""
+    from ssd_amd.engine.block_manager import BlockManager
+    from ssd_amd.engine.sequence import Sequence
+    Sequence.block_size = 4
+    bm = BlockManager(8, 4)
+    a = Sequence(list(range(8)))
+    bm.allocate(a)
+    assert a.num_cached_tokens == 0
+    bm.deallocate(a)                       # blocks return to the free list but stay hashed
+    b = Sequence(list(range(8)))
+    bm.allocate(b)
+    assert b.num_cached_tokens == 4        # first block hit, the last full block is taken fresh
+    c = Sequence(list(range(8)) + [99])    # one more token: both full blocks may hit, the partial block is computed
+    bm.allocate(c)
+    assert c.num_cached_tokens == 8
