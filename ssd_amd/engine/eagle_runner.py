@@ -16,6 +16,26 @@ from ssd_amd.engine.model_runner import ModelRunner
 from ssd_amd.hip import ops as H
 
 
+def glue_layout(num_tokens, counts, K: int) -> dict:
+    """Row layout of the EAGLE glue forward (reference draft_runner.py:548-612 builds it with masks over a packed tensor;
+    prepare_glue_decode_ctxt_eagle :450-493 the positions).  num_tokens are the ALREADY SHIFTED counts (sequence length - 1);
+    sequence b contributes counts[b] extend rows, the recovery row and K spec rows at positions n-1-counts[b] .. n-1+K.
+      pos     position of every packed row            cu      row offsets per sequence
+      tc_src  rows of the request's [B, K+1, A] activation tensor (extend rows, then the recovery row K) ...
+      tc_dst  ... and the packed rows they condition  sp_dst  packed rows conditioned on the previous round's prenorms
+      kp1     packed rows [recovery | spec] whose logits / prenorms feed the fork and the tree"""
+    pos, cu, tc_src, tc_dst, sp_dst, kp1 = [], [0], [], [], [], []
+    for b, n in enumerate(num_tokens):
+        ne, base = counts[b], cu[-1]
+        pos.extend(range(n - 1 - ne, n + K))
+        tc_src.extend([b * (K + 1) + j for j in range(ne)] + [b * (K + 1) + K])
+        tc_dst.extend(range(base, base + ne + 1))
+        sp_dst.extend(range(base + ne + 1, base + ne + 1 + K))
+        kp1.extend(range(base + ne, base + ne + K + 1))
+        cu.append(base + ne + K + 1)
+    return dict(pos=pos, cu=cu, tc_src=tc_src, tc_dst=tc_dst, sp_dst=sp_dst, kp1=kp1)
+
+
 class EagleDraftRunner(ModelRunner):
     def __init__(self, config, model_cfg, **kw):
         assert kw.get("is_draft", True) and model_cfg.family == "eagle3"
@@ -90,19 +110,12 @@ class EagleDraftRunner(ModelRunner):
         B, K, m = glue_ids.shape[0], self.K, self.model
         counts, ext_ids = eagle["ext_counts"], eagle["ext_ids"]
         self._note_ctx(max(num_tokens) + self._async_lookahead())
-        ids, pos, slots, cu = [], [], [], [0]
-        tc_src, tc_dst, sp_dst, kp1 = [], [], [], []
-        for b, (n, tb) in enumerate(zip(num_tokens, tables)):
-            ne, base = counts[b], cu[-1]
-            ids.extend(list(ext_ids[b][:ne]) + [0] * (K + 1))
-            for p in range(n - 1 - ne, n + K):
-                pos.append(p)
-                slots.append(self._slot(tb, p))
-            tc_src.extend([b * (K + 1) + j for j in range(ne)] + [b * (K + 1) + K])      # extend rows, then the recovery row
-            tc_dst.extend(range(base, base + ne + 1))
-            sp_dst.extend(range(base + ne + 1, base + ne + 1 + K))
-            kp1.extend(range(base + ne, base + ne + K + 1))
-            cu.append(base + ne + K + 1)
+        lay = glue_layout(num_tokens, counts, K)
+        pos, cu, tc_src, tc_dst, sp_dst, kp1 = lay["pos"], lay["cu"], lay["tc_src"], lay["tc_dst"], lay["sp_dst"], lay["kp1"]
+        ids, slots = [], []
+        for b, tb in enumerate(tables):
+            ids.extend(list(ext_ids[b][:counts[b]]) + [0] * (K + 1))
+            slots.extend(self._slot(tb, p) for p in pos[cu[b]:cu[b + 1]])
         T, n_tc = cu[-1], len(tc_src)
         assert T <= self.max_decode_tokens
         self._upload(self.d_ids, ids, torch.int64)

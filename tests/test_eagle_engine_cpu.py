@@ -205,3 +205,44 @@ def test_eagle_preemption_reprefills_with_fresh_activations():
         assert starts, "a preempted EAGLE sequence left the target's greedy stream"
         shifted += starts[0] > 0
     assert shifted >= 1
+
+
+def test_glue_layout_matches_the_reference_mask_construction():
+    """ssd_amd.engine.eagle_runner.glue_layout against the reference's construction of the same packed batch, restated
+    here with the reference's own tensor formulas (draft_runner.py:555-566 lengths and offsets, :568-576 the extend /
+    recovery / spec masks, :458-468 positions and context lengths, :640-644 the rows extracted for the fork)."""
+    import random
+    from ssd_amd.engine.eagle_runner import glue_layout
+    random.seed(5)
+    for _ in range(50):
+        B, K_ = random.randint(1, 5), random.randint(1, 7)
+        num_tokens_ref = torch.tensor([random.randint(K_ + 3, 300) for _ in range(B)])      # the reference's UNSHIFTED counts
+        extend_counts = torch.tensor([random.randint(0, K_) for _ in range(B)])
+        # --- reference formulas ---
+        seqlens_q = (extend_counts + K_ + 1).to(torch.int32)
+        cu = torch.zeros(B + 1, dtype=torch.int32)
+        cu[1:] = torch.cumsum(seqlens_q, 0)
+        total = int(cu[-1])
+        batch_idx = torch.repeat_interleave(torch.arange(B), seqlens_q)
+        local_off = torch.arange(total) - cu[:-1].long().repeat_interleave(seqlens_q)
+        n_ext_per_tok = extend_counts[batch_idx]
+        is_extend, is_rec, is_spec = local_off < n_ext_per_tok, local_off == n_ext_per_tok, local_off > n_ext_per_tok
+        base_pos = (num_tokens_ref - 2 - extend_counts).long()
+        positions = base_pos[batch_idx] + local_off
+        context_lens = num_tokens_ref - 1 + K_
+        rec_offsets = cu[:-1].long() + extend_counts.long()
+        extract_idx = (rec_offsets.unsqueeze(1) + torch.arange(K_ + 1).unsqueeze(0)).flatten()
+        # --- this engine (the draft server hands the runner num_tokens - 1) ---
+        shifted = [int(n) - 1 for n in num_tokens_ref]
+        lay = glue_layout(shifted, extend_counts.tolist(), K_)
+        assert lay["cu"] == cu.tolist() and lay["pos"] == positions.tolist()
+        assert [n + K_ for n in shifted] == context_lens.tolist()                            # what the runners upload as context lengths
+        assert lay["kp1"] == extract_idx.tolist()
+        assert lay["tc_dst"] == torch.nonzero(is_extend | is_rec).flatten().tolist()
+        assert lay["sp_dst"] == torch.nonzero(is_spec).flatten().tolist()
+        # sources: extend row j of sequence b -> extend_eagle_acts[b, j]; recovery -> the recovery activation (row K of our tensor)
+        want_src = []
+        for t in torch.nonzero(is_extend | is_rec).flatten().tolist():
+            b, j = int(batch_idx[t]), int(local_off[t])
+            want_src.append(b * (K_ + 1) + (j if j < int(extend_counts[b]) else K_))
+        assert lay["tc_src"] == want_src
