@@ -288,3 +288,57 @@ def test_profile_flags_print_the_reference_trace_lines(capfd, monkeypatch):
     assert out.count("[PROFILE target] handshake=") == steps and "hits=1/1 toks=4" in out
     assert out.count("[PROFILE verifier] target_call=") == steps
     assert out.count("[PROFILE draft] ") >= steps - 1 and "glue_fork=" in out and "tree[" in out
+
+
+def _worker_tp_and_draft_dp(rank, world, ndraft, port, q):
+    """The full-node shape of BASELINE.json configs[4]: a tensor-parallel target AND a data-parallel draft group."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from oracle.runner import oracle_runner_factory
+    from ssd_amd.engine.llm_engine import LLMEngine
+    from ssd_amd.model_config import ModelConfig
+    from ssd_amd.sampling_params import SamplingParams
+    t = ModelConfig("llama", 128, 2, 8, 4, 16, 256, 256, 1e-5, 5e5, 1024, False)      # 4 kv heads: tensor-parallel up to 4
+    eng = LLMEngine("t", hf_config=t, runner_factory=oracle_runner_factory(), num_gpus=world, num_draft_gpus=ndraft, draft="d",
+                    draft_hf_config=t, draft_weights_seed=0, speculate=True, speculate_k=3, draft_async=True, async_fan_out=2,
+                    jit_speculate=True, max_num_seqs=2, **KW)
+    tp = world - ndraft
+    assert (eng.topo.role == "draft") == (rank >= tp)
+    if rank < tp:
+        assert eng.topo.tp_size == tp and eng.topo.tp_rank == rank
+    out, m = eng.generate(PROMPTS, SamplingParams(temperature=0, max_new_tokens=14, ignore_eos=True), use_tqdm=False)
+    eng.exit()
+    q.put((rank, [o["token_ids"] for o in out], m["cache_hits"], m["accepted_suffix_lens_with_recovery"]))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_tp_and_draft_dp(world, ndraft):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 90) + world
+    ps = [ctx.Process(target=_worker_tp_and_draft_dp, args=(r, world, ndraft, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, toks, hits, lens = q.get(timeout=600)
+        got[r] = (toks, hits, lens)
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return got
+
+
+def test_tensor_parallel_target_with_draft_group_gloo():
+    """world 4 = TP 2 target + 2 draft ranks (what `bench.py --gpus 8` launches with 4 + 4): every target rank produces the
+    same stream, the draft ranks only serve, and with draft == target every request after the first is a hit."""
+    world, ndraft = 4, 2
+    got = _run_tp_and_draft_dp(world, ndraft)
+    tp = world - ndraft
+    assert all(got[r][0] == got[0][0] and len(got[r][0]) == 2 for r in range(tp))
+    assert all(got[r][0] == [] for r in range(tp, world))
+    assert all(got[r][1] == got[0][1] for r in range(tp))
+    assert got[0][1][0] == 0.0 and all(h == 1.0 for h in got[0][1][1:])
