@@ -347,7 +347,6 @@ def test_eagle_engine_at_real_8b_shapes_is_exact(gpu):
     autoregressive greedy stream (up to a recorded near-tie), with cache hits and multi-token acceptances along the way."""
     import gc
     from ssd_amd import weights as W
-    from ssd_amd.config import Config
     from ssd_amd.engine.llm_engine import LLMEngine, hip_runner_factory
     from ssd_amd.model_config import PRESETS
     from ssd_amd.sampling_params import SamplingParams
