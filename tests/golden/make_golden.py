@@ -14,6 +14,10 @@ Fixtures written next to this file:
   engine_golden.npz  greedy AR token stream and sync-SD accepted-suffix trace driven by reference modules
   tiny_eagle3.npz    tiny LlamaForCausalLM(use_eagle) + Eagle3DraftForCausalLM: weights, d2t, target activations, draft
                      prefill / JIT decode / variable-length glue / tree-decode logits and prenorms
+  draft_rounds_*.npz the reference's OWN DraftRunner methods (hit_cache_and_respond, jit_speculate, _build_tree_batch,
+                     _decode_tree, _populate_tree_cache) run on CPU for three speculation rounds of a batch of two sequences
+                     (miss -> JIT, all hits with extend rows, mixed -> JIT), plain draft and EAGLE-3 draft: requests,
+                     replies, forks and the speculation cache after every round
 """
 from __future__ import annotations
 
@@ -458,6 +462,194 @@ def gen_tiny_eagle():
     print("tiny_eagle3.npz written")
 
 
+class PlanShim:
+    """Stands in for flashinfer's BatchPrefillWithPagedKVCacheWrapper when the reference's OWN runner drives it:
+    ModelRunner.eager_tree_decode_plan (model_runner.py:552-592) hands plan() the custom mask it built with
+    get_custom_mask; Attention.forward (attention.py:114-125) then calls run()."""
+
+    def __init__(self, get_context):
+        self.get_context, self.mask, self.cu = get_context, None, None
+
+    def plan(self, cu_seqlens_q, kv_indptr, kv_indices, kv_last_page_len, nh, nkv, hd, block_size, custom_mask=None, **kw):
+        self.mask, self.cu = custom_mask, cu_seqlens_q
+
+    def run(self, q, kv):
+        from oracle import ops as O
+        ctx = self.get_context()
+        k_cache, v_cache = kv
+        B = ctx.context_lens.shape[0]
+        outs, off = [], 0
+        scale = q.shape[-1] ** -0.5
+        for b in range(B):
+            L = int(ctx.context_lens[b])
+            q0, q1 = int(self.cu[b]), int(self.cu[b + 1])
+            mb = self.mask[off:off + (q1 - q0) * L].view(q1 - q0, L)
+            off += (q1 - q0) * L
+            ks = O.gather_paged(k_cache, ctx.block_tables[b], L)
+            vs = O.gather_paged(v_cache, ctx.block_tables[b], L)
+            outs.append(O._sdpa(q[q0:q1], ks, vs, mb, scale))
+        return torch.cat(outs, 0)
+
+
+def gen_draft_rounds(eagle: bool):
+    """Three speculation rounds of a two-sequence batch through the reference's own DraftRunner methods (an instance made
+    without __init__: no process group, no GPU), eager mode.  Round 1: empty cache -> JIT chain.  Round 2: both requests hit
+    (sequence 0 "accepted" everything -> K extend rows under EAGLE; sequence 1 nothing).  Round 3: one hit + one miss ->
+    the whole batch is JIT-drafted (draft_runner.py:242-267).  The verification outcomes are CHOSEN (any outcome is a legal
+    request); the target only supplies activations (EAGLE)."""
+    from ssd.engine.draft_runner import DraftRunner
+    from ssd.utils.async_helpers.async_spec_helpers import make_glue_decode_input_ids  # noqa: F401 (used by the runner)
+    K, F = 2, 2
+    MQ = F * (K + 1)
+    bs, nblocks, max_blocks = 16, 40, 12
+    taps = [0, 1, 3]
+    tcfg = tiny_llama_cfg(h=256, L=4, nh=4, nkv=2, I=512, V=512)
+    dcfg = tiny_llama_cfg(h=128, L=1 if eagle else 2, nh=2, nkv=1, I=256, V=512)
+    g = torch.Generator().manual_seed(31)
+    if eagle:
+        tm = build(LlamaForCausalLM, tcfg, 21, 0.06, speculate=True, spec_k=K, use_eagle=True, eagle_layers=taps)
+        dcfg.draft_vocab_size = 256
+        dm = build(Eagle3DraftForCausalLM, dcfg, 22, 0.08, draft=True, speculate=True, use_eagle=True, eagle_layers=taps,
+                   d_model_target=tcfg.hidden_size, spec_k=K, async_fan_out=F, draft_async=True)
+        tgt_idx = torch.randperm(tcfg.vocab_size, generator=g)[:dcfg.draft_vocab_size].sort().values
+        dm.d2t_tensor = (tgt_idx - torch.arange(dcfg.draft_vocab_size)).long()
+    else:
+        tm = None
+        dm = build(LlamaForCausalLM, dcfg, 22, 0.08, draft=True, speculate=True, spec_k=K, async_fan_out=F, draft_async=True)
+    hd = dcfg.hidden_size // dcfg.num_attention_heads
+    shim = PlanShim(get_context)
+    kv = torch.zeros(2, dcfg.num_hidden_layers, nblocks, bs, dcfg.num_key_value_heads, hd, dtype=BF)
+    i = 0
+    for mod in dm.modules():
+        if hasattr(mod, "k_cache") and hasattr(mod, "v_cache"):
+            mod.k_cache, mod.v_cache, mod.only_prefill_wrapper = kv[0, i], kv[1, i], shim
+            i += 1
+    r = object.__new__(DraftRunner)
+    A = len(taps) * tcfg.hidden_size
+    r.config = types.SimpleNamespace(speculate=True, speculate_k=K, async_fan_out=F, MQ_LEN=MQ, draft_async=True, use_eagle=eagle,
+                                     jit_speculate=True, verbose=False, fan_out_list=[F] * (K + 1), fan_out_list_miss=[F] * (K + 1),
+                                     fan_out_t=torch.tensor([F] * (K + 1)), fan_out_t_miss=torch.tensor([F] * (K + 1)),
+                                     d_model_target=tcfg.hidden_size, max_blocks=max_blocks, max_model_len=512, sampler_x=None)
+    r.hf_config = types.SimpleNamespace(vocab_size=dcfg.vocab_size, hidden_size=dcfg.hidden_size, torch_dtype=BF,
+                                        num_attention_heads=dcfg.num_attention_heads, num_key_value_heads=dcfg.num_key_value_heads,
+                                        head_dim=hd)
+    r.device, r.block_size, r.enforce_eager, r.is_draft, r.draft_async = torch.device("cpu"), bs, True, True, True
+    r.model, r.sampler, r.tokenizer, r.only_prefill_wrapper = dm, Sampler(sampler_x=None, async_fan_out=F), None, shim
+    r._reset_tree_cache_tensors()
+    r._init_prealloc_buffers()
+
+    out = {"d." + k: v.data.clone() for k, v in dm.state_dict().items()}
+    out["d_cfg_i"], out["d_cfg_f"] = cfg_fields(dcfg, "llama")
+    out["K_F"] = torch.tensor([K, F])
+    if eagle:
+        out["d.d2t"] = dm.d2t_tensor.clone()
+        out["taps"], out["d_model_target"] = torch.tensor(taps), torch.tensor([tcfg.hidden_size])
+        td = [RefDriver(tm, tcfg, num_blocks=nblocks, table=[3, 7, 1, 9, 5, 11, 13, 15, 17, 19, 21, 23]),
+              RefDriver(tm, tcfg, num_blocks=nblocks, table=[2, 6, 0, 8, 4, 10, 12, 14, 16, 18, 20, 22])]
+        td[1].kv = td[0].kv                        # one target KV cache, two page tables
+        for mod in tm.modules():
+            if hasattr(mod, "k_cache") and hasattr(mod, "v_cache"):
+                pass
+
+    tables = [[4, 8, 1, 6, 10, 2, 12, 14, 16, 18, 20, 0], [5, 9, 3, 7, 11, 13, 15, 17, 19, 21, 23, 22]]
+    dbt = torch.tensor(tables, dtype=torch.int32)
+    out["draft_block_tables"] = dbt.clone()
+    prompts = [torch.randint(0, 512, (21,), generator=g).tolist(), torch.randint(0, 512, (13,), generator=g).tolist()]
+    out["prompt0"], out["prompt1"] = torch.tensor(prompts[0]), torch.tensor(prompts[1])
+    seq_ids = [7, 9]
+
+    @torch.inference_mode()
+    def target_acts(b, tokens, pos0, prefill):
+        d = td[b]
+        n = len(tokens)
+        cu = torch.tensor([0, n], dtype=torch.int32)
+        if prefill:
+            set_context(True, cu_seqlens_q=cu, cu_seqlens_k=cu, max_seqlen_q=n, max_seqlen_k=n, slot_mapping=d.slots(range(n)))
+        else:
+            set_context(False, cu_seqlens_q=cu, max_seqlen_q=n, slot_mapping=d.slots(range(pos0, pos0 + n)),
+                        context_lens=torch.tensor([pos0 + n], dtype=torch.int32), block_tables=d.bt)
+        h, acts = tm(torch.tensor(tokens, dtype=torch.int64), torch.arange(pos0, pos0 + n, dtype=torch.int64))
+        lg = tm.compute_logits(h, last_only=False).view(n, -1)
+        reset_context()
+        return lg.clone(), acts.clone()
+
+    # ---- draft prefill, the runner's own context preparation (draft_runner.py:80-99) ----
+    if eagle:
+        pre = [target_acts(b, prompts[b], 0, True) for b in range(2)]
+        ids = [p[1:] for p in prompts]
+        acts = torch.cat([pre[b][1][:-1] for b in range(2)], dim=0)
+        rec = [int(pre[b][0][-1].float().argmax()) for b in range(2)]
+        rec_acts = torch.stack([pre[b][1][-1] for b in range(2)])
+        out["prefill_acts"] = acts.clone()
+    else:
+        ids, acts = prompts, None
+        rec = [int(torch.randint(0, 512, (1,), generator=g)) for _ in range(2)]
+        rec_acts = None
+    num_tok = torch.tensor([len(x) for x in ids], dtype=torch.int64)
+    pc = r.prepare_prefill_ctxt(num_tok, dbt)
+    set_context(is_prefill=True, cu_seqlens_q=pc["cu_seqlens_q"], cu_seqlens_k=pc["cu_seqlens_k"], max_seqlen_q=pc["max_seqlen_q"],
+                max_seqlen_k=pc["max_seqlen_k"], slot_mapping=pc["slot_map"], context_lens=None)
+    r.run_model(torch.tensor(ids[0] + ids[1], dtype=torch.int64), pc["positions"], is_prefill=True, last_only=True, hidden_states=acts)
+    reset_context()
+
+    num_tokens = [len(p) + 1 for p in prompts]                       # after the recovery token is appended
+    keep = [-2, -2]                                                  # last_spec_step_accepted_len - 1 before the first step
+    ext = None
+    for rnd in range(3):
+        B = 2
+        keys = torch.tensor([[seq_ids[b], keep[b], rec[b]] for b in range(B)], dtype=torch.int64)
+        nt = torch.tensor(num_tokens, dtype=torch.int64)
+        temps = torch.zeros(B)
+        if eagle:
+            if ext is None:
+                ext = (torch.zeros(B, dtype=torch.int64), torch.zeros(B, K, A, dtype=BF), torch.zeros(B, K, dtype=torch.int64))
+            out[f"r{rnd}_rec_acts"], out[f"r{rnd}_ext_counts"] = rec_acts.clone(), ext[0].clone()
+            out[f"r{rnd}_ext_acts"], out[f"r{rnd}_ext_ids"] = ext[1].clone(), ext[2].clone()
+        out[f"r{rnd}_keys"], out[f"r{rnd}_num_tokens"] = keys.clone(), nt.clone()
+        toks, lgs, glue_ids, hits, acts_out = r.hit_cache_and_respond(keys, B, K, nt, temps, dbt, rec_acts)
+        out[f"r{rnd}_hits"], out[f"r{rnd}_tokens"] = hits.to(torch.int64).clone(), toks.clone()
+        r._reset_tree_cache_tensors()
+        partial = {"num_tokens": nt, "seq_ids": keys[:, 0], "temperatures": temps, "dbt": dbt, "cache_hits": hits, "returned_tokens": toks,
+                   "target_recovery_activations": rec_acts, "previous_activations": acts_out,
+                   "extend_counts": ext[0] if eagle else None, "extend_eagle_acts": ext[1] if eagle else None,
+                   "extend_token_ids": ext[2] if eagle else None}
+        tda = r._build_tree_batch(partial, glue_ids)
+        out[f"r{rnd}_forks"] = tda["input_ids"].view(B, MQ).clone()
+        t_tok, t_lg, t_act = r._decode_tree(tda)
+        r._populate_tree_cache(tda, t_tok, t_lg, tda["cache_hits"], t_act)
+        out[f"r{rnd}_cache_keys"], out[f"r{rnd}_cache_tokens"] = r.tree_cache_keys.clone(), r.tree_cache_tokens.clone()
+        if eagle:
+            out[f"r{rnd}_cache_acts"] = r.tree_cache_activations.clone()
+        # ---- the outcome of this round's verification, chosen so that the next request exercises hits / extends / a mix ----
+        forks = tda["input_ids"].view(B, MQ)
+        specs = [[rec[b]] + toks[b].tolist() for b in range(B)]
+        if eagle:                                 # the target really runs over the speculated tokens: its activations are the request's payload
+            v = [target_acts(b, specs[b], num_tokens[b] - 1, False)[1] for b in range(B)]
+        if rnd == 0:
+            acc = [K, 0]                          # sequence 0 accepted all K draft tokens, sequence 1 none
+            new_rec = [int(forks[0, K * F]), int(forks[1, 1])]            # both recovery tokens are forks of that position: hits
+        else:
+            acc = [1, 0]
+            new_rec = [int(forks[0, 1 * F + 1]), (int(forks[1].max()) + 1) % 512]    # a hit and a miss
+            if new_rec[1] in forks[1, :F].tolist():
+                new_rec[1] = (new_rec[1] + 7) % 512
+        for b in range(B):
+            num_tokens[b] += acc[b] + 1
+            keep[b] = acc[b]
+        if eagle:
+            cnt = torch.tensor(acc, dtype=torch.int64)
+            ea, ei = torch.zeros(B, K, A, dtype=BF), torch.zeros(B, K, dtype=torch.int64)
+            for b in range(B):
+                ea[b, :acc[b]] = v[b][:acc[b]]
+                ei[b, :acc[b]] = torch.tensor(specs[b][1:1 + acc[b]], dtype=torch.int64)
+            ext = (cnt, ea, ei)
+            rec_acts = torch.stack([v[b][acc[b]] for b in range(B)])
+        rec = new_rec
+    name = "draft_rounds_eagle3.npz" if eagle else "draft_rounds_llama.npz"
+    save_npz(os.path.join(HERE, name), out)
+    print(name, "written; hits per round:", [out[f"r{i}_hits"].tolist() for i in range(3)])
+
+
 def _top2_margin(row):
     t = row.float().topk(2).values
     return float(t[0] - t[1])
@@ -665,7 +857,7 @@ def gen_stochastic():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "logic", "llama", "qwen", "eagle", "engine", "scheduler", "stochastic"]
+    which = sys.argv[1:] or ["ops", "logic", "llama", "qwen", "eagle", "rounds", "engine", "scheduler", "stochastic"]
     if "ops" in which:
         gen_ops()
     if "logic" in which:
@@ -676,6 +868,9 @@ if __name__ == "__main__":
         gen_tiny_qwen()
     if "eagle" in which:
         gen_tiny_eagle()
+    if "rounds" in which:
+        gen_draft_rounds(False)
+        gen_draft_rounds(True)
     if "engine" in which:
         gen_engine()
     if "scheduler" in which:
