@@ -763,15 +763,21 @@ def gen_scheduler():
     from collections import deque
 
     traces = {}
-    for name, (speculate, K, nblocks, max_seqs) in {"ar": (False, 1, 24, 3), "spec": (True, 3, 40, 2), "tight": (True, 3, 14, 3)}.items():
+    # "eagle": ASYNC speculation (draft lookahead K+1+K*MQ_LEN) with the EAGLE-3 bookkeeping of postprocess_speculate
+    # (scheduler.py:303-320): which activation row conditions the next recovery token, which accepted tokens get extended
+    for name, (speculate, K, nblocks, max_seqs) in {"ar": (False, 1, 24, 3), "spec": (True, 3, 40, 2), "tight": (True, 3, 14, 3),
+                                                    "eagle": (True, 3, 30, 2)}.items():
+        eagle = name == "eagle"
         rnd = random.Random(11)
         bs = 16
         Sequence.block_size = bs
         Sequence.counter = __import__("itertools").count()
         sch = Scheduler.__new__(Scheduler)      # bypass AutoTokenizer / Config: set exactly the fields __init__ sets
         sch.max_num_seqs, sch.max_num_batched_tokens, sch.max_model_len = max_seqs, 256, 256
-        sch.eos, sch.speculate, sch.F, sch.K, sch.block_size, sch.verbose, sch.draft_async = 5, speculate, 3, K, bs, False, False
-        sch.fan_out_list = sch.fan_out_list_miss = None
+        sch.eos, sch.speculate, sch.F, sch.K, sch.block_size, sch.verbose, sch.draft_async = 5, speculate, 3, K, bs, False, eagle
+        sch.fan_out_list = sch.fan_out_list_miss = [2] * (K + 1) if eagle else None
+        if eagle:
+            sch.MQ_LEN = sum(sch.fan_out_list)
         sch.block_manager = BlockManager(nblocks, bs, is_draft=False, max_model_len=256)
         if speculate:
             sch.draft_block_manager = BlockManager(nblocks, bs, is_draft=True, speculate_k=K, max_model_len=256)
@@ -809,7 +815,14 @@ def gen_scheduler():
                     sfx.append([s.recovery_token_id] + [rnd.randrange(5, 200) if rnd.random() > 0.04 else 5 for _ in range(n)])
                     rec.append(rnd.randrange(6, 200))
                 ev["suffixes"], ev["rec"] = sfx, rec
-                sch.postprocess_speculate(seqs, sfx, rec)
+                if eagle:       # activation rows that name themselves: acts[i, j] = (step, i, j)
+                    acts = torch.tensor([[[step, i, j] for j in range(K + 1)] for i in range(len(seqs))], dtype=torch.float32)
+                    sch.postprocess_speculate(seqs, sfx, rec, eagle_acts=acts)
+                    ev["eagle"] = [{"last": s.last_target_hidden_state.tolist(), "count": int(s.extend_count),
+                                    "ids": [] if s.extend_token_ids is None else s.extend_token_ids.tolist(),
+                                    "acts": [] if s.extend_eagle_acts is None else s.extend_eagle_acts.tolist()} for s in seqs]
+                else:
+                    sch.postprocess_speculate(seqs, sfx, rec)
             ev["after_len"] = [s.num_tokens for s in seqs]
             ev["finished"] = [s.is_finished for s in seqs]
             ev["waiting"] = [s.seq_id for s in sch.waiting]

@@ -15,15 +15,16 @@ from ssd_amd.sampling_params import SamplingParams
 from tests.conftest import GOLDEN
 
 
-@pytest.mark.parametrize("name", ["ar", "spec", "tight"])
+@pytest.mark.parametrize("name", ["ar", "spec", "tight", "eagle"])
 def test_scheduler_matches_reference_trace(name):
     tr = json.load(open(os.path.join(GOLDEN, "scheduler_golden.json")))[name]
     bs = 16
     Sequence.block_size = bs
     Sequence.counter = itertools.count()
+    eagle = name == "eagle"         # the async + EAGLE-3 trace; prefix caching stays ON here, as in the reference's scheduler
     cfg = SimpleNamespace(max_num_seqs=tr["max_seqs"], max_num_batched_tokens=256, max_model_len=256, eos=5,
-                          speculate=tr["speculate"], draft_async=False, speculate_k=tr["K"], kvcache_block_size=bs,
-                          num_kvcache_blocks=tr["nblocks"], fan_out_list=None)
+                          speculate=tr["speculate"], draft_async=eagle, speculate_k=tr["K"], kvcache_block_size=bs,
+                          num_kvcache_blocks=tr["nblocks"], fan_out_list=[2] * (tr["K"] + 1) if eagle else None)
     sch = Scheduler(cfg, draft_num_blocks=tr["nblocks"] if tr["speculate"] else None)
     for toks, mnt, ign in tr["reqs"]:
         sch.add(Sequence(toks, SamplingParams(temperature=0.0, max_new_tokens=mnt, ignore_eos=ign)))
@@ -45,6 +46,16 @@ def test_scheduler_matches_reference_trace(name):
                 s.recovery_token_id = r
                 s.num_cached_tokens = s.num_prompt_tokens
                 s.num_draft_cached_tokens = s.num_prompt_tokens
+        elif eagle:
+            import torch
+            K = tr["K"]
+            acts = torch.tensor([[[i, b, j] for j in range(K + 1)] for b in range(len(seqs))], dtype=torch.float32)
+            sch.postprocess_speculate(seqs, ev["suffixes"], ev["rec"], eagle_acts=acts)
+            for s, want in zip(seqs, ev["eagle"]):      # scheduler.py:303-320
+                assert s.last_target_hidden_state.tolist() == want["last"], ctx
+                assert s.extend_count == want["count"], ctx
+                assert (s.extend_token_ids or []) == want["ids"], ctx
+                assert ([] if s.extend_eagle_acts is None else s.extend_eagle_acts.tolist()) == want["acts"], ctx
         else:
             sch.postprocess_speculate(seqs, ev["suffixes"], ev["rec"])
         assert [s.num_tokens for s in seqs] == ev["after_len"], ctx
