@@ -14,6 +14,11 @@ Fixtures written next to this file:
   engine_golden.npz  greedy AR token stream and sync-SD accepted-suffix trace driven by reference modules
   tiny_eagle3.npz    tiny LlamaForCausalLM(use_eagle) + Eagle3DraftForCausalLM: weights, d2t, target activations, draft
                      prefill / JIT decode / variable-length glue / tree-decode logits and prenorms
+  ref_engine.npz     the reference's OWN engine classes end to end on CPU -- Scheduler, AutoRegressiveStep / SpecDecodeStep,
+                     SpeculatorSync / SpeculatorAsync, Verifier, ModelRunner.run and the DraftRunner loop body (instances made
+                     without __init__, torch.distributed p2p replaced by in-process queues) -- for a batch of two requests:
+                     autoregressive, sync SD, async SSD (independent draft and draft == target), async SSD with an EAGLE-3
+                     draft: completions, accepted suffix lengths and cache hits of every step
   draft_rounds_*.npz the reference's OWN DraftRunner methods (hit_cache_and_respond, jit_speculate, _build_tree_batch,
                      _decode_tree, _populate_tree_cache) run on CPU for three speculation rounds of a batch of two sequences
                      (miss -> JIT, all hits with extend rows, mixed -> JIT), plain draft and EAGLE-3 draft: requests,
@@ -650,6 +655,203 @@ def gen_draft_rounds(eagle: bool):
     print(name, "written; hits per round:", [out[f"r{i}_hits"].tolist() for i in range(3)])
 
 
+class FakeDist:
+    """In-process stand-in for the 2-rank async process group: send() queues a copy for the peer, recv() pops -- and when the
+    TARGET (rank 0) waits on an empty queue the draft's pending commands are served first (`pump`), which is what the
+    concurrently running draft process would have done by then."""
+
+    def __init__(self):
+        from collections import deque
+        self.q = {0: deque(), 1: deque()}
+        self.pump = None
+
+    def send(self, t, dst, group=None):
+        self.q[dst].append(t.detach().clone())
+
+    def recv(self, t, src, group=None):
+        me = 1 - src
+        if me == 0 and not self.q[0]:
+            self.pump()
+        msg = self.q[me].popleft()
+        assert msg.shape == t.shape and msg.dtype == t.dtype, (msg.shape, t.shape, msg.dtype, t.dtype)
+        t.copy_(msg)
+
+
+def _bare_runner(cls, model, hf, config, is_draft, block_size, nblocks, shim=None):
+    """A reference ModelRunner / DraftRunner without its __init__ (no CUDA, no process group): exactly the attributes the
+    eager code paths read."""
+    r = object.__new__(cls)
+    hd = hf.hidden_size // hf.num_attention_heads
+    r.config, r.block_size, r.is_draft, r.rank, r.world_size, r.enforce_eager = config, block_size, is_draft, 0, 1, True
+    r.device, r.model, r.sampler, r.use_eagle = torch.device("cpu"), model, Sampler(sampler_x=None, async_fan_out=config.async_fan_out), config.use_eagle
+    r.hf_config = types.SimpleNamespace(vocab_size=hf.vocab_size, hidden_size=hf.hidden_size, torch_dtype=BF,
+                                        num_attention_heads=hf.num_attention_heads, num_key_value_heads=hf.num_key_value_heads, head_dim=hd)
+    r.tokenizer, r.async_pg, r.draft_async, r.verbose = None, None, config.draft_async, False
+    kv = torch.zeros(2, hf.num_hidden_layers, nblocks, block_size, hf.num_key_value_heads, hd, dtype=BF)
+    i = 0
+    for mod in model.modules():
+        if hasattr(mod, "k_cache") and hasattr(mod, "v_cache"):
+            mod.k_cache, mod.v_cache = kv[0, i], kv[1, i]
+            if shim is not None:
+                mod.only_prefill_wrapper = shim
+            i += 1
+    r.only_prefill_wrapper = shim
+    return r
+
+
+def gen_ref_engine():
+    import ssd.engine.draft_runner as DRM
+    import ssd.engine.model_runner as MRM
+    import ssd.engine.speculator_async as SAM
+    import ssd.utils.async_helpers.nccl_pack as NPM
+    import ssd.engine.helpers.runner_helpers as RH
+    from collections import deque
+    from ssd.engine.block_manager import BlockManager
+    from ssd.engine.scheduler import Scheduler
+    from ssd.engine.sequence import Sequence
+    from ssd.engine.step import AutoRegressiveStep, SpecDecodeStep
+    from ssd.engine.speculator_sync import SpeculatorSync
+    from ssd.engine.verifier import Verifier
+    from ssd.sampling_params import SamplingParams
+
+    # the helpers build their tensors with pin_memory=True and .cuda(): on this CPU-only run both are identities
+    real_tensor = torch.tensor
+    torch.tensor = lambda *a, **k: real_tensor(*a, **{x: y for x, y in k.items() if x != "pin_memory"})
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    tok = types.SimpleNamespace(decode=lambda ids, **k: "")
+    K, F, bs, nblocks, max_len = 3, 2, 16, 48, 256
+    MQ = F * (K + 1)
+    taps = [0, 1, 3]
+    tcfg = tiny_llama_cfg(h=256, L=4, nh=4, nkv=2, I=512, V=512)
+    dcfg = tiny_llama_cfg(h=128, L=1, nh=2, nkv=1, I=256, V=512)
+    g = torch.Generator().manual_seed(41)
+    prompts = [torch.randint(0, 512, (11,), generator=g).tolist(), torch.randint(0, 512, (7,), generator=g).tolist()]
+    new_tokens = 14
+
+    def scenario(name, mode, same=False, eagle=False):
+        Sequence.block_size = bs
+        Sequence.counter = __import__("itertools").count()
+        cfg = types.SimpleNamespace(speculate=mode != "ar", speculate_k=K, async_fan_out=F, MQ_LEN=MQ, draft_async=mode == "async",
+                                    use_eagle=eagle, jit_speculate=True, verbose=False, fan_out_list=[F] * (K + 1), fan_out_list_miss=[F] * (K + 1),
+                                    fan_out_t=torch.tensor([F] * (K + 1)), fan_out_t_miss=torch.tensor([F] * (K + 1)),
+                                    d_model_target=tcfg.hidden_size, max_blocks=max_len // bs, max_model_len=max_len, sampler_x=None,
+                                    eagle_layers=taps if eagle else None)
+        kw = dict(use_eagle=True, eagle_layers=taps) if eagle else {}
+        tm = build(LlamaForCausalLM, tcfg, 51, 0.06, speculate=mode != "ar", spec_k=K, **kw)
+        out = {"t." + k: v.data.clone() for k, v in tm.state_dict().items()}
+        out["t_cfg_i"], out["t_cfg_f"] = cfg_fields(tcfg, "llama")
+        dm = None
+        if mode != "ar":
+            if eagle:
+                dc = tiny_llama_cfg(h=128, L=1, nh=2, nkv=1, I=256, V=512)
+                dc.draft_vocab_size = 256
+                dm = build(Eagle3DraftForCausalLM, dc, 52, 0.08, draft=True, speculate=True, use_eagle=True, eagle_layers=taps,
+                           d_model_target=tcfg.hidden_size, spec_k=K, async_fan_out=F, draft_async=True)
+                gi = torch.Generator().manual_seed(43)
+                tgt_idx = torch.randperm(512, generator=gi)[:256].sort().values
+                dm.d2t_tensor = (tgt_idx - torch.arange(256)).long()
+                # both heads favour the same three tokens (tests/eagle_util.py peaky_weights): without agreement the hit and
+                # extend paths of the reference run would never execute
+                for di in torch.randperm(256, generator=gi)[:3].tolist():
+                    ti = int(tgt_idx[di])
+                    tm.lm_head.weight.data[ti] = (tm.lm_head.weight.data[ti].float() * 6.0).to(BF)
+                    dm.lm_head.weight.data[di] = (dm.lm_head.weight.data[di].float() * 6.0).to(BF)
+                out["t.lm_head.weight"] = tm.lm_head.weight.data.clone()
+                out["d.d2t"] = dm.d2t_tensor.clone()
+                out["taps"] = torch.tensor(taps)
+            elif same:
+                dc = tcfg
+                dm = build(LlamaForCausalLM, tcfg, 51, 0.06, draft=True, speculate=True, spec_k=K, async_fan_out=F, draft_async=mode == "async")
+            else:
+                dc = dcfg
+                dm = build(LlamaForCausalLM, dcfg, 53, 0.08, draft=True, speculate=True, spec_k=K, async_fan_out=F, draft_async=mode == "async")
+            out.update({"d." + k: v.data.clone() for k, v in dm.state_dict().items()})
+            out["d_cfg_i"], out["d_cfg_f"] = cfg_fields(dc, "llama")
+        shim = PlanShim(get_context)
+        target = _bare_runner(MRM.ModelRunner, tm, tcfg, cfg, False, bs, nblocks)
+        draft = None
+        if dm is not None:
+            draft = _bare_runner(DRM.DraftRunner if mode == "async" else MRM.ModelRunner, dm, dc, cfg, True, bs, nblocks, shim if mode == "async" else None)
+        sch = Scheduler.__new__(Scheduler)
+        sch.max_num_seqs, sch.max_num_batched_tokens, sch.max_model_len = 2, max_len, max_len
+        sch.eos, sch.speculate, sch.F, sch.K, sch.block_size, sch.verbose, sch.draft_async = -1, mode != "ar", F, K, bs, False, mode == "async"
+        sch.fan_out_list = sch.fan_out_list_miss = [F] * (K + 1)
+        sch.MQ_LEN = MQ
+        sch.block_manager = BlockManager(nblocks, bs, is_draft=False, max_model_len=max_len)
+        if mode != "ar":
+            sch.draft_block_manager = BlockManager(nblocks, bs, is_draft=True, speculate_k=K, max_model_len=max_len)
+        sch.waiting, sch.running = deque(), deque()
+        metrics = {"cache_hits": [], "accepted_suffix_lens_with_recovery": [], "accepted_suffix_lens_on_hit": [],
+                   "accepted_suffix_lens_on_miss": [], "target_verify_times": []}
+        if mode == "ar":
+            step = AutoRegressiveStep(sch, target, tok)
+        else:
+            if mode == "sync":
+                spec = SpeculatorSync(K, torch.device("cpu"), draft)
+            else:
+                fake = FakeDist()
+                for m in (DRM, MRM, SAM, NPM):
+                    m.dist = fake
+                draft._reset_tree_cache_tensors()
+                draft._init_prealloc_buffers()
+                draft._draft_step_times = []
+
+                def pump():     # the body of DraftRunner.draft_loop (draft_runner.py:859-915) for every queued command
+                    while fake.q[1]:
+                        cmd = draft.recv_cmd()
+                        if cmd == 1:
+                            draft.draft_async_prefill()
+                        elif cmd == 0:
+                            glue, partial = draft._service_spec_request()
+                            draft._reset_tree_cache_tensors()
+                            tda = draft._build_tree_batch(partial, glue)
+                            t_tok, t_lg, t_act = draft._decode_tree(tda)
+                            draft._populate_tree_cache(tda, t_tok, t_lg, tda["cache_hits"], t_act)
+                        else:
+                            raise RuntimeError(cmd)
+                fake.pump = pump
+                spec = SAM.SpeculatorAsync(K, torch.device("cpu"), F, max_len // bs, 512, BF, bs, max_len, None, 1, tok, False)
+            ver = Verifier(K, torch.device("cpu"), target, None, F, True if mode == "async" else False, tok, metrics)
+            step = SpecDecodeStep(sch, spec, ver, eagle, tok, mode == "async")
+        seqs = [Sequence(p, SamplingParams(temperature=0.0, max_new_tokens=new_tokens, ignore_eos=True)) for p in prompts]
+        for sq in seqs:
+            sch.add(sq)
+        nsteps = 0
+        while not sch.is_finished():
+            batch, is_prefill = sch.schedule()
+            step.prefill(batch) if is_prefill else step.decode(batch)
+            nsteps += 1
+            assert nsteps < 200
+        # one file for all scenarios: the target's weights are shared (the EAGLE run differs in three boosted head rows), the
+        # draft == target run stores no draft at all
+        for k_ in list(out):
+            if k_.startswith("t.") or k_.startswith("t_cfg"):
+                if name == "ar":
+                    merged[k_] = out[k_]
+                elif name == "eagle" and k_ == "t.lm_head.weight":
+                    merged["eagle/" + k_] = out[k_]
+            elif name in ("sync", "eagle"):                    # "sync" and "async_diff" share the independent draft
+                merged[("diff/" if name == "sync" else "eagle/") + k_] = out[k_]
+        merged["prompt0"], merged["prompt1"] = torch.tensor(prompts[0]), torch.tensor(prompts[1])
+        merged[name + "/completion0"] = torch.tensor(seqs[0].completion_token_ids)
+        merged[name + "/completion1"] = torch.tensor(seqs[1].completion_token_ids)
+        merged[name + "/accepted_lens"] = torch.tensor(metrics["accepted_suffix_lens_with_recovery"] or [0])
+        merged[name + "/cache_hits"] = torch.tensor(metrics["cache_hits"] or [-1.0])
+        merged["K_F_bs_blocks_new"] = torch.tensor([K, F, bs, nblocks, new_tokens])
+        return name, seqs[0].completion_token_ids[:6], metrics["accepted_suffix_lens_with_recovery"], metrics["cache_hits"]
+
+    import contextlib
+    import io
+    results, merged = [], {}
+    for args in (("ar", "ar"), ("sync", "sync"), ("async_diff", "async"), ("async_same", "async", True), ("eagle", "async", False, True)):
+        with contextlib.redirect_stdout(io.StringIO()):          # the reference prints every step under __debug__
+            results.append(scenario(*args))
+    torch.tensor = real_tensor
+    save_npz(os.path.join(HERE, "ref_engine.npz"), merged)
+    for r in results:
+        print("ref_engine", r)
+
+
 def _top2_margin(row):
     t = row.float().topk(2).values
     return float(t[0] - t[1])
@@ -870,7 +1072,7 @@ def gen_stochastic():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "logic", "llama", "qwen", "eagle", "rounds", "engine", "scheduler", "stochastic"]
+    which = sys.argv[1:] or ["ops", "logic", "llama", "qwen", "eagle", "rounds", "refengine", "engine", "scheduler", "stochastic"]
     if "ops" in which:
         gen_ops()
     if "logic" in which:
@@ -881,6 +1083,8 @@ if __name__ == "__main__":
         gen_tiny_qwen()
     if "eagle" in which:
         gen_tiny_eagle()
+    if "refengine" in which:
+        gen_ref_engine()
     if "rounds" in which:
         gen_draft_rounds(False)
         gen_draft_rounds(True)

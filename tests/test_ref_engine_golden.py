@@ -1,0 +1,61 @@
+"""The engine against end-to-end runs of the REFERENCE'S OWN ENGINE CLASSES (tests/golden/make_golden.py gen_ref_engine):
+its Scheduler, AutoRegressiveStep / SpecDecodeStep, SpeculatorSync / SpeculatorAsync, Verifier, ModelRunner.run and the
+DraftRunner loop body executed on CPU (runner instances made without __init__; the async process group replaced by in-process
+queues) for a batch of two requests -- autoregressive, synchronous speculation, asynchronous speculation with an independent
+draft (every request misses -> JIT) and with draft == target (hits, full acceptance), and asynchronous speculation with an
+EAGLE-3 draft (hits, partial acceptance, extend rows).  This engine, on the oracle backend with the same weights, must produce
+the same completions, the same accepted-suffix length at every verification and the same cache-hit rates."""
+import pytest
+import torch
+
+from oracle.runner import oracle_runner_factory
+from ssd_amd.engine.llm_engine import LLMEngine
+from ssd_amd.model_config import ModelConfig
+from ssd_amd.sampling_params import SamplingParams
+
+
+def cfg_of(g, prefix, family="llama", **kw):
+    ci, cf = g[prefix + "cfg_i"].tolist(), g[prefix + "cfg_f"].tolist()
+    return ModelConfig(family, ci[0], ci[1], ci[2], ci[3], ci[4], ci[5], ci[6], cf[0], cf[1], ci[7], False, **kw)
+
+
+def weights(g, prefix):
+    return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix) and "cfg" not in k}
+
+
+@pytest.mark.parametrize("name", ["ar", "sync", "async_diff", "async_same", "eagle"])
+def test_engine_matches_the_reference_engine_run(golden, name):
+    g = golden("ref_engine")
+    K, F, bs, nblocks, new_tokens = g["K_F_bs_blocks_new"].tolist()
+    tcfg = cfg_of(g, "t_")
+    tw = weights(g, "t.")
+    eagle = name == "eagle"
+    if eagle:
+        tw["lm_head.weight"] = g["eagle/t.lm_head.weight"]
+    kw = dict(hf_config=tcfg, max_num_seqs=2, max_model_len=256, max_num_batched_tokens=256, kvcache_block_size=bs,
+              num_kvcache_blocks=nblocks, num_draft_kvcache_blocks=nblocks)
+    dw = None
+    if name != "ar":
+        if name == "async_same":
+            dw, dcfg = tw, tcfg
+        elif eagle:
+            dw = weights(g, "eagle/d.")
+            dcfg = cfg_of(g, "eagle/d_", "eagle3", draft_vocab_size=int(dw["lm_head.weight"].shape[0]), d_model_target=tcfg.hidden_size,
+                          eagle_taps=int(g["eagle/taps"].numel()))
+        else:
+            dw, dcfg = weights(g, "diff/d."), cfg_of(g, "diff/d_")
+        kw.update(draft="d", draft_hf_config=dcfg, speculate=True, speculate_k=K)
+        if name != "sync":
+            kw.update(draft_async=True, async_fan_out=F, jit_speculate=True, inprocess_draft=True)
+        if eagle:
+            kw.update(use_eagle=True, eagle_layers=g["eagle/taps"].tolist())
+    eng = LLMEngine("t", runner_factory=oracle_runner_factory(weights_target=tw, weights_draft=dw), **kw)
+    prompts = [g["prompt0"].tolist(), g["prompt1"].tolist()]
+    out, m = eng.generate(prompts, SamplingParams(temperature=0, max_new_tokens=new_tokens, ignore_eos=True), use_tqdm=False)
+    assert out[0]["token_ids"] == g[name + "/completion0"].tolist()
+    assert out[1]["token_ids"] == g[name + "/completion1"].tolist()
+    if name != "ar":
+        assert list(m["accepted_suffix_lens_with_recovery"]) == g[name + "/accepted_lens"].tolist()
+    if name in ("async_diff", "async_same", "eagle"):
+        assert [round(float(h), 4) for h in m["cache_hits"]] == [round(float(h), 4) for h in g[name + "/cache_hits"].tolist()]
+    eng.exit()
