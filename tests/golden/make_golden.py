@@ -728,12 +728,14 @@ def gen_ref_engine():
     prompts = [torch.randint(0, 512, (11,), generator=g).tolist(), torch.randint(0, 512, (7,), generator=g).tolist()]
     new_tokens = 14
 
-    def scenario(name, mode, same=False, eagle=False):
+    def scenario(name, mode, same=False, eagle=False, fan=None, fan_miss=None):
         Sequence.block_size = bs
         Sequence.counter = __import__("itertools").count()
+        fan, fan_miss = fan or [F] * (K + 1), fan_miss or [F] * (K + 1)
+        assert sum(fan) == sum(fan_miss) == MQ
         cfg = types.SimpleNamespace(speculate=mode != "ar", speculate_k=K, async_fan_out=F, MQ_LEN=MQ, draft_async=mode == "async",
-                                    use_eagle=eagle, jit_speculate=True, verbose=False, fan_out_list=[F] * (K + 1), fan_out_list_miss=[F] * (K + 1),
-                                    fan_out_t=torch.tensor([F] * (K + 1)), fan_out_t_miss=torch.tensor([F] * (K + 1)),
+                                    use_eagle=eagle, jit_speculate=True, verbose=False, fan_out_list=fan, fan_out_list_miss=fan_miss,
+                                    fan_out_t=torch.tensor(fan), fan_out_t_miss=torch.tensor(fan_miss),
                                     d_model_target=tcfg.hidden_size, max_blocks=max_len // bs, max_model_len=max_len, sampler_x=None,
                                     eagle_layers=taps if eagle else None)
         kw = dict(use_eagle=True, eagle_layers=taps) if eagle else {}
@@ -775,7 +777,7 @@ def gen_ref_engine():
         sch = Scheduler.__new__(Scheduler)
         sch.max_num_seqs, sch.max_num_batched_tokens, sch.max_model_len = 2, max_len, max_len
         sch.eos, sch.speculate, sch.F, sch.K, sch.block_size, sch.verbose, sch.draft_async = -1, mode != "ar", F, K, bs, False, mode == "async"
-        sch.fan_out_list = sch.fan_out_list_miss = [F] * (K + 1)
+        sch.fan_out_list, sch.fan_out_list_miss = fan, fan_miss
         sch.MQ_LEN = MQ
         sch.block_manager = BlockManager(nblocks, bs, is_draft=False, max_model_len=max_len)
         if mode != "ar":
@@ -838,12 +840,15 @@ def gen_ref_engine():
         merged[name + "/accepted_lens"] = torch.tensor(metrics["accepted_suffix_lens_with_recovery"] or [0])
         merged[name + "/cache_hits"] = torch.tensor(metrics["cache_hits"] or [-1.0])
         merged["K_F_bs_blocks_new"] = torch.tensor([K, F, bs, nblocks, new_tokens])
+        merged[name + "/fan"], merged[name + "/fan_miss"] = torch.tensor(fan), torch.tensor(fan_miss)
         return name, seqs[0].completion_token_ids[:6], metrics["accepted_suffix_lens_with_recovery"], metrics["cache_hits"]
 
     import contextlib
     import io
     results, merged = [], {}
-    for args in (("ar", "ar"), ("sync", "sync"), ("async_diff", "async"), ("async_same", "async", True), ("eagle", "async", False, True)):
+    # "async_fanout": non-uniform fan-out lists, different on hits and on misses (config.py:31-32,65-70), draft == target
+    for args in (("ar", "ar"), ("sync", "sync"), ("async_diff", "async"), ("async_same", "async", True), ("eagle", "async", False, True),
+                 ("async_fanout", "async", True, False, [1, 2, 2, 3], [3, 2, 2, 1])):
         with contextlib.redirect_stdout(io.StringIO()):          # the reference prints every step under __debug__
             results.append(scenario(*args))
     torch.tensor = real_tensor

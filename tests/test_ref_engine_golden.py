@@ -2,8 +2,8 @@
 its Scheduler, AutoRegressiveStep / SpecDecodeStep, SpeculatorSync / SpeculatorAsync, Verifier, ModelRunner.run and the
 DraftRunner loop body executed on CPU (runner instances made without __init__; the async process group replaced by in-process
 queues) for a batch of two requests -- autoregressive, synchronous speculation, asynchronous speculation with an independent
-draft (every request misses -> JIT) and with draft == target (hits, full acceptance), and asynchronous speculation with an
-EAGLE-3 draft (hits, partial acceptance, extend rows).  This engine, on the oracle backend with the same weights, must produce
+draft (every request misses -> JIT), with draft == target (hits, full acceptance; also with non-uniform hit / miss fan-out
+lists), and with an EAGLE-3 draft (hits, partial acceptance, extend rows).  This engine, on the oracle backend with the same weights, must produce
 the same completions, the same accepted-suffix length at every verification and the same cache-hit rates."""
 import pytest
 import torch
@@ -23,7 +23,7 @@ def weights(g, prefix):
     return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix) and "cfg" not in k}
 
 
-@pytest.mark.parametrize("name", ["ar", "sync", "async_diff", "async_same", "eagle"])
+@pytest.mark.parametrize("name", ["ar", "sync", "async_diff", "async_same", "eagle", "async_fanout"])
 def test_engine_matches_the_reference_engine_run(golden, name):
     g = golden("ref_engine")
     K, F, bs, nblocks, new_tokens = g["K_F_bs_blocks_new"].tolist()
@@ -36,7 +36,7 @@ def test_engine_matches_the_reference_engine_run(golden, name):
               num_kvcache_blocks=nblocks, num_draft_kvcache_blocks=nblocks)
     dw = None
     if name != "ar":
-        if name == "async_same":
+        if name in ("async_same", "async_fanout"):
             dw, dcfg = tw, tcfg
         elif eagle:
             dw = weights(g, "eagle/d.")
@@ -46,7 +46,8 @@ def test_engine_matches_the_reference_engine_run(golden, name):
             dw, dcfg = weights(g, "diff/d."), cfg_of(g, "diff/d_")
         kw.update(draft="d", draft_hf_config=dcfg, speculate=True, speculate_k=K)
         if name != "sync":
-            kw.update(draft_async=True, async_fan_out=F, jit_speculate=True, inprocess_draft=True)
+            kw.update(draft_async=True, async_fan_out=F, jit_speculate=True, inprocess_draft=True,
+                      fan_out_list=g[name + "/fan"].tolist(), fan_out_list_miss=g[name + "/fan_miss"].tolist())
         if eagle:
             kw.update(use_eagle=True, eagle_layers=g["eagle/taps"].tolist())
     eng = LLMEngine("t", runner_factory=oracle_runner_factory(weights_target=tw, weights_draft=dw), **kw)
@@ -56,6 +57,6 @@ def test_engine_matches_the_reference_engine_run(golden, name):
     assert out[1]["token_ids"] == g[name + "/completion1"].tolist()
     if name != "ar":
         assert list(m["accepted_suffix_lens_with_recovery"]) == g[name + "/accepted_lens"].tolist()
-    if name in ("async_diff", "async_same", "eagle"):
+    if name in ("async_diff", "async_same", "eagle", "async_fanout"):
         assert [round(float(h), 4) for h in m["cache_hits"]] == [round(float(h), 4) for h in g[name + "/cache_hits"].tolist()]
     eng.exit()
