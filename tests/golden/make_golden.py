@@ -815,6 +815,32 @@ def gen_ref_engine():
                 spec = SAM.SpeculatorAsync(K, torch.device("cpu"), F, max_len // bs, 512, BF, bs, max_len, None, 1, tok, False)
             ver = Verifier(K, torch.device("cpu"), target, None, F, True if mode == "async" else False, tok, metrics)
             step = SpecDecodeStep(sch, spec, ver, eagle, tok, mode == "async")
+        # top-2 logit margin of every greedy decision of the TARGET, keyed (sequence index, position of the decided token):
+        # lets a comparison against an implementation with another accumulation order stop at the first near-tie
+        margin_log = {}
+        real_run = target.run
+
+        def logged_run(seqs_, is_prefill, last_only=True, *a, **k):
+            if last_only:
+                seen = []
+                real_sampler = target.sampler
+                target.sampler = lambda lg, t, *aa, **kk: (seen.append(lg.float().topk(2, dim=-1).values), real_sampler(lg, t, *aa, **kk))[1]
+                try:
+                    res = real_run(seqs_, is_prefill, last_only, *a, **k)
+                finally:
+                    target.sampler = real_sampler
+                for sq, top in zip(seqs_, seen[0]):
+                    margin_log[(sq.seq_id, len(sq))] = float(top[0] - top[1])
+                return res
+            res = real_run(seqs_, is_prefill, last_only, *a, **k)
+            lg = (res[0] if isinstance(res, tuple) else res).float().view(len(seqs_), K + 1, -1)
+            top = lg.topk(2, dim=-1).values
+            for b_, sq in enumerate(seqs_):
+                pos0 = sq.num_tokens - (K + 1)
+                for j in range(K + 1):
+                    margin_log[(sq.seq_id, pos0 + j + 1)] = float(top[b_, j, 0] - top[b_, j, 1])
+            return res
+        target.run = logged_run
         seqs = [Sequence(p, SamplingParams(temperature=0.0, max_new_tokens=new_tokens, ignore_eos=True)) for p in prompts]
         for sq in seqs:
             sch.add(sq)
@@ -841,6 +867,8 @@ def gen_ref_engine():
         merged[name + "/cache_hits"] = torch.tensor(metrics["cache_hits"] or [-1.0])
         merged["K_F_bs_blocks_new"] = torch.tensor([K, F, bs, nblocks, new_tokens])
         merged[name + "/fan"], merged[name + "/fan_miss"] = torch.tensor(fan), torch.tensor(fan_miss)
+        for b_, sq in enumerate(seqs):      # margin of the decision that produced completion token i of sequence b
+            merged[name + f"/margins{b_}"] = torch.tensor([margin_log[(sq.seq_id, sq.num_prompt_tokens + i)] for i in range(new_tokens)])
         return name, seqs[0].completion_token_ids[:6], metrics["accepted_suffix_lens_with_recovery"], metrics["cache_hits"]
 
     import contextlib
