@@ -14,6 +14,8 @@ Fixtures written next to this file:
   engine_golden.npz  greedy AR token stream and sync-SD accepted-suffix trace driven by reference modules
   tiny_eagle3.npz    tiny LlamaForCausalLM(use_eagle) + Eagle3DraftForCausalLM: weights, d2t, target activations, draft
                      prefill / JIT decode / variable-length glue / tree-decode logits and prenorms
+  eagle_loader.npz   an EAGLE-3 checkpoint as published (flat midlayer.* names) pushed through the reference's load_eagle_model:
+                     the checkpoint tensors and the module parameters they end up in
   ref_engine.npz     the reference's OWN engine classes end to end on CPU -- Scheduler, AutoRegressiveStep / SpecDecodeStep,
                      SpeculatorSync / SpeculatorAsync, Verifier, ModelRunner.run and the DraftRunner loop body (instances made
                      without __init__, torch.distributed p2p replaced by in-process queues) -- for a batch of two requests:
@@ -885,6 +887,51 @@ def gen_ref_engine():
         print("ref_engine", r)
 
 
+def gen_eagle_loader():
+    """ssd/utils/loader.py load_model -> load_eagle_model (:64-183) on a tiny Eagle3DraftForCausalLM: (a) a checkpoint that
+    ships its own embed_tokens, (b) one that borrows the target's (same hidden size).  Inputs and resulting parameters."""
+    import tempfile
+    from safetensors.torch import save_file
+    from ssd.utils.loader import load_model
+    orig_to = torch.Tensor.to
+    torch.Tensor.to = lambda self, *a, **k: orig_to(self, *[("cpu" if x == "cuda" else x) for x in a], **k)
+    g = torch.Generator().manual_seed(61)
+    cfg = tiny_llama_cfg(h=128, L=1, nh=2, nkv=1, I=256, V=512)
+    cfg.draft_vocab_size = 256
+    hd, nh, nkv, I, h, A = 64, 2, 1, 256, 128, 3 * 128
+
+    def rnd(*shape):
+        return (0.1 * torch.randn(*shape, generator=g)).to(BF)
+    ckpt = {"midlayer.self_attn.q_proj.weight": rnd(nh * hd, 2 * h), "midlayer.self_attn.k_proj.weight": rnd(nkv * hd, 2 * h),
+            "midlayer.self_attn.v_proj.weight": rnd(nkv * hd, 2 * h), "midlayer.self_attn.o_proj.weight": rnd(h, nh * hd),
+            "midlayer.mlp.gate_proj.weight": rnd(I, h), "midlayer.mlp.up_proj.weight": rnd(I, h), "midlayer.mlp.down_proj.weight": rnd(h, I),
+            "midlayer.input_layernorm.weight": rnd(h), "midlayer.hidden_norm.weight": rnd(h), "midlayer.post_attention_layernorm.weight": rnd(h),
+            "norm.weight": rnd(h), "fc.weight": rnd(h, A), "lm_head.weight": rnd(256, h),
+            "d2t": torch.randint(0, 200, (256,), generator=g), "t2d": torch.zeros(512, dtype=torch.bool)}
+    embed_own, embed_tgt = rnd(512, h), rnd(512, h)
+    out = {"ckpt." + k: v.clone() for k, v in ckpt.items()}
+    out["ckpt_embed_own"], out["target_embed"] = embed_own.clone(), embed_tgt.clone()
+    for case in ("own", "borrowed"):
+        m = build(Eagle3DraftForCausalLM, cfg, 62, 0.05, draft=True, speculate=True, use_eagle=True, eagle_layers=[0, 1, 3], d_model_target=h,
+                  spec_k=2, async_fan_out=2, draft_async=True)
+        with tempfile.TemporaryDirectory() as tmp:
+            ddir, tdir = os.path.join(tmp, "eagle3-draft"), os.path.join(tmp, "target")
+            os.makedirs(ddir)
+            os.makedirs(tdir)
+            tensors = {k: v.contiguous() for k, v in ckpt.items()}
+            if case == "own":
+                tensors["embed_tokens.weight"] = embed_own
+            save_file(tensors, os.path.join(ddir, "model.safetensors"))
+            save_file({"model.embed_tokens.weight": embed_tgt}, os.path.join(tdir, "model-00001-of-00001.safetensors"))
+            load_model(m, ddir, target_path=tdir, target_hidden_size=h)
+        for k, v in m.state_dict().items():
+            out[f"{case}.{k}"] = v.data.clone()
+        out[f"{case}.d2t"] = m.d2t_tensor.clone()
+    torch.Tensor.to = orig_to
+    save_npz(os.path.join(HERE, "eagle_loader.npz"), out)
+    print("eagle_loader.npz written")
+
+
 def _top2_margin(row):
     t = row.float().topk(2).values
     return float(t[0] - t[1])
@@ -1105,7 +1152,7 @@ def gen_stochastic():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "logic", "llama", "qwen", "eagle", "rounds", "refengine", "engine", "scheduler", "stochastic"]
+    which = sys.argv[1:] or ["ops", "logic", "llama", "qwen", "eagle", "rounds", "eagleloader", "refengine", "engine", "scheduler", "stochastic"]
     if "ops" in which:
         gen_ops()
     if "logic" in which:
@@ -1116,6 +1163,8 @@ if __name__ == "__main__":
         gen_tiny_qwen()
     if "eagle" in which:
         gen_tiny_eagle()
+    if "eagleloader" in which:
+        gen_eagle_loader()
     if "refengine" in which:
         gen_ref_engine()
     if "rounds" in which:

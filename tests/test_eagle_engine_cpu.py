@@ -246,3 +246,29 @@ def test_glue_layout_matches_the_reference_mask_construction():
             b, j = int(batch_idx[t]), int(local_off[t])
             want_src.append(b * (K_ + 1) + (j if j < int(extend_counts[b]) else K_))
         assert lay["tc_src"] == want_src
+
+
+def test_eagle_checkpoint_loader_matches_the_reference_loader(golden, tmp_path):
+    """tests/golden/eagle_loader.npz: an EAGLE-3 checkpoint with the published flat names went through the REFERENCE's
+    load_eagle_model (loader.py:64-183); weights.load_eagle_safetensors must put every tensor where the reference did --
+    with the checkpoint's own embedding and with the target's borrowed one."""
+    from safetensors.torch import save_file
+    from ssd_amd import weights as W
+    from ssd_amd.model_config import ModelConfig
+    g = golden("eagle_loader")
+    cfg = ModelConfig("eagle3", 128, 1, 2, 1, 64, 256, 512, 1e-5, 5e5, 512, False, draft_vocab_size=256, d_model_target=128, eagle_taps=3)
+    ckpt = {k[5:]: v.contiguous() for k, v in g.items() if k.startswith("ckpt.")}
+    for case in ("own", "borrowed"):
+        ddir, tdir = tmp_path / f"{case}-draft", tmp_path / f"{case}-target"
+        ddir.mkdir()
+        tdir.mkdir()
+        tensors = dict(ckpt)
+        if case == "own":
+            tensors["embed_tokens.weight"] = g["ckpt_embed_own"].contiguous()
+        save_file(tensors, str(ddir / "model.safetensors"))
+        save_file({"model.embed_tokens.weight": g["target_embed"].contiguous()}, str(tdir / "model-00001-of-00001.safetensors"))
+        got = dict(W.load_eagle_safetensors(cfg, str(ddir), target_dir=str(tdir)))
+        want = {k[len(case) + 1:]: v for k, v in g.items() if k.startswith(case + ".")}
+        assert set(got) == set(want), set(got) ^ set(want)
+        for name, v in want.items():
+            assert torch.equal(got[name], v), f"{case}: {name}"
