@@ -14,6 +14,8 @@ Fixtures written next to this file:
   engine_golden.npz  greedy AR token stream and sync-SD accepted-suffix trace driven by reference modules
   tiny_eagle3.npz    tiny LlamaForCausalLM(use_eagle) + Eagle3DraftForCausalLM: weights, d2t, target activations, draft
                      prefill / JIT decode / variable-length glue / tree-decode logits and prenorms
+  loader_tp.npz      HF-named Llama and Qwen3 checkpoints pushed through the reference's load_model into tensor-parallel
+                     (tp_size 2) reference models: the checkpoint tensors and what each rank's parameters hold
   eagle_loader.npz   an EAGLE-3 checkpoint as published (flat midlayer.* names) pushed through the reference's load_eagle_model:
                      the checkpoint tensors and the module parameters they end up in
   ref_engine.npz     the reference's OWN engine classes end to end on CPU -- Scheduler, AutoRegressiveStep / SpecDecodeStep,
@@ -932,6 +934,51 @@ def gen_eagle_loader():
     print("eagle_loader.npz written")
 
 
+def gen_loader_tp():
+    """ssd/utils/loader.py load_safetensors_model (:186-205) + the per-parameter weight_loaders (ssd/layers/linear.py:90-95,
+    116-122,148-162,188-193; ssd/layers/embed_head.py:41-47) at tp_size 2: which slice of every HF tensor lands on which rank."""
+    import tempfile
+    import ssd.layers.embed_head as EH
+    import ssd.layers.linear as LN
+    from safetensors.torch import save_file
+    from ssd.utils.loader import load_model
+    fake = types.SimpleNamespace(get_rank=lambda group=None: group.rank, get_world_size=lambda group=None: 2)
+    real = (LN.dist, EH.dist)
+    LN.dist, EH.dist = fake, fake
+    g = torch.Generator().manual_seed(71)
+    out = {}
+    qcfg = types.SimpleNamespace(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, head_dim=64,
+                                 intermediate_size=256, vocab_size=512, max_position_embeddings=512, rms_norm_eps=1e-6,
+                                 tie_word_embeddings=False, hidden_act="silu", attention_bias=False, rope_theta=1000000.0, rope_scaling=None)
+    for fam, cls, cfg in (("llama", LlamaForCausalLM, tiny_llama_cfg(h=128, L=2, nh=4, nkv=2, I=256, V=512)), ("qwen3", Qwen3ForCausalLM, qcfg)):
+        hd = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
+        nh, nkv, h, I, V = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
+
+        def rnd(*shape):
+            return (0.1 * torch.randn(*shape, generator=g)).to(BF)
+        hf = {"model.embed_tokens.weight": rnd(V, h), "model.norm.weight": rnd(h), "lm_head.weight": rnd(V, h)}
+        for li in range(cfg.num_hidden_layers):
+            p = f"model.layers.{li}."
+            hf.update({p + "self_attn.q_proj.weight": rnd(nh * hd, h), p + "self_attn.k_proj.weight": rnd(nkv * hd, h),
+                       p + "self_attn.v_proj.weight": rnd(nkv * hd, h), p + "self_attn.o_proj.weight": rnd(h, nh * hd),
+                       p + "mlp.gate_proj.weight": rnd(I, h), p + "mlp.up_proj.weight": rnd(I, h), p + "mlp.down_proj.weight": rnd(h, I),
+                       p + "input_layernorm.weight": rnd(h), p + "post_attention_layernorm.weight": rnd(h)})
+            if fam == "qwen3":
+                hf.update({p + "self_attn.q_norm.weight": rnd(hd), p + "self_attn.k_norm.weight": rnd(hd)})
+        out.update({f"{fam}.hf.{k}": v.clone() for k, v in hf.items()})
+        for rank in range(2):
+            m = build(cls, cfg, 72, 0.05, speculate=False, tp_group=types.SimpleNamespace(rank=rank), tp_size=2)
+            with tempfile.TemporaryDirectory() as tmp:
+                d = os.path.join(tmp, "model")
+                os.makedirs(d)
+                save_file({k: v.contiguous() for k, v in hf.items()}, os.path.join(d, "model.safetensors"))
+                load_model(m, d)
+            out.update({f"{fam}.rank{rank}.{k}": v.data.clone() for k, v in m.state_dict().items()})
+    LN.dist, EH.dist = real
+    save_npz(os.path.join(HERE, "loader_tp.npz"), out)
+    print("loader_tp.npz written")
+
+
 def _top2_margin(row):
     t = row.float().topk(2).values
     return float(t[0] - t[1])
@@ -1152,7 +1199,7 @@ def gen_stochastic():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "logic", "llama", "qwen", "eagle", "rounds", "eagleloader", "refengine", "engine", "scheduler", "stochastic"]
+    which = sys.argv[1:] or ["ops", "logic", "llama", "qwen", "eagle", "rounds", "loadertp", "eagleloader", "refengine", "engine", "scheduler", "stochastic"]
     if "ops" in which:
         gen_ops()
     if "logic" in which:
@@ -1163,6 +1210,8 @@ if __name__ == "__main__":
         gen_tiny_qwen()
     if "eagle" in which:
         gen_tiny_eagle()
+    if "loadertp" in which:
+        gen_loader_tp()
     if "eagleloader" in which:
         gen_eagle_loader()
     if "refengine" in which:

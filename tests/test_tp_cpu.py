@@ -107,3 +107,24 @@ def test_safetensors_roundtrip(tmp_path):
     assert set(loaded) == set(full)
     for k in full:
         assert torch.equal(loaded[k], full[k]), k
+
+
+@pytest.mark.parametrize("family", ["llama", "qwen3"])
+def test_safetensors_loader_matches_the_reference_loader_per_rank(golden, tmp_path, family):
+    """tests/golden/loader_tp.npz: an HF-named checkpoint went through the REFERENCE's load_model into tensor-parallel
+    (tp_size 2) reference models; weights.load_safetensors must hand every rank exactly the slices the reference's
+    weight_loaders put there (packed q/k/v and gate/up, row-parallel o/down, vocabulary-parallel embedding and head)."""
+    from safetensors.torch import save_file
+    from ssd_amd import weights as W
+    from ssd_amd.model_config import ModelConfig
+    g = golden("loader_tp")
+    hf = {k[len(family) + 4:]: v.contiguous() for k, v in g.items() if k.startswith(family + ".hf.")}
+    save_file(hf, str(tmp_path / "model.safetensors"))
+    qk = family == "qwen3"
+    cfg = ModelConfig(family, 128, 2, 4, 2, 32 if not qk else 64, 256, 512, 1e-6 if qk else 1e-5, 1e6 if qk else 5e5, 512, False, qk)
+    for rank in range(2):
+        got = dict(W.load_safetensors(cfg, str(tmp_path), rank, 2))
+        want = {k[len(family) + 7:]: v for k, v in g.items() if k.startswith(f"{family}.rank{rank}.")}
+        assert set(got) == set(want), set(got) ^ set(want)
+        for name, v in want.items():
+            assert torch.equal(got[name], v), f"{family} rank {rank}: {name}"
