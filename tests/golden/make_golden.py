@@ -685,7 +685,7 @@ def _bare_runner(cls, model, hf, config, is_draft, block_size, nblocks, shim=Non
     """A reference ModelRunner / DraftRunner without its __init__ (no CUDA, no process group): exactly the attributes the
     eager code paths read."""
     r = object.__new__(cls)
-    hd = hf.hidden_size // hf.num_attention_heads
+    hd = getattr(hf, "head_dim", None) or hf.hidden_size // hf.num_attention_heads
     r.config, r.block_size, r.is_draft, r.rank, r.world_size, r.enforce_eager = config, block_size, is_draft, 0, 1, True
     r.device, r.model, r.sampler, r.use_eagle = torch.device("cpu"), model, Sampler(sampler_x=None, async_fan_out=config.async_fan_out), config.use_eagle
     r.hf_config = types.SimpleNamespace(vocab_size=hf.vocab_size, hidden_size=hf.hidden_size, torch_dtype=BF,
@@ -732,7 +732,11 @@ def gen_ref_engine():
     prompts = [torch.randint(0, 512, (11,), generator=g).tolist(), torch.randint(0, 512, (7,), generator=g).tolist()]
     new_tokens = 14
 
-    def scenario(name, mode, same=False, eagle=False, fan=None, fan_miss=None):
+    qcfg = types.SimpleNamespace(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, head_dim=64,
+                                 intermediate_size=256, vocab_size=512, max_position_embeddings=512, rms_norm_eps=1e-6,
+                                 tie_word_embeddings=False, hidden_act="silu", attention_bias=False, rope_theta=1000000.0, rope_scaling=None)
+
+    def scenario(name, mode, same=False, eagle=False, fan=None, fan_miss=None, qwen=False):
         Sequence.block_size = bs
         Sequence.counter = __import__("itertools").count()
         fan, fan_miss = fan or [F] * (K + 1), fan_miss or [F] * (K + 1)
@@ -743,9 +747,10 @@ def gen_ref_engine():
                                     d_model_target=tcfg.hidden_size, max_blocks=max_len // bs, max_model_len=max_len, sampler_x=None,
                                     eagle_layers=taps if eagle else None)
         kw = dict(use_eagle=True, eagle_layers=taps) if eagle else {}
-        tm = build(LlamaForCausalLM, tcfg, 51, 0.06, speculate=mode != "ar", spec_k=K, **kw)
+        tcfg_ = qcfg if qwen else tcfg
+        tm = build(Qwen3ForCausalLM if qwen else LlamaForCausalLM, tcfg_, 51, 0.06, speculate=mode != "ar", spec_k=K, **kw)
         out = {"t." + k: v.data.clone() for k, v in tm.state_dict().items()}
-        out["t_cfg_i"], out["t_cfg_f"] = cfg_fields(tcfg, "llama")
+        out["t_cfg_i"], out["t_cfg_f"] = cfg_fields(tcfg_, "qwen3" if qwen else "llama")
         dm = None
         if mode != "ar":
             if eagle:
@@ -765,6 +770,9 @@ def gen_ref_engine():
                 out["t.lm_head.weight"] = tm.lm_head.weight.data.clone()
                 out["d.d2t"] = dm.d2t_tensor.clone()
                 out["taps"] = torch.tensor(taps)
+            elif qwen:         # Qwen3 target + Qwen3 draft with the same weights (the reference hands a Qwen3 draft no tp_group)
+                dc = qcfg
+                dm = build(Qwen3ForCausalLM, qcfg, 51, 0.06, draft=True, speculate=True, spec_k=K, async_fan_out=F, draft_async=mode == "async")
             elif same:
                 dc = tcfg
                 dm = build(LlamaForCausalLM, tcfg, 51, 0.06, draft=True, speculate=True, spec_k=K, async_fan_out=F, draft_async=mode == "async")
@@ -774,7 +782,7 @@ def gen_ref_engine():
             out.update({"d." + k: v.data.clone() for k, v in dm.state_dict().items()})
             out["d_cfg_i"], out["d_cfg_f"] = cfg_fields(dc, "llama")
         shim = PlanShim(get_context)
-        target = _bare_runner(MRM.ModelRunner, tm, tcfg, cfg, False, bs, nblocks)
+        target = _bare_runner(MRM.ModelRunner, tm, tcfg_, cfg, False, bs, nblocks)
         draft = None
         if dm is not None:
             draft = _bare_runner(DRM.DraftRunner if mode == "async" else MRM.ModelRunner, dm, dc, cfg, True, bs, nblocks, shim if mode == "async" else None)
@@ -857,7 +865,10 @@ def gen_ref_engine():
         # one file for all scenarios: the target's weights are shared (the EAGLE run differs in three boosted head rows), the
         # draft == target run stores no draft at all
         for k_ in list(out):
-            if k_.startswith("t.") or k_.startswith("t_cfg"):
+            if qwen:
+                if (k_.startswith("t.") or k_.startswith("t_cfg")) and name == "qwen_sync":
+                    merged["qwen/" + k_] = out[k_]
+            elif k_.startswith("t.") or k_.startswith("t_cfg"):
                 if name == "ar":
                     merged[k_] = out[k_]
                 elif name == "eagle" and k_ == "t.lm_head.weight":
@@ -880,7 +891,8 @@ def gen_ref_engine():
     results, merged = [], {}
     # "async_fanout": non-uniform fan-out lists, different on hits and on misses (config.py:31-32,65-70), draft == target
     for args in (("ar", "ar"), ("sync", "sync"), ("async_diff", "async"), ("async_same", "async", True), ("eagle", "async", False, True),
-                 ("async_fanout", "async", True, False, [1, 2, 2, 3], [3, 2, 2, 1])):
+                 ("async_fanout", "async", True, False, [1, 2, 2, 3], [3, 2, 2, 1]),
+                 ("qwen_sync", "sync", True, False, None, None, True), ("qwen_async", "async", True, False, None, None, True)):
         with contextlib.redirect_stdout(io.StringIO()):          # the reference prints every step under __debug__
             results.append(scenario(*args))
     torch.tensor = real_tensor

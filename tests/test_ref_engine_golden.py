@@ -23,12 +23,17 @@ def weights(g, prefix):
     return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix) and "cfg" not in k}
 
 
-@pytest.mark.parametrize("name", ["ar", "sync", "async_diff", "async_same", "eagle", "async_fanout"])
-def test_engine_matches_the_reference_engine_run(golden, name):
-    g = golden("ref_engine")
+SCENARIOS = ["ar", "sync", "async_diff", "async_same", "eagle", "async_fanout", "qwen_sync", "qwen_async"]
+
+
+def scenario_setup(g, name):
+    """(target weights, draft weights or None, LLMEngine keyword arguments, tokens to generate) of one golden scenario."""
     K, F, bs, nblocks, new_tokens = g["K_F_bs_blocks_new"].tolist()
-    tcfg = cfg_of(g, "t_")
-    tw = weights(g, "t.")
+    qwen = name.startswith("qwen")            # Qwen3 target + Qwen3 draft (same weights): the per-head q / k norm path
+    if qwen:
+        tcfg, tw = cfg_of(g, "qwen/t_", "qwen3", qk_norm=True), weights(g, "qwen/t.")
+    else:
+        tcfg, tw = cfg_of(g, "t_"), weights(g, "t.")
     eagle = name == "eagle"
     if eagle:
         tw["lm_head.weight"] = g["eagle/t.lm_head.weight"]
@@ -36,7 +41,7 @@ def test_engine_matches_the_reference_engine_run(golden, name):
               num_kvcache_blocks=nblocks, num_draft_kvcache_blocks=nblocks)
     dw = None
     if name != "ar":
-        if name in ("async_same", "async_fanout"):
+        if name in ("async_same", "async_fanout") or qwen:
             dw, dcfg = tw, tcfg
         elif eagle:
             dw = weights(g, "eagle/d.")
@@ -45,11 +50,18 @@ def test_engine_matches_the_reference_engine_run(golden, name):
         else:
             dw, dcfg = weights(g, "diff/d."), cfg_of(g, "diff/d_")
         kw.update(draft="d", draft_hf_config=dcfg, speculate=True, speculate_k=K)
-        if name != "sync":
+        if name not in ("sync", "qwen_sync"):
             kw.update(draft_async=True, async_fan_out=F, jit_speculate=True, inprocess_draft=True,
                       fan_out_list=g[name + "/fan"].tolist(), fan_out_list_miss=g[name + "/fan_miss"].tolist())
         if eagle:
             kw.update(use_eagle=True, eagle_layers=g["eagle/taps"].tolist())
+    return tw, dw, kw, new_tokens
+
+
+@pytest.mark.parametrize("name", SCENARIOS)
+def test_engine_matches_the_reference_engine_run(golden, name):
+    g = golden("ref_engine")
+    tw, dw, kw, new_tokens = scenario_setup(g, name)
     eng = LLMEngine("t", runner_factory=oracle_runner_factory(weights_target=tw, weights_draft=dw), **kw)
     prompts = [g["prompt0"].tolist(), g["prompt1"].tolist()]
     out, m = eng.generate(prompts, SamplingParams(temperature=0, max_new_tokens=new_tokens, ignore_eos=True), use_tqdm=False)
@@ -57,6 +69,6 @@ def test_engine_matches_the_reference_engine_run(golden, name):
     assert out[1]["token_ids"] == g[name + "/completion1"].tolist()
     if name != "ar":
         assert list(m["accepted_suffix_lens_with_recovery"]) == g[name + "/accepted_lens"].tolist()
-    if name in ("async_diff", "async_same", "eagle", "async_fanout"):
+    if kw.get("draft_async"):
         assert [round(float(h), 4) for h in m["cache_hits"]] == [round(float(h), 4) for h in g[name + "/cache_hits"].tolist()]
     eng.exit()

@@ -21,38 +21,18 @@ def gpu():
     return torch.device("cuda", 0)
 
 
-@pytest.mark.parametrize("name", ["ar", "sync", "async_diff", "async_same", "eagle", "async_fanout"])
+from tests.test_ref_engine_golden import SCENARIOS, scenario_setup
+
+
+@pytest.mark.parametrize("name", SCENARIOS)
 def test_hip_engine_vs_reference_engine_run(gpu, golden, name):
     """The HIP engine against the completions of the reference's own engine classes; a divergence is only legitimate where
     the reference's own top-2 margin of that decision is a near-tie."""
     from ssd_amd.engine.llm_engine import LLMEngine
     from ssd_amd.sampling_params import SamplingParams
     from tests.test_model_gpu import hip_factory
-    from tests.test_ref_engine_golden import cfg_of, weights
     g = golden("ref_engine")
-    K, F, bs, nblocks, new_tokens = g["K_F_bs_blocks_new"].tolist()
-    tcfg, tw = cfg_of(g, "t_"), weights(g, "t.")
-    eagle = name == "eagle"
-    if eagle:
-        tw["lm_head.weight"] = g["eagle/t.lm_head.weight"]
-    kw = dict(hf_config=tcfg, max_num_seqs=2, max_model_len=256, max_num_batched_tokens=256, kvcache_block_size=bs,
-              num_kvcache_blocks=nblocks, num_draft_kvcache_blocks=nblocks)
-    dw = None
-    if name != "ar":
-        if name in ("async_same", "async_fanout"):
-            dw, dcfg = tw, tcfg
-        elif eagle:
-            dw = weights(g, "eagle/d.")
-            dcfg = cfg_of(g, "eagle/d_", "eagle3", draft_vocab_size=int(dw["lm_head.weight"].shape[0]), d_model_target=tcfg.hidden_size,
-                          eagle_taps=int(g["eagle/taps"].numel()))
-        else:
-            dw, dcfg = weights(g, "diff/d."), cfg_of(g, "diff/d_")
-        kw.update(draft="d", draft_hf_config=dcfg, speculate=True, speculate_k=K)
-        if name != "sync":
-            kw.update(draft_async=True, async_fan_out=F, jit_speculate=True, inprocess_draft=True,
-                      fan_out_list=g[name + "/fan"].tolist(), fan_out_list_miss=g[name + "/fan_miss"].tolist())
-        if eagle:
-            kw.update(use_eagle=True, eagle_layers=g["eagle/taps"].tolist())
+    tw, dw, kw, new_tokens = scenario_setup(g, name)
     eng = LLMEngine("t", runner_factory=hip_factory(tw, dw), **kw)
     prompts = [g["prompt0"].tolist(), g["prompt1"].tolist()]
     out, m = eng.generate(prompts, SamplingParams(temperature=0, max_new_tokens=new_tokens, ignore_eos=True), use_tqdm=False)
