@@ -736,7 +736,7 @@ def gen_ref_engine():
                                  intermediate_size=256, vocab_size=512, max_position_embeddings=512, rms_norm_eps=1e-6,
                                  tie_word_embeddings=False, hidden_act="silu", attention_bias=False, rope_theta=1000000.0, rope_scaling=None)
 
-    def scenario(name, mode, same=False, eagle=False, fan=None, fan_miss=None, qwen=False):
+    def scenario(name, mode, same=False, eagle=False, fan=None, fan_miss=None, qwen=False, eos=-1):
         Sequence.block_size = bs
         Sequence.counter = __import__("itertools").count()
         fan, fan_miss = fan or [F] * (K + 1), fan_miss or [F] * (K + 1)
@@ -788,7 +788,7 @@ def gen_ref_engine():
             draft = _bare_runner(DRM.DraftRunner if mode == "async" else MRM.ModelRunner, dm, dc, cfg, True, bs, nblocks, shim if mode == "async" else None)
         sch = Scheduler.__new__(Scheduler)
         sch.max_num_seqs, sch.max_num_batched_tokens, sch.max_model_len = 2, max_len, max_len
-        sch.eos, sch.speculate, sch.F, sch.K, sch.block_size, sch.verbose, sch.draft_async = -1, mode != "ar", F, K, bs, False, mode == "async"
+        sch.eos, sch.speculate, sch.F, sch.K, sch.block_size, sch.verbose, sch.draft_async = eos, mode != "ar", F, K, bs, False, mode == "async"
         sch.fan_out_list, sch.fan_out_list_miss = fan, fan_miss
         sch.MQ_LEN = MQ
         sch.block_manager = BlockManager(nblocks, bs, is_draft=False, max_model_len=max_len)
@@ -853,7 +853,7 @@ def gen_ref_engine():
                     margin_log[(sq.seq_id, pos0 + j + 1)] = float(top[b_, j, 0] - top[b_, j, 1])
             return res
         target.run = logged_run
-        seqs = [Sequence(p, SamplingParams(temperature=0.0, max_new_tokens=new_tokens, ignore_eos=True)) for p in prompts]
+        seqs = [Sequence(p, SamplingParams(temperature=0.0, max_new_tokens=new_tokens, ignore_eos=eos < 0)) for p in prompts]
         for sq in seqs:
             sch.add(sq)
         nsteps = 0
@@ -882,8 +882,9 @@ def gen_ref_engine():
         merged[name + "/cache_hits"] = torch.tensor(metrics["cache_hits"] or [-1.0])
         merged["K_F_bs_blocks_new"] = torch.tensor([K, F, bs, nblocks, new_tokens])
         merged[name + "/fan"], merged[name + "/fan_miss"] = torch.tensor(fan), torch.tensor(fan_miss)
+        merged[name + "/eos"] = torch.tensor([eos])
         for b_, sq in enumerate(seqs):      # margin of the decision that produced completion token i of sequence b
-            merged[name + f"/margins{b_}"] = torch.tensor([margin_log[(sq.seq_id, sq.num_prompt_tokens + i)] for i in range(new_tokens)])
+            merged[name + f"/margins{b_}"] = torch.tensor([margin_log[(sq.seq_id, sq.num_prompt_tokens + i)] for i in range(sq.num_completion_tokens)])
         return name, seqs[0].completion_token_ids[:6], metrics["accepted_suffix_lens_with_recovery"], metrics["cache_hits"]
 
     import contextlib
@@ -892,7 +893,9 @@ def gen_ref_engine():
     # "async_fanout": non-uniform fan-out lists, different on hits and on misses (config.py:31-32,65-70), draft == target
     for args in (("ar", "ar"), ("sync", "sync"), ("async_diff", "async"), ("async_same", "async", True), ("eagle", "async", False, True),
                  ("async_fanout", "async", True, False, [1, 2, 2, 3], [3, 2, 2, 1]),
-                 ("qwen_sync", "sync", True, False, None, None, True), ("qwen_async", "async", True, False, None, None, True)):
+                 ("qwen_sync", "sync", True, False, None, None, True), ("qwen_async", "async", True, False, None, None, True),
+                 # EOS inside an accepted suffix (scheduler.py:172-198): token 481 is the 4th token sequence 0 generates
+                 ("async_eos", "async", True, False, None, None, False, 481), ("sync_eos", "sync", False, False, None, None, False, 481)):
         with contextlib.redirect_stdout(io.StringIO()):          # the reference prints every step under __debug__
             results.append(scenario(*args))
     torch.tensor = real_tensor

@@ -23,7 +23,7 @@ def weights(g, prefix):
     return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix) and "cfg" not in k}
 
 
-SCENARIOS = ["ar", "sync", "async_diff", "async_same", "eagle", "async_fanout", "qwen_sync", "qwen_async"]
+SCENARIOS = ["ar", "sync", "async_diff", "async_same", "eagle", "async_fanout", "qwen_sync", "qwen_async", "async_eos", "sync_eos"]
 
 
 def scenario_setup(g, name):
@@ -41,7 +41,7 @@ def scenario_setup(g, name):
               num_kvcache_blocks=nblocks, num_draft_kvcache_blocks=nblocks)
     dw = None
     if name != "ar":
-        if name in ("async_same", "async_fanout") or qwen:
+        if name in ("async_same", "async_fanout", "async_eos") or qwen:
             dw, dcfg = tw, tcfg
         elif eagle:
             dw = weights(g, "eagle/d.")
@@ -50,11 +50,12 @@ def scenario_setup(g, name):
         else:
             dw, dcfg = weights(g, "diff/d."), cfg_of(g, "diff/d_")
         kw.update(draft="d", draft_hf_config=dcfg, speculate=True, speculate_k=K)
-        if name not in ("sync", "qwen_sync"):
+        if name not in ("sync", "qwen_sync", "sync_eos"):
             kw.update(draft_async=True, async_fan_out=F, jit_speculate=True, inprocess_draft=True,
                       fan_out_list=g[name + "/fan"].tolist(), fan_out_list_miss=g[name + "/fan_miss"].tolist())
         if eagle:
             kw.update(use_eagle=True, eagle_layers=g["eagle/taps"].tolist())
+    kw["eos"] = int(g[name + "/eos"][0])
     return tw, dw, kw, new_tokens
 
 
@@ -64,7 +65,7 @@ def test_engine_matches_the_reference_engine_run(golden, name):
     tw, dw, kw, new_tokens = scenario_setup(g, name)
     eng = LLMEngine("t", runner_factory=oracle_runner_factory(weights_target=tw, weights_draft=dw), **kw)
     prompts = [g["prompt0"].tolist(), g["prompt1"].tolist()]
-    out, m = eng.generate(prompts, SamplingParams(temperature=0, max_new_tokens=new_tokens, ignore_eos=True), use_tqdm=False)
+    out, m = eng.generate(prompts, SamplingParams(temperature=0, max_new_tokens=new_tokens, ignore_eos=kw["eos"] < 0), use_tqdm=False)
     assert out[0]["token_ids"] == g[name + "/completion0"].tolist()
     assert out[1]["token_ids"] == g[name + "/completion1"].tolist()
     if name != "ar":

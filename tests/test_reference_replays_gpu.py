@@ -35,7 +35,7 @@ def test_hip_engine_vs_reference_engine_run(gpu, golden, name):
     tw, dw, kw, new_tokens = scenario_setup(g, name)
     eng = LLMEngine("t", runner_factory=hip_factory(tw, dw), **kw)
     prompts = [g["prompt0"].tolist(), g["prompt1"].tolist()]
-    out, m = eng.generate(prompts, SamplingParams(temperature=0, max_new_tokens=new_tokens, ignore_eos=True), use_tqdm=False)
+    out, m = eng.generate(prompts, SamplingParams(temperature=0, max_new_tokens=new_tokens, ignore_eos=kw["eos"] < 0), use_tqdm=False)
     for b in range(2):
         margins = {len(prompts[b]) + i: float(v) for i, v in enumerate(g[f"{name}/margins{b}"].tolist())}
         assert_stream_matches(out[b]["token_ids"], g[f"{name}/completion{b}"].tolist(), margins, len(prompts[b]), f"{name} seq {b}")
