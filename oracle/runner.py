@@ -167,6 +167,11 @@ class OracleRunner:
             cur = self._pick(lg, seqs)
             spec[:, k + 1] = torch.tensor(cur)
         self._lq = torch.stack(lq, dim=1)
+        if bool((self._temps(seqs) > 0).any()):
+            # the reference's (K+1)-th draft forward (speculator_sync.py:47-56; deferred to deposit_pending here) goes through
+            # run() and its Sampler too: one more exponential draw per logit, discarded.  The oracle consumes it at the same
+            # point of the random stream, so that a seeded reference run can be replayed token for token.
+            torch.empty(B, lg.shape[-1], dtype=torch.float32).exponential_(1)
         return spec
 
     @torch.inference_mode()
@@ -232,6 +237,8 @@ class OracleRunner:
         out = torch.zeros(B, K, dtype=torch.int64)
         cur = list(rec)
         t = None if temps is None or not any(x > 0 for x in temps) else torch.tensor(temps, dtype=torch.float32)
+        if t is not None:
+            self._mirror_response_init(B)
         lq, pres = [], []
         for i in range(K):
             pos = [n - 1 + i for n in num_tokens]
@@ -280,9 +287,21 @@ class OracleRunner:
         self._glue_pre = pre[rows].view(B, K + 1, -1)
         return O.fork_topf(lg[rows].view(B, K + 1, -1), glue_ids, fan_lists)
 
+    def _mirror_response_init(self, B):
+        """Random-stream bookkeeping for seeded replays of a reference run at temperature > 0 (tests/test_ref_engine_golden.py):
+        the reference's hit_cache_and_respond starts every request by filling its reply buffer with uniform noise
+        (draft_runner.py:192-193) -- B*K*V bf16 draws from the global generator, before the JIT chain on a miss and before
+        the tree sampling on a hit.  The oracle consumes the same draws at the same point: at the top of draft_jit, or --
+        when the round had no JIT chain -- at the top of the glue."""
+        torch.empty((B, self.K, self.cfg.vocab_size), dtype=torch.bfloat16).uniform_()
+        self._response_init_done = True
+
     @torch.inference_mode()
     def draft_glue_fork(self, glue_ids, num_tokens, tables, fan_lists, eagle=None):
         """Glue decode + fork (draft_runner.py:620-700; async_spec_helpers.py:26-78)."""
+        if getattr(self, "_sampling_rounds", False) and not getattr(self, "_response_init_done", False):
+            self._mirror_response_init(glue_ids.shape[0])
+        self._response_init_done = False
         if eagle is not None:
             return self._eagle_glue_fork(glue_ids, num_tokens, tables, fan_lists, eagle)
         B, K = glue_ids.shape[0], self.K
@@ -307,6 +326,7 @@ class OracleRunner:
         toks = forks.reshape(-1)
         out = torch.zeros(B * mq, K, dtype=torch.int64)
         t = None if temps is None or not any(x > 0 for x in temps) else torch.tensor(temps, dtype=torch.float32).repeat_interleave(mq)
+        self._sampling_rounds = t is not None
         tl, pres = [], []
         if eagle:       # branch i starts from the glue prenorm of its position j_i (draft_runner.py:660-676), then conditions on itself
             cond = torch.cat([self._glue_pre[b, torch.tensor(jlists[b])] for b in range(B)], dim=0)

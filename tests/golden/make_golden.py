@@ -736,7 +736,7 @@ def gen_ref_engine():
                                  intermediate_size=256, vocab_size=512, max_position_embeddings=512, rms_norm_eps=1e-6,
                                  tie_word_embeddings=False, hidden_act="silu", attention_bias=False, rope_theta=1000000.0, rope_scaling=None)
 
-    def scenario(name, mode, same=False, eagle=False, fan=None, fan_miss=None, qwen=False, eos=-1):
+    def scenario(name, mode, same=False, eagle=False, fan=None, fan_miss=None, qwen=False, eos=-1, temp=0.0):
         Sequence.block_size = bs
         Sequence.counter = __import__("itertools").count()
         fan, fan_miss = fan or [F] * (K + 1), fan_miss or [F] * (K + 1)
@@ -853,9 +853,10 @@ def gen_ref_engine():
                     margin_log[(sq.seq_id, pos0 + j + 1)] = float(top[b_, j, 0] - top[b_, j, 1])
             return res
         target.run = logged_run
-        seqs = [Sequence(p, SamplingParams(temperature=0.0, max_new_tokens=new_tokens, ignore_eos=eos < 0)) for p in prompts]
+        seqs = [Sequence(p, SamplingParams(temperature=temp, max_new_tokens=new_tokens, ignore_eos=eos < 0)) for p in prompts]
         for sq in seqs:
             sch.add(sq)
+        torch.manual_seed(777)              # temperature > 0: the whole run draws from ONE seeded global stream
         nsteps = 0
         while not sch.is_finished():
             batch, is_prefill = sch.schedule()
@@ -882,7 +883,7 @@ def gen_ref_engine():
         merged[name + "/cache_hits"] = torch.tensor(metrics["cache_hits"] or [-1.0])
         merged["K_F_bs_blocks_new"] = torch.tensor([K, F, bs, nblocks, new_tokens])
         merged[name + "/fan"], merged[name + "/fan_miss"] = torch.tensor(fan), torch.tensor(fan_miss)
-        merged[name + "/eos"] = torch.tensor([eos])
+        merged[name + "/eos"], merged[name + "/temp"] = torch.tensor([eos]), torch.tensor([temp])
         for b_, sq in enumerate(seqs):      # margin of the decision that produced completion token i of sequence b
             merged[name + f"/margins{b_}"] = torch.tensor([margin_log[(sq.seq_id, sq.num_prompt_tokens + i)] for i in range(sq.num_completion_tokens)])
         return name, seqs[0].completion_token_ids[:6], metrics["accepted_suffix_lens_with_recovery"], metrics["cache_hits"]
@@ -895,7 +896,11 @@ def gen_ref_engine():
                  ("async_fanout", "async", True, False, [1, 2, 2, 3], [3, 2, 2, 1]),
                  ("qwen_sync", "sync", True, False, None, None, True), ("qwen_async", "async", True, False, None, None, True),
                  # EOS inside an accepted suffix (scheduler.py:172-198): token 481 is the 4th token sequence 0 generates
-                 ("async_eos", "async", True, False, None, None, False, 481), ("sync_eos", "sync", False, False, None, None, False, 481)):
+                 ("async_eos", "async", True, False, None, None, False, 481), ("sync_eos", "sync", False, False, None, None, False, 481),
+                 # temperature 0.8, independent draft, synchronous: sampled draft chains, sampled recovery tokens
+                 ("sync_temp", "sync", False, False, None, None, False, -1, 0.8), ("ar_temp", "ar", False, False, None, None, False, -1, 0.8),
+                 # ... asynchronous: sampled JIT chains and tree branches, ratio acceptance + residual resampling in verify()
+                 ("async_temp", "async", False, False, None, None, False, -1, 0.8), ("async_same_temp", "async", True, False, None, None, False, -1, 0.8)):
         with contextlib.redirect_stdout(io.StringIO()):          # the reference prints every step under __debug__
             results.append(scenario(*args))
     torch.tensor = real_tensor

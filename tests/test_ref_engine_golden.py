@@ -23,7 +23,7 @@ def weights(g, prefix):
     return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix) and "cfg" not in k}
 
 
-SCENARIOS = ["ar", "sync", "async_diff", "async_same", "eagle", "async_fanout", "qwen_sync", "qwen_async", "async_eos", "sync_eos"]
+SCENARIOS = ["ar", "sync", "async_diff", "async_same", "eagle", "async_fanout", "qwen_sync", "qwen_async", "async_eos", "sync_eos", "sync_temp", "ar_temp", "async_temp", "async_same_temp"]
 
 
 def scenario_setup(g, name):
@@ -40,8 +40,8 @@ def scenario_setup(g, name):
     kw = dict(hf_config=tcfg, max_num_seqs=2, max_model_len=256, max_num_batched_tokens=256, kvcache_block_size=bs,
               num_kvcache_blocks=nblocks, num_draft_kvcache_blocks=nblocks)
     dw = None
-    if name != "ar":
-        if name in ("async_same", "async_fanout", "async_eos") or qwen:
+    if name not in ("ar", "ar_temp"):
+        if name in ("async_same", "async_fanout", "async_eos", "async_same_temp") or qwen:
             dw, dcfg = tw, tcfg
         elif eagle:
             dw = weights(g, "eagle/d.")
@@ -50,7 +50,7 @@ def scenario_setup(g, name):
         else:
             dw, dcfg = weights(g, "diff/d."), cfg_of(g, "diff/d_")
         kw.update(draft="d", draft_hf_config=dcfg, speculate=True, speculate_k=K)
-        if name not in ("sync", "qwen_sync", "sync_eos"):
+        if name not in ("sync", "qwen_sync", "sync_eos", "sync_temp"):
             kw.update(draft_async=True, async_fan_out=F, jit_speculate=True, inprocess_draft=True,
                       fan_out_list=g[name + "/fan"].tolist(), fan_out_list_miss=g[name + "/fan_miss"].tolist())
         if eagle:
@@ -59,16 +59,21 @@ def scenario_setup(g, name):
     return tw, dw, kw, new_tokens
 
 
+def sampling(g, name, kw, new_tokens):
+    return SamplingParams(temperature=float(g[name + "/temp"][0]), max_new_tokens=new_tokens, ignore_eos=kw["eos"] < 0)
+
+
 @pytest.mark.parametrize("name", SCENARIOS)
 def test_engine_matches_the_reference_engine_run(golden, name):
     g = golden("ref_engine")
     tw, dw, kw, new_tokens = scenario_setup(g, name)
     eng = LLMEngine("t", runner_factory=oracle_runner_factory(weights_target=tw, weights_draft=dw), **kw)
     prompts = [g["prompt0"].tolist(), g["prompt1"].tolist()]
-    out, m = eng.generate(prompts, SamplingParams(temperature=0, max_new_tokens=new_tokens, ignore_eos=kw["eos"] < 0), use_tqdm=False)
+    torch.manual_seed(777)          # the seed of the reference run: at temperature > 0 both draw from one global stream
+    out, m = eng.generate(prompts, sampling(g, name, kw, new_tokens), use_tqdm=False)
     assert out[0]["token_ids"] == g[name + "/completion0"].tolist()
     assert out[1]["token_ids"] == g[name + "/completion1"].tolist()
-    if name != "ar":
+    if kw.get("speculate"):
         assert list(m["accepted_suffix_lens_with_recovery"]) == g[name + "/accepted_lens"].tolist()
     if kw.get("draft_async"):
         assert [round(float(h), 4) for h in m["cache_hits"]] == [round(float(h), 4) for h in g[name + "/cache_hits"].tolist()]
