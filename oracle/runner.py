@@ -251,7 +251,8 @@ class OracleRunner:
             else:
                 lg = self._decode(cur, pos, slots, [p + 1 for p in pos], bt)
             lq.append(lg)
-            cur = (O.argmax_rows(lg) if t is None else O.sample(lg, t)).tolist()
+            # the JIT chain samples with is_tree=True (draft_runner.py:172): sampler_x rescales it like the tree steps
+            cur = (O.argmax_rows(lg) if t is None else O.sample(lg, t, self.config.sampler_x, self.config.async_fan_out)).tolist()
             out[:, i] = torch.tensor(cur)
         self._lq = torch.stack(lq, dim=1)
         self._jit_acts = torch.stack(pres, dim=1) if pres else None

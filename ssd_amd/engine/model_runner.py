@@ -301,7 +301,14 @@ class ModelRunner:
             V = self.cfg.vocab_size
             if chain:
                 H.store_step_rows(lg, V, self.d_logits_q, B, V, self.K, self.d_step)
-            H.sample_rows(lg, V, B, V, self.d_temps, 1, self.d_rng, 1, self.d_next)
+            if chain and self.is_draft and self.sx is not None:
+                # the async draft's JIT chain samples with is_tree=True (reference draft_runner.py:172 -> sampler.py:29-31):
+                # under sampler_x its tokens come from the rescaled distribution, the q that verify() divides by
+                H.topk_rows(lg, V, B, V, self.sx_k, self.d_boost)
+                H.sample_rows(lg, V, B, V, self.d_temps, 1, self.d_rng, 1, self.d_next, boost_idx=self.d_boost, boost_k=self.sx_k,
+                              boost_x=self.sx)
+            else:
+                H.sample_rows(lg, V, B, V, self.d_temps, 1, self.d_rng, 1, self.d_next)
             H.rng_advance(self.d_rng)
         else:
             self.model.argmax(B, self.d_next)

@@ -687,7 +687,7 @@ def _bare_runner(cls, model, hf, config, is_draft, block_size, nblocks, shim=Non
     r = object.__new__(cls)
     hd = getattr(hf, "head_dim", None) or hf.hidden_size // hf.num_attention_heads
     r.config, r.block_size, r.is_draft, r.rank, r.world_size, r.enforce_eager = config, block_size, is_draft, 0, 1, True
-    r.device, r.model, r.sampler, r.use_eagle = torch.device("cpu"), model, Sampler(sampler_x=None, async_fan_out=config.async_fan_out), config.use_eagle
+    r.device, r.model, r.sampler, r.use_eagle = torch.device("cpu"), model, Sampler(sampler_x=config.sampler_x, async_fan_out=config.async_fan_out), config.use_eagle
     r.hf_config = types.SimpleNamespace(vocab_size=hf.vocab_size, hidden_size=hf.hidden_size, torch_dtype=BF,
                                         num_attention_heads=hf.num_attention_heads, num_key_value_heads=hf.num_key_value_heads, head_dim=hd)
     r.tokenizer, r.async_pg, r.draft_async, r.verbose = None, None, config.draft_async, False
@@ -736,7 +736,7 @@ def gen_ref_engine():
                                  intermediate_size=256, vocab_size=512, max_position_embeddings=512, rms_norm_eps=1e-6,
                                  tie_word_embeddings=False, hidden_act="silu", attention_bias=False, rope_theta=1000000.0, rope_scaling=None)
 
-    def scenario(name, mode, same=False, eagle=False, fan=None, fan_miss=None, qwen=False, eos=-1, temp=0.0):
+    def scenario(name, mode, same=False, eagle=False, fan=None, fan_miss=None, qwen=False, eos=-1, temp=0.0, sx=None, dtemp=None):
         Sequence.block_size = bs
         Sequence.counter = __import__("itertools").count()
         fan, fan_miss = fan or [F] * (K + 1), fan_miss or [F] * (K + 1)
@@ -744,7 +744,7 @@ def gen_ref_engine():
         cfg = types.SimpleNamespace(speculate=mode != "ar", speculate_k=K, async_fan_out=F, MQ_LEN=MQ, draft_async=mode == "async",
                                     use_eagle=eagle, jit_speculate=True, verbose=False, fan_out_list=fan, fan_out_list_miss=fan_miss,
                                     fan_out_t=torch.tensor(fan), fan_out_t_miss=torch.tensor(fan_miss),
-                                    d_model_target=tcfg.hidden_size, max_blocks=max_len // bs, max_model_len=max_len, sampler_x=None,
+                                    d_model_target=tcfg.hidden_size, max_blocks=max_len // bs, max_model_len=max_len, sampler_x=sx,
                                     eagle_layers=taps if eagle else None)
         kw = dict(use_eagle=True, eagle_layers=taps) if eagle else {}
         tcfg_ = qcfg if qwen else tcfg
@@ -825,7 +825,7 @@ def gen_ref_engine():
                             raise RuntimeError(cmd)
                 fake.pump = pump
                 spec = SAM.SpeculatorAsync(K, torch.device("cpu"), F, max_len // bs, 512, BF, bs, max_len, None, 1, tok, False)
-            ver = Verifier(K, torch.device("cpu"), target, None, F, True if mode == "async" else False, tok, metrics)
+            ver = Verifier(K, torch.device("cpu"), target, sx, F, True if mode == "async" else False, tok, metrics)
             step = SpecDecodeStep(sch, spec, ver, eagle, tok, mode == "async")
         # top-2 logit margin of every greedy decision of the TARGET, keyed (sequence index, position of the decided token):
         # lets a comparison against an implementation with another accumulation order stop at the first near-tie
@@ -853,7 +853,7 @@ def gen_ref_engine():
                     margin_log[(sq.seq_id, pos0 + j + 1)] = float(top[b_, j, 0] - top[b_, j, 1])
             return res
         target.run = logged_run
-        seqs = [Sequence(p, SamplingParams(temperature=temp, max_new_tokens=new_tokens, ignore_eos=eos < 0)) for p in prompts]
+        seqs = [Sequence(p, SamplingParams(temperature=temp, draft_temperature=dtemp, max_new_tokens=new_tokens, ignore_eos=eos < 0)) for p in prompts]
         for sq in seqs:
             sch.add(sq)
         torch.manual_seed(777)              # temperature > 0: the whole run draws from ONE seeded global stream
@@ -884,6 +884,8 @@ def gen_ref_engine():
         merged["K_F_bs_blocks_new"] = torch.tensor([K, F, bs, nblocks, new_tokens])
         merged[name + "/fan"], merged[name + "/fan_miss"] = torch.tensor(fan), torch.tensor(fan_miss)
         merged[name + "/eos"], merged[name + "/temp"] = torch.tensor([eos]), torch.tensor([temp])
+        merged[name + "/sampler_x"] = torch.tensor([-1.0 if sx is None else sx])
+        merged[name + "/draft_temp"] = torch.tensor([-1.0 if dtemp is None else dtemp])
         for b_, sq in enumerate(seqs):      # margin of the decision that produced completion token i of sequence b
             merged[name + f"/margins{b_}"] = torch.tensor([margin_log[(sq.seq_id, sq.num_prompt_tokens + i)] for i in range(sq.num_completion_tokens)])
         return name, seqs[0].completion_token_ids[:6], metrics["accepted_suffix_lens_with_recovery"], metrics["cache_hits"]
@@ -900,7 +902,9 @@ def gen_ref_engine():
                  # temperature 0.8, independent draft, synchronous: sampled draft chains, sampled recovery tokens
                  ("sync_temp", "sync", False, False, None, None, False, -1, 0.8), ("ar_temp", "ar", False, False, None, None, False, -1, 0.8),
                  # ... asynchronous: sampled JIT chains and tree branches, ratio acceptance + residual resampling in verify()
-                 ("async_temp", "async", False, False, None, None, False, -1, 0.8), ("async_same_temp", "async", True, False, None, None, False, -1, 0.8)):
+                 ("async_temp", "async", False, False, None, None, False, -1, 0.8), ("async_same_temp", "async", True, False, None, None, False, -1, 0.8),
+                 # sampler_x (top-(F+1) rescaling in the tree sampler and in verify())
+                 ("async_temp_x", "async", False, False, None, None, False, -1, 0.8, 0.5)):
         with contextlib.redirect_stdout(io.StringIO()):          # the reference prints every step under __debug__
             results.append(scenario(*args))
     torch.tensor = real_tensor

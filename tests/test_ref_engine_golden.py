@@ -23,7 +23,7 @@ def weights(g, prefix):
     return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix) and "cfg" not in k}
 
 
-SCENARIOS = ["ar", "sync", "async_diff", "async_same", "eagle", "async_fanout", "qwen_sync", "qwen_async", "async_eos", "sync_eos", "sync_temp", "ar_temp", "async_temp", "async_same_temp"]
+SCENARIOS = ["ar", "sync", "async_diff", "async_same", "eagle", "async_fanout", "qwen_sync", "qwen_async", "async_eos", "sync_eos", "sync_temp", "ar_temp", "async_temp", "async_same_temp", "async_temp_x"]
 
 
 def scenario_setup(g, name):
@@ -56,11 +56,15 @@ def scenario_setup(g, name):
         if eagle:
             kw.update(use_eagle=True, eagle_layers=g["eagle/taps"].tolist())
     kw["eos"] = int(g[name + "/eos"][0])
+    if float(g[name + "/sampler_x"][0]) > 0:
+        kw["sampler_x"] = float(g[name + "/sampler_x"][0])
     return tw, dw, kw, new_tokens
 
 
 def sampling(g, name, kw, new_tokens):
-    return SamplingParams(temperature=float(g[name + "/temp"][0]), max_new_tokens=new_tokens, ignore_eos=kw["eos"] < 0)
+    dt = float(g[name + "/draft_temp"][0])
+    return SamplingParams(temperature=float(g[name + "/temp"][0]), draft_temperature=None if dt < 0 else dt, max_new_tokens=new_tokens,
+                          ignore_eos=kw["eos"] < 0)
 
 
 @pytest.mark.parametrize("name", SCENARIOS)
