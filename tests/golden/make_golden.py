@@ -904,7 +904,10 @@ def gen_ref_engine():
                  # ... asynchronous: sampled JIT chains and tree branches, ratio acceptance + residual resampling in verify()
                  ("async_temp", "async", False, False, None, None, False, -1, 0.8), ("async_same_temp", "async", True, False, None, None, False, -1, 0.8),
                  # sampler_x (top-(F+1) rescaling in the tree sampler and in verify())
-                 ("async_temp_x", "async", False, False, None, None, False, -1, 0.8, 0.5)):
+                 ("async_temp_x", "async", False, False, None, None, False, -1, 0.8, 0.5),
+                 # draft == target in synchronous mode (every round fully accepted: the (K+1)-th draft forward matters every step),
+                 # and non-uniform fan-out lists with an independent draft (every request misses: the MISS list shapes the tree)
+                 ("sync_same", "sync", True), ("async_diff_fanout", "async", False, False, [1, 2, 2, 3], [3, 2, 2, 1])):
         with contextlib.redirect_stdout(io.StringIO()):          # the reference prints every step under __debug__
             results.append(scenario(*args))
     torch.tensor = real_tensor

@@ -23,7 +23,7 @@ def weights(g, prefix):
     return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix) and "cfg" not in k}
 
 
-SCENARIOS = ["ar", "sync", "async_diff", "async_same", "eagle", "async_fanout", "qwen_sync", "qwen_async", "async_eos", "sync_eos", "sync_temp", "ar_temp", "async_temp", "async_same_temp", "async_temp_x"]
+SCENARIOS = ["ar", "sync", "async_diff", "async_same", "eagle", "async_fanout", "qwen_sync", "qwen_async", "async_eos", "sync_eos", "sync_temp", "ar_temp", "async_temp", "async_same_temp", "async_temp_x", "sync_same", "async_diff_fanout"]
 
 
 def scenario_setup(g, name):
@@ -41,7 +41,7 @@ def scenario_setup(g, name):
               num_kvcache_blocks=nblocks, num_draft_kvcache_blocks=nblocks)
     dw = None
     if name not in ("ar", "ar_temp"):
-        if name in ("async_same", "async_fanout", "async_eos", "async_same_temp") or qwen:
+        if name in ("async_same", "async_fanout", "async_eos", "async_same_temp", "sync_same") or qwen:
             dw, dcfg = tw, tcfg
         elif eagle:
             dw = weights(g, "eagle/d.")
@@ -50,7 +50,7 @@ def scenario_setup(g, name):
         else:
             dw, dcfg = weights(g, "diff/d."), cfg_of(g, "diff/d_")
         kw.update(draft="d", draft_hf_config=dcfg, speculate=True, speculate_k=K)
-        if name not in ("sync", "qwen_sync", "sync_eos", "sync_temp"):
+        if name not in ("sync", "qwen_sync", "sync_eos", "sync_temp", "sync_same"):
             kw.update(draft_async=True, async_fan_out=F, jit_speculate=True, inprocess_draft=True,
                       fan_out_list=g[name + "/fan"].tolist(), fan_out_list_miss=g[name + "/fan_miss"].tolist())
         if eagle:
