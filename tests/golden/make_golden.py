@@ -736,7 +736,7 @@ def gen_ref_engine():
                                  intermediate_size=256, vocab_size=512, max_position_embeddings=512, rms_norm_eps=1e-6,
                                  tie_word_embeddings=False, hidden_act="silu", attention_bias=False, rope_theta=1000000.0, rope_scaling=None)
 
-    def scenario(name, mode, same=False, eagle=False, fan=None, fan_miss=None, qwen=False, eos=-1, temp=0.0, sx=None, dtemp=None):
+    def scenario(name, mode, same=False, eagle=False, fan=None, fan_miss=None, qwen=False, eos=-1, temp=0.0, sx=None, dtemp=None, peaky=False):
         Sequence.block_size = bs
         Sequence.counter = __import__("itertools").count()
         fan, fan_miss = fan or [F] * (K + 1), fan_miss or [F] * (K + 1)
@@ -779,6 +779,11 @@ def gen_ref_engine():
             else:
                 dc = dcfg
                 dm = build(LlamaForCausalLM, dcfg, 53, 0.08, draft=True, speculate=True, spec_k=K, async_fan_out=F, draft_async=mode == "async")
+                if peaky:       # an independent draft that still agrees with the target now and then: three boosted head rows in both
+                    for ti in torch.randperm(512, generator=torch.Generator().manual_seed(47))[:3].tolist():
+                        tm.lm_head.weight.data[ti] = (tm.lm_head.weight.data[ti].float() * 6.0).to(BF)
+                        dm.lm_head.weight.data[ti] = (dm.lm_head.weight.data[ti].float() * 6.0).to(BF)
+                    out["t.lm_head.weight"] = tm.lm_head.weight.data.clone()
             out.update({"d." + k: v.data.clone() for k, v in dm.state_dict().items()})
             out["d_cfg_i"], out["d_cfg_f"] = cfg_fields(dc, "llama")
         shim = PlanShim(get_context)
@@ -876,6 +881,8 @@ def gen_ref_engine():
                     merged["eagle/" + k_] = out[k_]
             elif name in ("sync", "eagle"):                    # "sync" and "async_diff" share the independent draft
                 merged[("diff/" if name == "sync" else "eagle/") + k_] = out[k_]
+            if peaky and name == "async_peaky" and (k_ == "t.lm_head.weight" or k_ == "d.lm_head.weight"):
+                merged["peaky/" + k_] = out[k_]
         merged["prompt0"], merged["prompt1"] = torch.tensor(prompts[0]), torch.tensor(prompts[1])
         merged[name + "/completion0"] = torch.tensor(seqs[0].completion_token_ids)
         merged[name + "/completion1"] = torch.tensor(seqs[1].completion_token_ids)
@@ -907,7 +914,10 @@ def gen_ref_engine():
                  ("async_temp_x", "async", False, False, None, None, False, -1, 0.8, 0.5),
                  # draft == target in synchronous mode (every round fully accepted: the (K+1)-th draft forward matters every step),
                  # and non-uniform fan-out lists with an independent draft (every request misses: the MISS list shapes the tree)
-                 ("sync_same", "sync", True), ("async_diff_fanout", "async", False, False, [1, 2, 2, 3], [3, 2, 2, 1])):
+                 ("sync_same", "sync", True), ("async_diff_fanout", "async", False, False, [1, 2, 2, 3], [3, 2, 2, 1]),
+                 # an independent draft that agrees with the target now and then: partial acceptance, hits AND misses
+                 ("async_peaky", "async", False, False, None, None, False, -1, 0.0, None, None, True),
+                 ("sync_peaky", "sync", False, False, None, None, False, -1, 0.0, None, None, True)):
         with contextlib.redirect_stdout(io.StringIO()):          # the reference prints every step under __debug__
             results.append(scenario(*args))
     torch.tensor = real_tensor
