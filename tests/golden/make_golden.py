@@ -736,13 +736,14 @@ def gen_ref_engine():
                                  intermediate_size=256, vocab_size=512, max_position_embeddings=512, rms_norm_eps=1e-6,
                                  tie_word_embeddings=False, hidden_act="silu", attention_bias=False, rope_theta=1000000.0, rope_scaling=None)
 
-    def scenario(name, mode, same=False, eagle=False, fan=None, fan_miss=None, qwen=False, eos=-1, temp=0.0, sx=None, dtemp=None, peaky=False):
+    def scenario(name, mode, same=False, eagle=False, fan=None, fan_miss=None, qwen=False, eos=-1, temp=0.0, sx=None, dtemp=None, peaky=False,
+                 jit=True):
         Sequence.block_size = bs
         Sequence.counter = __import__("itertools").count()
         fan, fan_miss = fan or [F] * (K + 1), fan_miss or [F] * (K + 1)
         assert sum(fan) == sum(fan_miss) == MQ
         cfg = types.SimpleNamespace(speculate=mode != "ar", speculate_k=K, async_fan_out=F, MQ_LEN=MQ, draft_async=mode == "async",
-                                    use_eagle=eagle, jit_speculate=True, verbose=False, fan_out_list=fan, fan_out_list_miss=fan_miss,
+                                    use_eagle=eagle, jit_speculate=jit, verbose=False, fan_out_list=fan, fan_out_list_miss=fan_miss,
                                     fan_out_t=torch.tensor(fan), fan_out_t_miss=torch.tensor(fan_miss),
                                     d_model_target=tcfg.hidden_size, max_blocks=max_len // bs, max_model_len=max_len, sampler_x=sx,
                                     eagle_layers=taps if eagle else None)
@@ -830,7 +831,7 @@ def gen_ref_engine():
                             raise RuntimeError(cmd)
                 fake.pump = pump
                 spec = SAM.SpeculatorAsync(K, torch.device("cpu"), F, max_len // bs, 512, BF, bs, max_len, None, 1, tok, False)
-            ver = Verifier(K, torch.device("cpu"), target, sx, F, True if mode == "async" else False, tok, metrics)
+            ver = Verifier(K, torch.device("cpu"), target, sx, F, jit if mode == "async" else False, tok, metrics)
             step = SpecDecodeStep(sch, spec, ver, eagle, tok, mode == "async")
         # top-2 logit margin of every greedy decision of the TARGET, keyed (sequence index, position of the decided token):
         # lets a comparison against an implementation with another accumulation order stop at the first near-tie
@@ -892,6 +893,7 @@ def gen_ref_engine():
         merged[name + "/fan"], merged[name + "/fan_miss"] = torch.tensor(fan), torch.tensor(fan_miss)
         merged[name + "/eos"], merged[name + "/temp"] = torch.tensor([eos]), torch.tensor([temp])
         merged[name + "/sampler_x"] = torch.tensor([-1.0 if sx is None else sx])
+        merged[name + "/jit"] = torch.tensor([1 if jit else 0])
         merged[name + "/draft_temp"] = torch.tensor([-1.0 if dtemp is None else dtemp])
         for b_, sq in enumerate(seqs):      # margin of the decision that produced completion token i of sequence b
             merged[name + f"/margins{b_}"] = torch.tensor([margin_log[(sq.seq_id, sq.num_prompt_tokens + i)] for i in range(sq.num_completion_tokens)])
@@ -917,7 +919,10 @@ def gen_ref_engine():
                  ("sync_same", "sync", True), ("async_diff_fanout", "async", False, False, [1, 2, 2, 3], [3, 2, 2, 1]),
                  # an independent draft that agrees with the target now and then: partial acceptance, hits AND misses
                  ("async_peaky", "async", False, False, None, None, False, -1, 0.0, None, None, True),
-                 ("sync_peaky", "sync", False, False, None, None, False, -1, 0.0, None, None, True)):
+                 ("sync_peaky", "sync", False, False, None, None, False, -1, 0.0, None, None, True),
+                 # the "fast" backup (no JIT chain: a miss is answered with filler tokens) on the partially agreeing pair, and EAGLE with EOS
+                 ("async_fast", "async", False, False, None, None, False, -1, 0.0, None, None, True, False),
+                 ("eagle_eos", "async", False, True, None, None, False, 362)):
         with contextlib.redirect_stdout(io.StringIO()):          # the reference prints every step under __debug__
             results.append(scenario(*args))
     torch.tensor = real_tensor

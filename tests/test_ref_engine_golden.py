@@ -23,7 +23,7 @@ def weights(g, prefix):
     return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix) and "cfg" not in k}
 
 
-SCENARIOS = ["ar", "sync", "async_diff", "async_same", "eagle", "async_fanout", "qwen_sync", "qwen_async", "async_eos", "sync_eos", "sync_temp", "ar_temp", "async_temp", "async_same_temp", "async_temp_x", "sync_same", "async_diff_fanout", "async_peaky", "sync_peaky"]
+SCENARIOS = ["ar", "sync", "async_diff", "async_same", "eagle", "async_fanout", "qwen_sync", "qwen_async", "async_eos", "sync_eos", "sync_temp", "ar_temp", "async_temp", "async_same_temp", "async_temp_x", "sync_same", "async_diff_fanout", "async_peaky", "sync_peaky", "async_fast", "eagle_eos"]
 
 
 def scenario_setup(g, name):
@@ -34,7 +34,7 @@ def scenario_setup(g, name):
         tcfg, tw = cfg_of(g, "qwen/t_", "qwen3", qk_norm=True), weights(g, "qwen/t.")
     else:
         tcfg, tw = cfg_of(g, "t_"), weights(g, "t.")
-    eagle = name == "eagle"
+    eagle = name.startswith("eagle")
     if eagle:
         tw["lm_head.weight"] = g["eagle/t.lm_head.weight"]
     kw = dict(hf_config=tcfg, max_num_seqs=2, max_model_len=256, max_num_batched_tokens=256, kvcache_block_size=bs,
@@ -49,11 +49,11 @@ def scenario_setup(g, name):
                           eagle_taps=int(g["eagle/taps"].numel()))
         else:
             dw, dcfg = weights(g, "diff/d."), cfg_of(g, "diff/d_")
-            if name.endswith("_peaky"):         # the same independent draft, three head rows boosted in both models
+            if name.endswith("_peaky") or name == "async_fast":         # the same independent draft, three head rows boosted in both models
                 tw["lm_head.weight"], dw["lm_head.weight"] = g["peaky/t.lm_head.weight"], g["peaky/d.lm_head.weight"]
         kw.update(draft="d", draft_hf_config=dcfg, speculate=True, speculate_k=K)
         if name not in ("sync", "qwen_sync", "sync_eos", "sync_temp", "sync_same", "sync_peaky"):
-            kw.update(draft_async=True, async_fan_out=F, jit_speculate=True, inprocess_draft=True,
+            kw.update(draft_async=True, async_fan_out=F, jit_speculate=bool(int(g[name + "/jit"][0])), inprocess_draft=True,
                       fan_out_list=g[name + "/fan"].tolist(), fan_out_list_miss=g[name + "/fan_miss"].tolist())
         if eagle:
             kw.update(use_eagle=True, eagle_layers=g["eagle/taps"].tolist())
@@ -79,8 +79,8 @@ def test_engine_matches_the_reference_engine_run(golden, name):
     out, m = eng.generate(prompts, sampling(g, name, kw, new_tokens), use_tqdm=False)
     assert out[0]["token_ids"] == g[name + "/completion0"].tolist()
     assert out[1]["token_ids"] == g[name + "/completion1"].tolist()
-    if kw.get("speculate"):
+    if kw.get("speculate") and name != "async_fast":        # (a miss is answered with filler tokens: the reference's are random)
         assert list(m["accepted_suffix_lens_with_recovery"]) == g[name + "/accepted_lens"].tolist()
-    if kw.get("draft_async"):
+    if kw.get("draft_async") and name != "async_fast":      # (one lucky random filler token saves the reference a step there)
         assert [round(float(h), 4) for h in m["cache_hits"]] == [round(float(h), 4) for h in g[name + "/cache_hits"].tolist()]
     eng.exit()
