@@ -737,7 +737,9 @@ def gen_ref_engine():
                                  tie_word_embeddings=False, hidden_act="silu", attention_bias=False, rope_theta=1000000.0, rope_scaling=None)
 
     def scenario(name, mode, same=False, eagle=False, fan=None, fan_miss=None, qwen=False, eos=-1, temp=0.0, sx=None, dtemp=None, peaky=False,
-                 jit=True):
+                 jit=True, geom=(3, 2)):
+        K, F = geom                          # speculation depth and fan-out of this scenario
+        MQ = F * (K + 1)
         Sequence.block_size = bs
         Sequence.counter = __import__("itertools").count()
         fan, fan_miss = fan or [F] * (K + 1), fan_miss or [F] * (K + 1)
@@ -889,7 +891,8 @@ def gen_ref_engine():
         merged[name + "/completion1"] = torch.tensor(seqs[1].completion_token_ids)
         merged[name + "/accepted_lens"] = torch.tensor(metrics["accepted_suffix_lens_with_recovery"] or [0])
         merged[name + "/cache_hits"] = torch.tensor(metrics["cache_hits"] or [-1.0])
-        merged["K_F_bs_blocks_new"] = torch.tensor([K, F, bs, nblocks, new_tokens])
+        merged["K_F_bs_blocks_new"] = torch.tensor([3, 2, bs, nblocks, new_tokens])
+        merged[name + "/K_F"] = torch.tensor([K, F])
         merged[name + "/fan"], merged[name + "/fan_miss"] = torch.tensor(fan), torch.tensor(fan_miss)
         merged[name + "/eos"], merged[name + "/temp"] = torch.tensor([eos]), torch.tensor([temp])
         merged[name + "/sampler_x"] = torch.tensor([-1.0 if sx is None else sx])
@@ -922,7 +925,11 @@ def gen_ref_engine():
                  ("sync_peaky", "sync", False, False, None, None, False, -1, 0.0, None, None, True),
                  # the "fast" backup (no JIT chain: a miss is answered with filler tokens) on the partially agreeing pair, and EAGLE with EOS
                  ("async_fast", "async", False, False, None, None, False, -1, 0.0, None, None, True, False),
-                 ("eagle_eos", "async", False, True, None, None, False, 362)):
+                 ("eagle_eos", "async", False, True, None, None, False, 362),
+                 # other tree geometries: the smallest (K = 1, F = 1: two branches) and a deeper, wider one (K = 5, F = 3: 18 branches)
+                 ("async_k1f1", "async", True, False, None, None, False, -1, 0.0, None, None, False, True, (1, 1)),
+                 ("async_k5f3", "async", False, False, None, None, False, -1, 0.0, None, None, True, True, (5, 3)),
+                 ("eagle_k5f3", "async", False, True, None, None, False, -1, 0.0, None, None, False, True, (5, 3))):
         with contextlib.redirect_stdout(io.StringIO()):          # the reference prints every step under __debug__
             results.append(scenario(*args))
     torch.tensor = real_tensor

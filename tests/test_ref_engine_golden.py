@@ -23,12 +23,13 @@ def weights(g, prefix):
     return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix) and "cfg" not in k}
 
 
-SCENARIOS = ["ar", "sync", "async_diff", "async_same", "eagle", "async_fanout", "qwen_sync", "qwen_async", "async_eos", "sync_eos", "sync_temp", "ar_temp", "async_temp", "async_same_temp", "async_temp_x", "sync_same", "async_diff_fanout", "async_peaky", "sync_peaky", "async_fast", "eagle_eos"]
+SCENARIOS = ["ar", "sync", "async_diff", "async_same", "eagle", "async_fanout", "qwen_sync", "qwen_async", "async_eos", "sync_eos", "sync_temp", "ar_temp", "async_temp", "async_same_temp", "async_temp_x", "sync_same", "async_diff_fanout", "async_peaky", "sync_peaky", "async_fast", "eagle_eos", "async_k1f1", "async_k5f3", "eagle_k5f3"]
 
 
 def scenario_setup(g, name):
     """(target weights, draft weights or None, LLMEngine keyword arguments, tokens to generate) of one golden scenario."""
-    K, F, bs, nblocks, new_tokens = g["K_F_bs_blocks_new"].tolist()
+    _, _, bs, nblocks, new_tokens = g["K_F_bs_blocks_new"].tolist()
+    K, F = g[name + "/K_F"].tolist()
     qwen = name.startswith("qwen")            # Qwen3 target + Qwen3 draft (same weights): the per-head q / k norm path
     if qwen:
         tcfg, tw = cfg_of(g, "qwen/t_", "qwen3", qk_norm=True), weights(g, "qwen/t.")
@@ -41,7 +42,7 @@ def scenario_setup(g, name):
               num_kvcache_blocks=nblocks, num_draft_kvcache_blocks=nblocks)
     dw = None
     if name not in ("ar", "ar_temp"):
-        if name in ("async_same", "async_fanout", "async_eos", "async_same_temp", "sync_same") or qwen:
+        if name in ("async_same", "async_fanout", "async_eos", "async_same_temp", "sync_same", "async_k1f1") or qwen:
             dw, dcfg = tw, tcfg
         elif eagle:
             dw = weights(g, "eagle/d.")
@@ -49,7 +50,7 @@ def scenario_setup(g, name):
                           eagle_taps=int(g["eagle/taps"].numel()))
         else:
             dw, dcfg = weights(g, "diff/d."), cfg_of(g, "diff/d_")
-            if name.endswith("_peaky") or name == "async_fast":         # the same independent draft, three head rows boosted in both models
+            if name.endswith("_peaky") or name in ("async_fast", "async_k5f3"):         # the same independent draft, three head rows boosted in both models
                 tw["lm_head.weight"], dw["lm_head.weight"] = g["peaky/t.lm_head.weight"], g["peaky/d.lm_head.weight"]
         kw.update(draft="d", draft_hf_config=dcfg, speculate=True, speculate_k=K)
         if name not in ("sync", "qwen_sync", "sync_eos", "sync_temp", "sync_same", "sync_peaky"):
