@@ -731,13 +731,14 @@ def gen_ref_engine():
     g = torch.Generator().manual_seed(41)
     prompts = [torch.randint(0, 512, (11,), generator=g).tolist(), torch.randint(0, 512, (7,), generator=g).tolist()]
     new_tokens = 14
+    prompt3 = torch.randint(0, 512, (9,), generator=g).tolist()
 
     qcfg = types.SimpleNamespace(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, head_dim=64,
                                  intermediate_size=256, vocab_size=512, max_position_embeddings=512, rms_norm_eps=1e-6,
                                  tie_word_embeddings=False, hidden_act="silu", attention_bias=False, rope_theta=1000000.0, rope_scaling=None)
 
     def scenario(name, mode, same=False, eagle=False, fan=None, fan_miss=None, qwen=False, eos=-1, temp=0.0, sx=None, dtemp=None, peaky=False,
-                 jit=True, geom=(3, 2)):
+                 jit=True, geom=(3, 2), nreq=2):
         K, F = geom                          # speculation depth and fan-out of this scenario
         MQ = F * (K + 1)
         Sequence.block_size = bs
@@ -861,7 +862,10 @@ def gen_ref_engine():
                     margin_log[(sq.seq_id, pos0 + j + 1)] = float(top[b_, j, 0] - top[b_, j, 1])
             return res
         target.run = logged_run
-        seqs = [Sequence(p, SamplingParams(temperature=temp, draft_temperature=dtemp, max_new_tokens=new_tokens, ignore_eos=eos < 0)) for p in prompts]
+        plist = prompts + [prompt3] if nreq == 3 else prompts       # three requests through two batch slots: the third is prefilled mid-run
+        seqs = [Sequence(p, SamplingParams(temperature=temp, draft_temperature=dtemp, max_new_tokens=new_tokens - 3 * i, ignore_eos=eos < 0))
+                for i, p in enumerate(plist)] if nreq == 3 else \
+               [Sequence(p, SamplingParams(temperature=temp, draft_temperature=dtemp, max_new_tokens=new_tokens, ignore_eos=eos < 0)) for p in prompts]
         for sq in seqs:
             sch.add(sq)
         torch.manual_seed(777)              # temperature > 0: the whole run draws from ONE seeded global stream
@@ -889,10 +893,14 @@ def gen_ref_engine():
         merged["prompt0"], merged["prompt1"] = torch.tensor(prompts[0]), torch.tensor(prompts[1])
         merged[name + "/completion0"] = torch.tensor(seqs[0].completion_token_ids)
         merged[name + "/completion1"] = torch.tensor(seqs[1].completion_token_ids)
+        if nreq == 3:
+            merged["prompt2"] = torch.tensor(prompt3)
+            merged[name + "/completion2"] = torch.tensor(seqs[2].completion_token_ids)
         merged[name + "/accepted_lens"] = torch.tensor(metrics["accepted_suffix_lens_with_recovery"] or [0])
         merged[name + "/cache_hits"] = torch.tensor(metrics["cache_hits"] or [-1.0])
         merged["K_F_bs_blocks_new"] = torch.tensor([3, 2, bs, nblocks, new_tokens])
         merged[name + "/K_F"] = torch.tensor([K, F])
+        merged[name + "/nreq"] = torch.tensor([nreq])
         merged[name + "/fan"], merged[name + "/fan_miss"] = torch.tensor(fan), torch.tensor(fan_miss)
         merged[name + "/eos"], merged[name + "/temp"] = torch.tensor([eos]), torch.tensor([temp])
         merged[name + "/sampler_x"] = torch.tensor([-1.0 if sx is None else sx])
@@ -929,7 +937,11 @@ def gen_ref_engine():
                  # other tree geometries: the smallest (K = 1, F = 1: two branches) and a deeper, wider one (K = 5, F = 3: 18 branches)
                  ("async_k1f1", "async", True, False, None, None, False, -1, 0.0, None, None, False, True, (1, 1)),
                  ("async_k5f3", "async", False, False, None, None, False, -1, 0.0, None, None, True, True, (5, 3)),
-                 ("eagle_k5f3", "async", False, True, None, None, False, -1, 0.0, None, None, False, True, (5, 3))):
+                 ("eagle_k5f3", "async", False, True, None, None, False, -1, 0.0, None, None, False, True, (5, 3)),
+                 # three requests (14 / 11 / 8 new tokens) through two batch slots: the third is admitted, and prefilled on the draft, mid-run
+                 ("async_queue", "async", False, False, None, None, False, -1, 0.0, None, None, True, True, (3, 2), 3),
+                 ("eagle_queue", "async", False, True, None, None, False, -1, 0.0, None, None, False, True, (3, 2), 3),
+                 ("sync_queue", "sync", False, False, None, None, False, -1, 0.0, None, None, True, True, (3, 2), 3)):
         with contextlib.redirect_stdout(io.StringIO()):          # the reference prints every step under __debug__
             results.append(scenario(*args))
     torch.tensor = real_tensor

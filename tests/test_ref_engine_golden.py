@@ -23,7 +23,7 @@ def weights(g, prefix):
     return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix) and "cfg" not in k}
 
 
-SCENARIOS = ["ar", "sync", "async_diff", "async_same", "eagle", "async_fanout", "qwen_sync", "qwen_async", "async_eos", "sync_eos", "sync_temp", "ar_temp", "async_temp", "async_same_temp", "async_temp_x", "sync_same", "async_diff_fanout", "async_peaky", "sync_peaky", "async_fast", "eagle_eos", "async_k1f1", "async_k5f3", "eagle_k5f3"]
+SCENARIOS = ["ar", "sync", "async_diff", "async_same", "eagle", "async_fanout", "qwen_sync", "qwen_async", "async_eos", "sync_eos", "sync_temp", "ar_temp", "async_temp", "async_same_temp", "async_temp_x", "sync_same", "async_diff_fanout", "async_peaky", "sync_peaky", "async_fast", "eagle_eos", "async_k1f1", "async_k5f3", "eagle_k5f3", "async_queue", "eagle_queue", "sync_queue"]
 
 
 def scenario_setup(g, name):
@@ -50,10 +50,10 @@ def scenario_setup(g, name):
                           eagle_taps=int(g["eagle/taps"].numel()))
         else:
             dw, dcfg = weights(g, "diff/d."), cfg_of(g, "diff/d_")
-            if name.endswith("_peaky") or name in ("async_fast", "async_k5f3"):         # the same independent draft, three head rows boosted in both models
+            if name.endswith("_peaky") or name in ("async_fast", "async_k5f3", "async_queue", "sync_queue"):         # the same independent draft, three head rows boosted in both models
                 tw["lm_head.weight"], dw["lm_head.weight"] = g["peaky/t.lm_head.weight"], g["peaky/d.lm_head.weight"]
         kw.update(draft="d", draft_hf_config=dcfg, speculate=True, speculate_k=K)
-        if name not in ("sync", "qwen_sync", "sync_eos", "sync_temp", "sync_same", "sync_peaky"):
+        if not name.startswith("sync") and name != "qwen_sync":
             kw.update(draft_async=True, async_fan_out=F, jit_speculate=bool(int(g[name + "/jit"][0])), inprocess_draft=True,
                       fan_out_list=g[name + "/fan"].tolist(), fan_out_list_miss=g[name + "/fan_miss"].tolist())
         if eagle:
@@ -75,11 +75,15 @@ def test_engine_matches_the_reference_engine_run(golden, name):
     g = golden("ref_engine")
     tw, dw, kw, new_tokens = scenario_setup(g, name)
     eng = LLMEngine("t", runner_factory=oracle_runner_factory(weights_target=tw, weights_draft=dw), **kw)
-    prompts = [g["prompt0"].tolist(), g["prompt1"].tolist()]
+    nreq = int(g[name + "/nreq"][0])
+    prompts = [g[f"prompt{i}"].tolist() for i in range(nreq)]
+    sp = sampling(g, name, kw, new_tokens)
+    if nreq == 3:       # three requests through two batch slots, each with its own length budget
+        sp = [SamplingParams(temperature=sp.temperature, max_new_tokens=new_tokens - 3 * i, ignore_eos=sp.ignore_eos) for i in range(3)]
     torch.manual_seed(777)          # the seed of the reference run: at temperature > 0 both draw from one global stream
-    out, m = eng.generate(prompts, sampling(g, name, kw, new_tokens), use_tqdm=False)
-    assert out[0]["token_ids"] == g[name + "/completion0"].tolist()
-    assert out[1]["token_ids"] == g[name + "/completion1"].tolist()
+    out, m = eng.generate(prompts, sp, use_tqdm=False)
+    for i in range(nreq):
+        assert out[i]["token_ids"] == g[name + f"/completion{i}"].tolist(), f"request {i}"
     if kw.get("speculate") and name != "async_fast":        # (a miss is answered with filler tokens: the reference's are random)
         assert list(m["accepted_suffix_lens_with_recovery"]) == g[name + "/accepted_lens"].tolist()
     if kw.get("draft_async") and name != "async_fast":      # (one lucky random filler token saves the reference a step there)
