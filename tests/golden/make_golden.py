@@ -941,7 +941,10 @@ def gen_ref_engine():
                  # three requests (14 / 11 / 8 new tokens) through two batch slots: the third is admitted, and prefilled on the draft, mid-run
                  ("async_queue", "async", False, False, None, None, False, -1, 0.0, None, None, True, True, (3, 2), 3),
                  ("eagle_queue", "async", False, True, None, None, False, -1, 0.0, None, None, False, True, (3, 2), 3),
-                 ("sync_queue", "sync", False, False, None, None, False, -1, 0.0, None, None, True, True, (3, 2), 3)):
+                 ("sync_queue", "sync", False, False, None, None, False, -1, 0.0, None, None, True, True, (3, 2), 3),
+                 # target at temperature 0.8, draft at 0.5 (draft_temperature): q and p are tempered differently in verify()
+                 ("async_dtemp", "async", False, False, None, None, False, -1, 0.8, None, 0.5, True),
+                 ("sync_dtemp", "sync", False, False, None, None, False, -1, 0.8, None, 0.5, True)):
         with contextlib.redirect_stdout(io.StringIO()):          # the reference prints every step under __debug__
             results.append(scenario(*args))
     torch.tensor = real_tensor
