@@ -865,7 +865,8 @@ def gen_ref_engine():
         plist = prompts + [prompt3] if nreq == 3 else prompts       # three requests through two batch slots: the third is prefilled mid-run
         seqs = [Sequence(p, SamplingParams(temperature=temp, draft_temperature=dtemp, max_new_tokens=new_tokens - 3 * i, ignore_eos=eos < 0))
                 for i, p in enumerate(plist)] if nreq == 3 else \
-               [Sequence(p, SamplingParams(temperature=temp, draft_temperature=dtemp, max_new_tokens=new_tokens, ignore_eos=eos < 0)) for p in prompts]
+               [Sequence(p, SamplingParams(temperature=(temp[i] if isinstance(temp, tuple) else temp), draft_temperature=dtemp,
+                                           max_new_tokens=new_tokens, ignore_eos=eos < 0)) for i, p in enumerate(prompts)]
         for sq in seqs:
             sch.add(sq)
         torch.manual_seed(777)              # temperature > 0: the whole run draws from ONE seeded global stream
@@ -902,7 +903,8 @@ def gen_ref_engine():
         merged[name + "/K_F"] = torch.tensor([K, F])
         merged[name + "/nreq"] = torch.tensor([nreq])
         merged[name + "/fan"], merged[name + "/fan_miss"] = torch.tensor(fan), torch.tensor(fan_miss)
-        merged[name + "/eos"], merged[name + "/temp"] = torch.tensor([eos]), torch.tensor([temp])
+        merged[name + "/eos"] = torch.tensor([eos])
+        merged[name + "/temp"] = torch.tensor(list(temp) if isinstance(temp, tuple) else [temp] * len(seqs))
         merged[name + "/sampler_x"] = torch.tensor([-1.0 if sx is None else sx])
         merged[name + "/jit"] = torch.tensor([1 if jit else 0])
         merged[name + "/draft_temp"] = torch.tensor([-1.0 if dtemp is None else dtemp])
@@ -944,7 +946,10 @@ def gen_ref_engine():
                  ("sync_queue", "sync", False, False, None, None, False, -1, 0.0, None, None, True, True, (3, 2), 3),
                  # target at temperature 0.8, draft at 0.5 (draft_temperature): q and p are tempered differently in verify()
                  ("async_dtemp", "async", False, False, None, None, False, -1, 0.8, None, 0.5, True),
-                 ("sync_dtemp", "sync", False, False, None, None, False, -1, 0.8, None, 0.5, True)):
+                 ("sync_dtemp", "sync", False, False, None, None, False, -1, 0.8, None, 0.5, True),
+                 # a mixed batch: request 0 samples at temperature 0.8, request 1 is greedy
+                 ("async_mixed", "async", False, False, None, None, False, -1, (0.8, 0.0), None, None, True),
+                 ("sync_mixed", "sync", False, False, None, None, False, -1, (0.8, 0.0), None, None, True)):
         with contextlib.redirect_stdout(io.StringIO()):          # the reference prints every step under __debug__
             results.append(scenario(*args))
     torch.tensor = real_tensor

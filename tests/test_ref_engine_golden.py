@@ -23,7 +23,7 @@ def weights(g, prefix):
     return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix) and "cfg" not in k}
 
 
-SCENARIOS = ["ar", "sync", "async_diff", "async_same", "eagle", "async_fanout", "qwen_sync", "qwen_async", "async_eos", "sync_eos", "sync_temp", "ar_temp", "async_temp", "async_same_temp", "async_temp_x", "sync_same", "async_diff_fanout", "async_peaky", "sync_peaky", "async_fast", "eagle_eos", "async_k1f1", "async_k5f3", "eagle_k5f3", "async_queue", "eagle_queue", "sync_queue", "async_dtemp", "sync_dtemp"]
+SCENARIOS = ["ar", "sync", "async_diff", "async_same", "eagle", "async_fanout", "qwen_sync", "qwen_async", "async_eos", "sync_eos", "sync_temp", "ar_temp", "async_temp", "async_same_temp", "async_temp_x", "sync_same", "async_diff_fanout", "async_peaky", "sync_peaky", "async_fast", "eagle_eos", "async_k1f1", "async_k5f3", "eagle_k5f3", "async_queue", "eagle_queue", "sync_queue", "async_dtemp", "sync_dtemp", "async_mixed", "sync_mixed"]
 
 
 def scenario_setup(g, name):
@@ -50,7 +50,7 @@ def scenario_setup(g, name):
                           eagle_taps=int(g["eagle/taps"].numel()))
         else:
             dw, dcfg = weights(g, "diff/d."), cfg_of(g, "diff/d_")
-            if name.endswith("_peaky") or name in ("async_fast", "async_k5f3", "async_queue", "sync_queue", "async_dtemp", "sync_dtemp"):         # the same independent draft, three head rows boosted in both models
+            if name.endswith("_peaky") or name in ("async_fast", "async_k5f3", "async_queue", "sync_queue", "async_dtemp", "sync_dtemp", "async_mixed", "sync_mixed"):         # the same independent draft, three head rows boosted in both models
                 tw["lm_head.weight"], dw["lm_head.weight"] = g["peaky/t.lm_head.weight"], g["peaky/d.lm_head.weight"]
         kw.update(draft="d", draft_hf_config=dcfg, speculate=True, speculate_k=K)
         if not name.startswith("sync") and name != "qwen_sync":
@@ -65,9 +65,11 @@ def scenario_setup(g, name):
 
 
 def sampling(g, name, kw, new_tokens):
+    """One SamplingParams per request (temperatures may differ inside the batch)."""
     dt = float(g[name + "/draft_temp"][0])
-    return SamplingParams(temperature=float(g[name + "/temp"][0]), draft_temperature=None if dt < 0 else dt, max_new_tokens=new_tokens,
-                          ignore_eos=kw["eos"] < 0)
+    nreq = int(g[name + "/nreq"][0])
+    return [SamplingParams(temperature=float(t), draft_temperature=None if dt < 0 else dt, ignore_eos=kw["eos"] < 0,
+                           max_new_tokens=new_tokens - (3 * i if nreq == 3 else 0)) for i, t in enumerate(g[name + "/temp"].tolist())]
 
 
 @pytest.mark.parametrize("name", SCENARIOS)
@@ -77,10 +79,7 @@ def test_engine_matches_the_reference_engine_run(golden, name):
     eng = LLMEngine("t", runner_factory=oracle_runner_factory(weights_target=tw, weights_draft=dw), **kw)
     nreq = int(g[name + "/nreq"][0])
     prompts = [g[f"prompt{i}"].tolist() for i in range(nreq)]
-    sp = sampling(g, name, kw, new_tokens)
-    if nreq == 3:       # three requests through two batch slots, each with its own length budget
-        sp = [SamplingParams(temperature=sp.temperature, draft_temperature=sp.draft_temperature, max_new_tokens=new_tokens - 3 * i,
-                             ignore_eos=sp.ignore_eos) for i in range(3)]
+    sp = sampling(g, name, kw, new_tokens)      # (three requests through two batch slots: each has its own length budget)
     torch.manual_seed(777)          # the seed of the reference run: at temperature > 0 both draw from one global stream
     out, m = eng.generate(prompts, sp, use_tqdm=False)
     for i in range(nreq):
