@@ -738,7 +738,7 @@ def gen_ref_engine():
                                  tie_word_embeddings=False, hidden_act="silu", attention_bias=False, rope_theta=1000000.0, rope_scaling=None)
 
     def scenario(name, mode, same=False, eagle=False, fan=None, fan_miss=None, qwen=False, eos=-1, temp=0.0, sx=None, dtemp=None, peaky=False,
-                 jit=True, geom=(3, 2), nreq=2):
+                 jit=True, geom=(3, 2), nreq=2, max_len=256):
         K, F = geom                          # speculation depth and fan-out of this scenario
         MQ = F * (K + 1)
         Sequence.block_size = bs
@@ -902,6 +902,7 @@ def gen_ref_engine():
         merged["K_F_bs_blocks_new"] = torch.tensor([3, 2, bs, nblocks, new_tokens])
         merged[name + "/K_F"] = torch.tensor([K, F])
         merged[name + "/nreq"] = torch.tensor([nreq])
+        merged[name + "/max_model_len"] = torch.tensor([max_len])
         merged[name + "/fan"], merged[name + "/fan_miss"] = torch.tensor(fan), torch.tensor(fan_miss)
         merged[name + "/eos"] = torch.tensor([eos])
         merged[name + "/temp"] = torch.tensor(list(temp) if isinstance(temp, tuple) else [temp] * len(seqs))

@@ -59,6 +59,7 @@ def scenario_setup(g, name):
         if eagle:
             kw.update(use_eagle=True, eagle_layers=g["eagle/taps"].tolist())
     kw["eos"] = int(g[name + "/eos"][0])
+    kw["max_model_len"] = int(g[name + "/max_model_len"][0])
     if float(g[name + "/sampler_x"][0]) > 0:
         kw["sampler_x"] = float(g[name + "/sampler_x"][0])
     return tw, dw, kw, new_tokens
