@@ -181,6 +181,9 @@ class LLMEngine:
                 return self.step(step)
         t = perf_counter()
         seqs, is_prefill = self.scheduler.schedule()
+        capped = [(s.seq_id, s.completion_token_ids) for s in self.scheduler.pop_capped()]     # stopped at max_model_len
+        if not seqs:            # every runnable sequence was one of those
+            return capped
         n = step.prefill(seqs) if is_prefill else step.decode(seqs)
         dt = perf_counter() - t
         if is_prefill:
@@ -189,7 +192,7 @@ class LLMEngine:
         else:
             METRICS["decode_total_time"] += dt
             METRICS["decode_total_tokens"] += n
-        return [(s.seq_id, s.completion_token_ids) for s in seqs if s.is_finished]
+        return capped + [(s.seq_id, s.completion_token_ids) for s in seqs if s.is_finished]
 
     def is_finished(self) -> bool:
         return self.scheduler.is_finished()

@@ -42,6 +42,7 @@ class Scheduler:
                                                     speculate_k=self.K, max_model_len=self.max_model_len, prefix_cache=pc)
         self.waiting: deque[Sequence] = deque()
         self.running: deque[Sequence] = deque()
+        self.capped: list[Sequence] = []        # finished by schedule() itself: see _length_capped
 
     def is_finished(self) -> bool:
         return not self.waiting and not self.running
@@ -89,6 +90,8 @@ class Scheduler:
         tgt, dft = self.lookaheads()
         while self.running and len(picked) < self.max_num_seqs:
             seq = self.running.popleft()
+            if self._length_capped(seq, tgt, dft):
+                continue
             admitted = True
             while not self._can_append(seq, tgt, dft):
                 if self.running:
@@ -104,6 +107,26 @@ class Scheduler:
                 picked.append(seq)
         self.running.extendleft(reversed(picked))
         return picked, False
+
+    def _length_capped(self, seq: Sequence, tgt: int, dft: int | None) -> bool:
+        """A running sequence whose next step would reserve positions past max_model_len can never be scheduled again, however
+        many blocks are free: it is finished here, at the length it has.  (The reference has no such exit: can_append refuses
+        on the model-length guard (block_manager.py:137-147), the sequence preempts itself, and the step runs an empty batch
+        -- `max() arg is an empty sequence` in prepare_block_tables_from_seqs.)  In speculative modes the cap therefore sits
+        one lookahead (K+1 target positions; K+1+K*MQ_LEN draft positions under async speculation) below max_model_len."""
+        need = max(tgt, dft or 0)
+        if seq.num_tokens + need <= self.max_model_len:
+            return False
+        seq.status = SequenceStatus.FINISHED
+        self.block_manager.deallocate(seq)
+        if self.speculate:
+            self.draft_block_manager.deallocate(seq)
+        self.capped.append(seq)
+        return True
+
+    def pop_capped(self) -> list[Sequence]:
+        out, self.capped = self.capped, []
+        return out
 
     def preempt(self, seq: Sequence) -> None:
         seq.status = SequenceStatus.WAITING

@@ -182,3 +182,32 @@ def test_fully_cached_sequence_still_has_tokens_to_prefill():
     c = Sequence(list(range(8)) + [99])    # one more token: both full blocks may hit, the partial block is computed
     bm.allocate(c)
     assert c.num_cached_tokens == 8
+
+
+def test_generation_stops_at_max_model_len_instead_of_crashing():
+    """A request that runs into max_model_len: the reference's scheduler refuses every further step, the sequence preempts
+    itself and the engine dies on an empty batch.  Here it finishes with what it has -- a prefix of the unconstrained
+    stream; the cap sits one lookahead below max_model_len in the speculative modes."""
+    from oracle.runner import oracle_runner_factory
+    from ssd_amd.engine.llm_engine import LLMEngine
+    from ssd_amd.model_config import ModelConfig
+    from ssd_amd.sampling_params import SamplingParams
+    t = ModelConfig("llama", 64, 2, 4, 2, 32, 128, 256, 1e-5, 5e5, 1024, False)
+    prompts = [[1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11], [3, 4, 5, 6, 7, 8, 9]]
+    sp = SamplingParams(temperature=0, max_new_tokens=200, ignore_eos=True)
+    base = dict(hf_config=t, max_num_seqs=2, max_num_batched_tokens=256, kvcache_block_size=16, num_kvcache_blocks=40,
+                num_draft_kvcache_blocks=40, weights_std=0.1)
+    free, _ = LLMEngine("t", runner_factory=oracle_runner_factory(), max_model_len=256, **base).generate(
+        prompts, SamplingParams(temperature=0, max_new_tokens=60, ignore_eos=True), use_tqdm=False)
+    K, F = 3, 2
+    for mode, lookahead in (("ar", 1), ("sync", K + 1), ("async", K + 1 + K * F * (K + 1))):
+        kw = dict(base, max_model_len=64)
+        if mode != "ar":
+            kw.update(draft="d", draft_hf_config=t, draft_weights_seed=0, speculate=True, speculate_k=K)
+        if mode == "async":
+            kw.update(draft_async=True, async_fan_out=F, jit_speculate=True, inprocess_draft=True)
+        out, _ = LLMEngine("t", runner_factory=oracle_runner_factory(), **kw).generate(prompts, sp, use_tqdm=False)
+        for p, o, f in zip(prompts, out, free):
+            n = len(p) + len(o["token_ids"])
+            assert 64 - lookahead - K <= n <= 64, (mode, n)
+            assert o["token_ids"] == f["token_ids"][:len(o["token_ids"])], mode
