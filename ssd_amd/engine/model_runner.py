@@ -375,10 +375,15 @@ class ModelRunner:
         B = len(seqs)
         if is_prefill and B > self.seq_cap:
             assert not draft_return_logits
-            toks = []
+            toks, acts = [], []
             for i in range(0, B, self.seq_cap):
-                toks.extend(self.run(seqs[i:i + self.seq_cap], True, last_only))
+                part = seqs[i:i + self.seq_cap]
+                toks.extend(self.run(part, True, last_only))
+                if self.model.acts is not None:         # EAGLE-3 taps: the static buffer only holds the last slice
+                    acts.append(self.model.acts[:sum(len(s) - s.num_cached_tokens for s in part)].clone())
+            self._acts_sliced = torch.cat(acts, dim=0) if acts else None
             return toks
+        self._acts_sliced = None
         if is_prefill:
             T, max_q = self._prepare_prefill(seqs)
 
@@ -427,6 +432,10 @@ class ModelRunner:
         """[n, taps * h] tapped activations of the last prefill / verify forward (reference model_runner.py:613-616); a view
         of a static buffer -- callers clone what they keep."""
         assert self.model.acts is not None, "activation taps are only collected under use_eagle"
+        sliced = getattr(self, "_acts_sliced", None)
+        if sliced is not None:              # a prefill batch that was run in slices of seq_cap sequences
+            assert sliced.shape[0] == n
+            return sliced
         return self.model.acts[:n]
 
     def _log_margins(self, rows: int, keys) -> None:
@@ -514,6 +523,7 @@ class ModelRunner:
         (Verifier.verify + verify(), verifier.py:54-153, utils/verify.py:5-48).  One packed D2H copy.
         Returns (new_suffixes, recovery_tokens)."""
         B, K = len(seqs), self.K
+        self._acts_sliced = None
         stochastic = temps_q is not None
         key = ("verify_s" if stochastic else "verify", B)
         if stochastic:
