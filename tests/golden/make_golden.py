@@ -950,7 +950,11 @@ def gen_ref_engine():
                  ("sync_dtemp", "sync", False, False, None, None, False, -1, 0.8, None, 0.5, True),
                  # a mixed batch: request 0 samples at temperature 0.8, request 1 is greedy
                  ("async_mixed", "async", False, False, None, None, False, -1, (0.8, 0.0), None, None, True),
-                 ("sync_mixed", "sync", False, False, None, None, False, -1, (0.8, 0.0), None, None, True)):
+                 ("sync_mixed", "sync", False, False, None, None, False, -1, (0.8, 0.0), None, None, True),
+                 # hits and misses in one run with DIFFERENT hit / miss fan-out lists; the smallest EAGLE tree
+                 ("async_peaky_fanout", "async", False, False, [1, 2, 2, 3], [3, 2, 2, 1], False, -1, 0.0, None, None, True),
+                 ("eagle_k1f1", "async", False, True, None, None, False, -1, 0.0, None, None, False, True, (1, 1)),
+                 ("eagle_fanout", "async", False, True, [1, 2, 2, 3], [3, 2, 2, 1])):
         with contextlib.redirect_stdout(io.StringIO()):          # the reference prints every step under __debug__
             results.append(scenario(*args))
     torch.tensor = real_tensor

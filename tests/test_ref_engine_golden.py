@@ -23,7 +23,7 @@ def weights(g, prefix):
     return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix) and "cfg" not in k}
 
 
-SCENARIOS = ["ar", "sync", "async_diff", "async_same", "eagle", "async_fanout", "qwen_sync", "qwen_async", "async_eos", "sync_eos", "sync_temp", "ar_temp", "async_temp", "async_same_temp", "async_temp_x", "sync_same", "async_diff_fanout", "async_peaky", "sync_peaky", "async_fast", "eagle_eos", "async_k1f1", "async_k5f3", "eagle_k5f3", "async_queue", "eagle_queue", "sync_queue", "async_dtemp", "sync_dtemp", "async_mixed", "sync_mixed"]
+SCENARIOS = ["ar", "sync", "async_diff", "async_same", "eagle", "async_fanout", "qwen_sync", "qwen_async", "async_eos", "sync_eos", "sync_temp", "ar_temp", "async_temp", "async_same_temp", "async_temp_x", "sync_same", "async_diff_fanout", "async_peaky", "sync_peaky", "async_fast", "eagle_eos", "async_k1f1", "async_k5f3", "eagle_k5f3", "async_queue", "eagle_queue", "sync_queue", "async_dtemp", "sync_dtemp", "async_mixed", "sync_mixed", "async_peaky_fanout", "eagle_k1f1", "eagle_fanout"]
 
 
 def scenario_setup(g, name):
@@ -50,7 +50,7 @@ def scenario_setup(g, name):
                           eagle_taps=int(g["eagle/taps"].numel()))
         else:
             dw, dcfg = weights(g, "diff/d."), cfg_of(g, "diff/d_")
-            if name.endswith("_peaky") or name in ("async_fast", "async_k5f3", "async_queue", "sync_queue", "async_dtemp", "sync_dtemp", "async_mixed", "sync_mixed"):         # the same independent draft, three head rows boosted in both models
+            if name.endswith("_peaky") or name in ("async_peaky_fanout","async_fast", "async_k5f3", "async_queue", "sync_queue", "async_dtemp", "sync_dtemp", "async_mixed", "sync_mixed"):         # the same independent draft, three head rows boosted in both models
                 tw["lm_head.weight"], dw["lm_head.weight"] = g["peaky/t.lm_head.weight"], g["peaky/d.lm_head.weight"]
         kw.update(draft="d", draft_hf_config=dcfg, speculate=True, speculate_k=K)
         if not name.startswith("sync") and name != "qwen_sync":
