@@ -112,7 +112,11 @@ class HipDecoder:
         self.taps = sorted(set(taps)) if taps else None
         self.acts = z(T, len(self.taps) * self.h) if self.taps else None
         self.max_splits = 16
-        self._ws_pf = None           # fp32 split-K partials of the prefill GEMM, allocated by the first prefill
+        # fp32 split-K partials of the prefill GEMM (csrc/gemm_pf.hip), sized ONCE for the largest matrix that can take that
+        # path (layer matrices and the LM head): prefill hipGraphs bake this pointer, so it must never be reallocated
+        pf_shapes = [(self.qkv_n, self.h), (self.h, self.qn), (2 * self.I, self.h), (self.h, self.I), (self.V, self.h)]
+        need = max([H.gemm_pf_workspace_bytes(128, n, k) // 4 for n, k in pf_shapes if self._pf_eligible(n, k)], default=0)
+        self._ws_pf = z(need, dtype=torch.float32) if need and max_tokens > 32 else None
         st = min(T, max_split_tokens)
         self.ws_o = z(st * self.nh * self.max_splits * self.hd, dtype=torch.float32)
         self.ws_ml = z(st * self.nh * self.max_splits * 2, dtype=torch.float32)
@@ -181,14 +185,16 @@ class HipDecoder:
     # ---------------------------------------------------------------------------------------------
     PF_MIN_WEIGHT_BYTES = 100 << 20
 
+    @classmethod
+    def _pf_eligible(cls, N: int, K: int) -> bool:
+        return 2 * N * K >= cls.PF_MIN_WEIGHT_BYTES and N % 128 == 0 and K % 128 == 0
+
     def _gemm_chunk(self, xf, K, w, N, y, m, ldy, epi, bias):
         """One <= 128-row chunk.  Prefill-sized chunks of a big matrix go to the LDS-shared / split-K kernel
         (csrc/gemm_pf.hip): measured on MI355X at M = 128, 70B layer GEMMs 611 -> 383 us, 8B gate_up 83 -> 62 us; small
         matrices (<100 MB: too few workgroups without deep K-splits) stay on the skinny kernel."""
-        if m > 32 and 2 * N * K >= self.PF_MIN_WEIGHT_BYTES and N % 128 == 0 and K % 128 == 0:
-            need = H.gemm_pf_workspace_bytes(128, N, K) // 4
-            if self._ws_pf is None or self._ws_pf.numel() < need:
-                self._ws_pf = torch.empty(need, dtype=torch.float32, device=self.device)
+        if m > 32 and self._pf_eligible(N, K):
+            assert self._ws_pf is not None and self._ws_pf.numel() * 4 >= H.gemm_pf_workspace_bytes(128, N, K), (N, K)
             H.gemm_pf(xf, w, y, m, N, K, ldy, self._ws_pf, epilogue=epi, bias=bias)
         else:
             H.gemm(xf, w, y, m, N, K, ldy, epi, bias)

@@ -505,7 +505,14 @@ def gen_draft_rounds(eagle: bool):
     without __init__: no process group, no GPU), eager mode.  Round 1: empty cache -> JIT chain.  Round 2: both requests hit
     (sequence 0 "accepted" everything -> K extend rows under EAGLE; sequence 1 nothing).  Round 3: one hit + one miss ->
     the whole batch is JIT-drafted (draft_runner.py:242-267).  The verification outcomes are CHOSEN (any outcome is a legal
-    request); the target only supplies activations (EAGLE)."""
+    request); the target only supplies activations (EAGLE).
+    Every decision the draft takes here is a rank order among the top logits of a row (chain tokens = rank 1; forks = the
+    top F after excluding the speculated token, async_spec_helpers.py:26-78, i.e. ranks within the top F+2).  The logits are
+    bf16 at magnitude 2-4, so a few of the ~110 decisions of a run are exact ties or one-ulp gaps whatever the seed, and a
+    different fp32 accumulation order may legitimately flip those.  The fixture therefore records, per forward, each row's
+    top-1 / top-2 gap and the smallest gap between consecutive top-(F+2) logits, in ulps of the row's largest logit
+    (`r{n}_jit_gap2`, `r{n}_glue_gapF`, `r{n}_tree_gap2`): the GPU replay (tests/test_reference_replays_gpu.py) accepts a
+    difference only at a decision whose recorded gap is <= 2 ulps, and stops comparing what depends on it."""
     from ssd.engine.draft_runner import DraftRunner
     from ssd.utils.async_helpers.async_spec_helpers import make_glue_decode_input_ids  # noqa: F401 (used by the runner)
     K, F = 2, 2
@@ -546,6 +553,18 @@ def gen_draft_rounds(eagle: bool):
     r.model, r.sampler, r.tokenizer, r.only_prefill_wrapper = dm, Sampler(sampler_x=None, async_fan_out=F), None, shim
     r._reset_tree_cache_tensors()
     r._init_prealloc_buffers()
+    gaps = []                                # one (shape, top-2 gap per row, min top-(F+2) gap per row) per forward, in ulps
+    inner_run_model = r.run_model
+
+    def logged_run_model(*a, **k):
+        res = inner_run_model(*a, **k)
+        lg = res[0] if isinstance(res, tuple) else res
+        top = lg.float().reshape(-1, lg.shape[-1]).topk(F + 2, dim=-1).values
+        ulp = torch.exp2(torch.floor(torch.log2(top[:, 0].abs().clamp_min(1e-30))) - 7)
+        d = top[:, :-1] - top[:, 1:]
+        gaps.append((lg.dim(), lg.reshape(-1, lg.shape[-1]).shape[0], d[:, 0] / ulp, d.min(dim=-1).values / ulp))
+        return res
+    r.run_model = logged_run_model
 
     out = {"d." + k: v.data.clone() for k, v in dm.state_dict().items()}
     out["d_cfg_i"], out["d_cfg_f"] = cfg_fields(dcfg, "llama")
@@ -615,6 +634,7 @@ def gen_draft_rounds(eagle: bool):
             out[f"r{rnd}_rec_acts"], out[f"r{rnd}_ext_counts"] = rec_acts.clone(), ext[0].clone()
             out[f"r{rnd}_ext_acts"], out[f"r{rnd}_ext_ids"] = ext[1].clone(), ext[2].clone()
         out[f"r{rnd}_keys"], out[f"r{rnd}_num_tokens"] = keys.clone(), nt.clone()
+        gaps.clear()
         toks, lgs, glue_ids, hits, acts_out = r.hit_cache_and_respond(keys, B, K, nt, temps, dbt, rec_acts)
         out[f"r{rnd}_hits"], out[f"r{rnd}_tokens"] = hits.to(torch.int64).clone(), toks.clone()
         r._reset_tree_cache_tensors()
@@ -629,6 +649,11 @@ def gen_draft_rounds(eagle: bool):
         out[f"r{rnd}_cache_keys"], out[f"r{rnd}_cache_tokens"] = r.tree_cache_keys.clone(), r.tree_cache_tokens.clone()
         if eagle:
             out[f"r{rnd}_cache_acts"] = r.tree_cache_activations.clone()
+        if not eagle:         # (the EAGLE fixture replays strictly on the MI355X as it is; its glue has a variable row count)
+            jit = [g2 for nd, rows, g2, _ in gaps if nd == 2 and rows == B]
+            out[f"r{rnd}_jit_gap2"] = torch.stack(jit) if jit else torch.zeros(0, B)                       # [forwards, B]
+            out[f"r{rnd}_glue_gapF"] = torch.cat([gf for nd, rows, _, gf in gaps if nd == 3]).view(B, -1)   # [B, K+1]
+            out[f"r{rnd}_tree_gap2"] = torch.stack([g2 for nd, rows, g2, _ in gaps if nd == 2 and rows == B * MQ])   # [K, B*MQ]
         # ---- the outcome of this round's verification, chosen so that the next request exercises hits / extends / a mix ----
         forks = tda["input_ids"].view(B, MQ)
         specs = [[rec[b]] + toks[b].tolist() for b in range(B)]
@@ -1290,8 +1315,9 @@ if __name__ == "__main__":
         gen_eagle_loader()
     if "refengine" in which:
         gen_ref_engine()
-    if "rounds" in which:
+    if "rounds" in which or "rounds_llama" in which:
         gen_draft_rounds(False)
+    if "rounds" in which or "rounds_eagle" in which:
         gen_draft_rounds(True)
     if "engine" in which:
         gen_engine()
