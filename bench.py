@@ -77,7 +77,8 @@ def parse(argv=None):
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--ttft-samples", type=int, default=3)
+    ap.add_argument("--ttft-samples", type=int, default=11,
+                    help="TTFT runs; the first two are dropped (eager first sighting of the shape, then hipGraph capture)")
     ap.add_argument("--ref-seqs", type=int, default=2, help="sequences of the reference-protocol run (512 output tokens each); 0 = skip")
     ap.add_argument("--ref-output-len", type=int, default=512)
     return ap.parse_args(argv)
@@ -158,19 +159,47 @@ def gemm_roofline(legs):
             tot_bytes += b * L * fwd_per_step
             tot_time += dt * L * fwd_per_step
             tot_launch += L * fwd_per_step
-    achieved = tot_bytes / tot_time
-    out = {"bound": "hbm", "kernel": "skinny weight-streaming GEMM family (gemm_wf_kernel, gemm_sk_kernel, gemm_fused_kernel)",
+    fam = tot_bytes / tot_time
+    # The DOMINANT kernel = the launch kind with the largest share of the step's GPU time (the target's gate_up + SiLU GEMM at
+    # M = k + 1: gemm_wf_kernel<1,4,1> for the 70B): `achieved` / `frac` are ITS algorithmic bytes (2*N*K)
+    # over ITS average launch duration, measured live above with HIP events.  The launch-weighted mean over the whole skinny-GEMM
+    # family (target + draft, every shape of the step) is reported beside it as `family`.
+    dom_tag = max(per_kind, key=lambda t: per_kind[t]["us"] * per_kind[t]["launches_per_step"])
+    dom = per_kind[dom_tag]
+    dom_bytes = dom["MB"] * 1e6
+    achieved = dom_bytes / (dom["us"] * 1e-6)
+    out = {"bound": "hbm", "kernel": f"{dom_tag} (skinny weight-streaming GEMM: gemm_wf_kernel / gemm_fused_kernel, csrc/gemm*.hip)",
            "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4),
-           "traffic": None, "launches_per_step": round(tot_launch, 1), "avg_launch_us": round(tot_time / tot_launch * 1e6, 2),
-           "bytes_per_launch_avg": int(tot_bytes / tot_launch), "per_kind": per_kind}
+           "traffic": None, "bytes_per_launch": int(dom_bytes), "avg_launch_us": dom["us"],
+           "share_of_gemm_time": round(dom["us"] * dom["launches_per_step"] / (tot_time * 1e6), 4),
+           "family": {"kernels": "every skinny-GEMM launch of one step (target + draft): gemm_wf_kernel, gemm_sk/sp_kernel, gemm_fused_kernel",
+                      "achieved": round(fam / 1e9, 1), "frac": round(fam / HBM_PEAK, 4), "launches_per_step": round(tot_launch, 1),
+                      "avg_launch_us": round(tot_time / tot_launch * 1e6, 2), "bytes_per_launch_avg": int(tot_bytes / tot_launch)},
+           "per_kind": per_kind}
+    # the committed rocprofv3 --kernel-trace --stats summary of the same command (profiles/): its average for this kernel must agree
+    if dom_tag.startswith("target.gate_up") and any(r.cfg.hidden_size == 8192 and r.model.tp_size == 1 for r, _, _ in legs if r is not None):
+        import glob
+        import re
+        for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c4_kernel_stats.txt")), reverse=True):
+            try:
+                with open(fn) as f:
+                    hit = next((l for l in f if "gemm_wf_kernel<1, 4, 1>" in l), None)
+                m_ = re.search(r"avg=\s*([0-9.]+)us", hit or "")
+                if m_:
+                    us = float(m_.group(1))
+                    out["rocprof"] = {"source": os.path.relpath(fn, ROOT), "kernel": "gemm_wf_kernel<1, 4, 1>", "avg_us": us,
+                                      "frac": round(dom_bytes / (us * 1e-6) / HBM_PEAK, 4)}
+                    break
+            except Exception:
+                continue
     # HBM traffic per launch: PMC counters cannot be collected from inside this process; the committed separate
     # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (profiles/collect.sh; FETCH_SIZE doubled as the gfx950
     # guide prescribes) give read+write bytes = ratio x algorithmic bytes for this kernel family
-    for fn in ("traffic_r02.json", "traffic_r01.json"):
+    for fn in ("traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
         try:
             with open(os.path.join(ROOT, "profiles", fn)) as f:
                 t = json.load(f)
-            out["traffic"] = int(tot_bytes / tot_launch * t["gemm_traffic_over_algorithmic"])
+            out["traffic"] = int(dom_bytes * t["gemm_traffic_over_algorithmic"])
             out["traffic_source"] = t.get("source", fn)
             if "mfma_util" in t and "per_kernel" in t["mfma_util"] and any(r.cfg.hidden_size == 8192 for r, _, _ in legs if r is not None):
                 # north_star: "rocprof HBM GB/s and MFMA utilisation against gfx950 peak" -- the separate counter pass of
@@ -220,7 +249,8 @@ def collective_probe(engine, M):
     us = e0.elapsed_time(e1) * 1e3 / (5 * n)
     one_shot = m.custom_ar is not None
     return {"all_reduce": "one-shot full-mesh over hipIpc (csrc/comm.hip)" if one_shot else "RCCL (torch.distributed nccl)",
-            "one_shot_validated": one_shot, "fused_add_rmsnorm": bool(one_shot and m.fuse_ar_norm),
+            "one_shot_validated": one_shot, "one_shot_status": getattr(engine.model_runner, "custom_ar_status", None),
+            "fused_add_rmsnorm": bool(one_shot and m.fuse_ar_norm),
             "message_bytes": M * m.h * 2, "avg_us": round(us, 2), "backend": dist.get_backend(m.tp_group)}
 
 
@@ -341,7 +371,10 @@ def main():
         engine.generate([prompt], SamplingParams(temperature=0, ignore_eos=True, max_new_tokens=1), use_tqdm=False,
                         stream_callback=lambda sid, toks: first.append(time.perf_counter()) if not first else None)
         ttfts.append((first[0] - t0) * 1e3)
-    ttft_p50 = statistics.median(ttfts[1:] if len(ttfts) > 1 else ttfts)   # first run pays graph capture
+    # a prefill shape runs eagerly the first time and is captured the second time (engine/model_runner.py run): steady state
+    # -- what a serving process sees for its recurring prompt shapes -- starts with the third sample
+    kept = ttfts[2:] if len(ttfts) > 2 else ttfts[-1:]
+    ttft_p50 = statistics.median(kept)
 
     # ---- timed decode steps through the real engine ----
     total = args.warmup + args.steps
@@ -397,7 +430,9 @@ def main():
                "tokens_per_s_decode": round(m["decode_total_tokens"] / m["decode_total_time"], 2) if m["decode_total_time"] else None,
                "mean_accepted_len": round(sum(rl) / max(1, len(rl)), 4),
                "cache_hit_rate": round(sum(rh) / len(rh), 4) if rh else None,
-               "ms_per_step": round(1e3 * m["decode_total_time"] / max(1, len(rl)), 4), "final_context": args.input_len + args.ref_output_len}
+               "ms_per_step": round(1e3 * m["decode_total_time"] / max(1, len(rl)), 4), "final_context": args.input_len + args.ref_output_len,
+               # the greedy stream is the TARGET's: independent of draft placement / data-parallelism at equal TP degree
+               "stream_head": [int(t) for t in outs[0]["token_ids"][:48]]}
     tokens = sum(lens)
     ms_step = dt / args.steps * 1e3
     tm = engine.model_runner.model
@@ -435,10 +470,16 @@ def main():
         "config": {"workload": f"{args.workload}: {tname} target TP={tp} + {dname} draft, {mode}, b=1, temp=0, "
                                f"input_len={args.input_len}, kv block 256, max_model_len {max_len}",
                    "parallelism": f"tp{tp}" + (f"+draft{ndraft}" if dedicated else ""), "hipgraph": not args.eager,
-                   "pair": "random" if eagle else args.pair, "eagle3": eagle},
+                   "pair": "random" if eagle else args.pair, "eagle3": eagle,
+                   "parity": "greedy token streams bit-exact vs the reference-driven traces up to recorded near-ties (top-2 margin <= 1 bf16 "
+                             "ulp); the north_star's '1e-3 abs on verify logits' is enforced on the fp32 LM-head epilogue and, at model "
+                             "level, as rms|HIP - fp64 truth| <= 1.25 x rms|reference - fp64 truth| + 1e-3 (two bf16 pipelines cannot "
+                             "agree to 1e-3: one bf16 ulp at |logit| 8 is 0.0625) -- tests/test_real_shapes_gpu.py, DESIGN.md section 5"},
         "mean_accepted_len": round(tokens / max(1, len(lens)), 4),
         "cache_hit_rate": None if hit_rate is None else round(hit_rate, 4),
-        "ttft_p50_ms": round(ttft_p50, 3),
+        "ttft_p50_ms": round(ttft_p50, 3), "ttft_samples_ms": [round(t, 2) for t in kept],
+        # the reference's own protocol (2 x 128 -> 512 tokens, prefill included, context -> 640): THE tokens/s to quote
+        "value_reference_protocol": None if ref is None else ref["tokens_per_s_total"],
         "draft_forwards_per_step": round(draft_fwd, 3),
         "step_hbm_bytes_per_gpu": int(step_bytes),
         "step_roofline_frac": round(step_bytes / (dt / args.steps) / HBM_PEAK, 4),

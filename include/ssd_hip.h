@@ -151,6 +151,30 @@ int ssd_attn_paged(const void* q_rows, const void* k_cache, const void* v_cache,
                    int tree_mq, int tree_step, int tree_F, const int32_t* tree_jidx, int splits, int flags,
                    void* ws_o, void* ws_ml, void* out_rows, void* out_frag, void* stream);
 
+/* LM head on the greedy path: F.linear + logits.argmax(-1) -- ssd/layers/embed_head.py:88-116 followed by
+ * ssd/layers/sampler.py:15-20 / ssd/utils/verify.py:34.  ssd_gemm_wf_argmax writes the bf16 logits rows like ssd_gemm_wf
+ * (M <= 32) AND, per workgroup, the (max value, lowest index) of each token row over the features that workgroup produced
+ * (compared on the bf16-rounded logits): part_val / part_idx [m * part_stride + p], p < ssd_gemm_wf_argmax_parts(M, N, K)
+ * (a host-side query; returns the count, or a negative error).  ssd_argmax_parts* finish the argmax from those candidates
+ * (larger value, then lower index == argmax over the stored logits) and, in the same launch, do what the loop does with
+ * the tokens next:
+ *   ssd_argmax_parts          out / out2 / out3[row * out3_stride] (any may be NULL) = idx + idx_offset; out_val (optional)
+ *                             = the row maximum (vocab-parallel merge input, see ssd_argmax_merge)
+ *   ssd_argmax_parts_verify   + ssd_verify_greedy (K + 1 <= 16 rows per sequence; preds optional [B*(K+1)])
+ *   ssd_argmax_parts_advance  + ssd_draft_advance */
+int ssd_gemm_wf_argmax_parts(int M, int N, int K);
+int ssd_gemm_wf_argmax(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K, int ldy,
+                       float* part_val, int32_t* part_idx, int part_stride, void* stream);
+int ssd_argmax_parts(const float* part_val, const int32_t* part_idx, int nparts, long part_stride, int T, long idx_offset,
+                     int64_t* out, int64_t* out2, int64_t* out3, long out3_stride, float* out_val, void* stream);
+int ssd_argmax_parts_verify(const float* part_val, const int32_t* part_idx, int nparts, long part_stride,
+                            const int64_t* speculations, int B, int K, int64_t* preds, int32_t* accept_len,
+                            int64_t* recovery, int64_t* packed, void* stream);
+int ssd_argmax_parts_advance(const float* part_val, const int32_t* part_idx, int nparts, long part_stride, int64_t* next,
+                             int64_t* input_ids, int64_t* positions, int32_t* slots, int32_t* context_lens,
+                             const int32_t* block_tables, int max_blocks, int block_size, int64_t* spec, int K,
+                             int32_t* step, int B, void* stream);
+
 /* Sampler.forward at temperature 0 -- ssd/layers/sampler.py:15-20; verify.py:34.  out2 optional copy. */
 int ssd_argmax_rows(const void* logits_rows, long ld, int T, int V, int64_t* out, int64_t* out2, void* stream);
 /* Vocab-parallel form of the same argmax (ParallelLMHead gather + cat, ssd/layers/embed_head.py:88-92, followed by

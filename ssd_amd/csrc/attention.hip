@@ -53,12 +53,15 @@ __global__ void __launch_bounds__(512) attn_kernel(const AttnParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int W = blockDim.x >> 6;
   bf16_t* vlds = reinterpret_cast<bf16_t*>(smem + (size_t)wave * REGION);
-  const int b = blockIdx.y / p.nkv, h = blockIdx.y % p.nkv;
+  // grid = (B * nkv, row-tile groups, key splits): the (sequence, kv head) index is the FASTEST grid dimension, so with 8 kv
+  // heads every workgroup of one kv head -- all the row tiles of a tree step / a prefill, all key splits -- is dispatched to the
+  // same XCD (workgroup id % 8) and shares that head's K/V pages in ONE L2 instead of fetching them into eight
+  const int b = blockIdx.x / p.nkv, h = blockIdx.x % p.nkv;
   const int G = p.nh / p.nkv;
   const int q0 = p.cu_q ? p.cu_q[b] : b * p.q_per_seq;
   const int Tq = p.cu_q ? (p.cu_q[b + 1] - q0) : p.q_per_seq;
   const int rows = Tq * G;
-  const int tile_base = blockIdx.x * RT;
+  const int tile_base = blockIdx.y * RT;
   if (tile_base * 16 >= rows) return;   // block-uniform
   const int ctx = p.context_lens[b];
   const int32_t* bt = p.block_tables + (size_t)b * p.max_blocks;
@@ -417,7 +420,7 @@ static int attn_launch(const AttnParams& p, int B, int T, int max_q, int waves, 
   // (the 24-branch tree step has 6 row tiles per kv head: one tile per workgroup measured 10.5 -> 7.7 us at ctx 150 and
   // 19.6 -> 12.6 us at ctx 640 on the 1B draft, profiles/r02_draft_probe.txt)
   const int rt = (row_tiles > 8 && !force_rt1) ? 2 : 1;
-  dim3 grid((row_tiles + rt - 1) / rt, B * p.nkv, p.splits);
+  dim3 grid(B * p.nkv, (row_tiles + rt - 1) / rt, p.splits);
   // one key tile in flight per wave (KT = 1): measured on MI355X, KT = 2/4 buy nothing -- with 8 waves per workgroup
   // the scan is bound by the handful of CUs it occupies, not by a single wave's load latency
   const int rc = rt == 2 ? attn_launch_rt<HD, 2, 1>(p, grid, waves, st) : attn_launch_rt<HD, 1, 1>(p, grid, waves, st);

@@ -13,7 +13,17 @@
 //  * Weight loads are non-temporal (each byte is read exactly once per forward).
 #include "common.h"
 
-enum { EPI_ROWS = 0, EPI_SILU_FRAG = 1, EPI_ROWS_F32 = 2 };
+enum { EPI_ROWS = 0, EPI_SILU_FRAG = 1, EPI_ROWS_F32 = 2, EPI_ROWS_ARGMAX = 3 };
+
+// EPI_ROWS_ARGMAX (the LM head on the greedy path): bf16 rows as EPI_ROWS, plus every workgroup's own (max value, lowest
+// index) of each token row over the features it produced -- compared on the bf16-ROUNDED values, i.e. exactly what an
+// argmax over the stored logits sees -- written to part_val / part_idx [m * part_stride + blockIdx.x].  ssd_argmax_parts*
+// (sample.hip) finishes the argmax from these few thousand candidates instead of re-reading M x V logits from one
+// workgroup per row (13 us for one 128K-token row: a single CU's load bandwidth).
+struct ArgPart { float v; int i; };
+__device__ __forceinline__ ArgPart arg_better(ArgPart a, ArgPart b) {
+  return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
 
 extern "C" int ssd_gemm_splitk(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K, int ldy,
                                int splits, int waves, void* workspace, void* counters, void* stream);
@@ -27,7 +37,8 @@ struct Stage {
 template <int MT, int NT, int EPI>
 __global__ void __launch_bounds__(1024)
 gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
-               const bf16_t* __restrict__ bias, void* __restrict__ Yv, int M, int N, int K, int ldy, int tpw) {
+               const bf16_t* __restrict__ bias, void* __restrict__ Yv, int M, int N, int K, int ldy, int tpw,
+               float* __restrict__ part_val, int* __restrict__ part_idx, int part_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -73,6 +84,9 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
     }
   };
   if (t_begin < t_end && kt0 < kmain) load(cur, kt0);
+  ArgPart run[MT];          // EPI_ROWS_ARGMAX: this wave's best candidate per token row so far (identical in the 4 lanes of a row)
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) run[mt] = ArgPart{-INFINITY, 0x7fffffff};
 
   for (int tile = t_begin; tile < t_end; ++tile) {
   const int tile0 = tile * NT;
@@ -178,9 +192,38 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
           *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(Yv) + (size_t)m * ldy + n) = v;
         }
       }
+      if (EPI == EPI_ROWS_ARGMAX) {
+        ArgPart c = {-INFINITY, 0x7fffffff};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {              // ascending n: a strict > keeps the lowest index of equal values
+          const float v = round_bf(s[r]);
+          if (v > c.v) c = ArgPart{v, n + r};
+        }
+        c = arg_better(c, ArgPart{__shfl_xor(c.v, 16, 64), __shfl_xor(c.i, 16, 64)});
+        c = arg_better(c, ArgPart{__shfl_xor(c.v, 32, 64), __shfl_xor(c.i, 32, 64)});
+#pragma unroll
+        for (int q = 0; q < MT; ++q)
+          if (q == mt) run[q] = arg_better(run[q], c);
+      }
     }
   }
   __syncthreads();   // the combine area is reused by the next tile
+  }
+  if (EPI == EPI_ROWS_ARGMAX) {
+    // per-wave candidates -> LDS -> one (value, index) per token row and workgroup
+    ArgPart* lb = reinterpret_cast<ArgPart*>(smem);      // [nw][MT*16]
+    if (lane < 16) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) lb[(wave * MT + mt) * 16 + lane] = run[mt];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < MT * 16; t += blockDim.x) {
+      if (t >= M) break;
+      ArgPart b = lb[t];
+      for (int w = 1; w < nw; ++w) b = arg_better(b, lb[w * MT * 16 + t]);
+      part_val[(size_t)t * part_stride + blockIdx.x] = b.v;
+      part_idx[(size_t)t * part_stride + blockIdx.x] = b.i;
+    }
   }
 }
 
@@ -190,10 +233,11 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
 // ---------------------------------------------------------------------------------------------
 template <int MT, int NT, int EPI>
 static int launch_t(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int ldy,
-                    int waves, int tpw, hipStream_t st) {
+                    int waves, int tpw, hipStream_t st, float* part_val = nullptr, int* part_idx = nullptr, int part_stride = 0) {
   const int ntiles = (N / 16) / NT;
   if (tpw < 1) tpw = 1;
   const int blocks = (ntiles + tpw - 1) / tpw;
+  if (EPI == EPI_ROWS_ARGMAX && (!part_val || !part_idx || part_stride < blocks)) return SSD_ERR_ARG;
   const size_t lds = (size_t)waves * NT * MT * 64 * sizeof(f32x4_t);
   auto kern = gemm_wf_kernel<MT, NT, EPI>;
   if (lds > 64 * 1024) {
@@ -201,7 +245,7 @@ static int launch_t(const void* x, const void* w, const void* bias, void* y, int
       return SSD_ERR_LAUNCH;
   }
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, st, (const u32x4_t*)w, (const u32x4_t*)x,
-                     (const bf16_t*)bias, y, M, N, K, ldy, tpw);
+                     (const bf16_t*)bias, y, M, N, K, ldy, tpw, part_val, part_idx, part_stride);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
@@ -275,4 +319,53 @@ extern "C" int ssd_gemm_wf(const void* x_frag, const void* w_frag, const void* b
   if (mt >= 4 && waves > 8) waves = 8;  // LDS for the combine: waves*nt*mt KiB
   if (mt >= 8 && waves > 4) waves = 4;
   return ssd_gemm_wf_cfg(x_frag, w_frag, bias, y, M, N, K, ldy, epilogue, nt, waves, stream);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LM head on the greedy path: logits rows + per-workgroup argmax candidates in one launch (EPI_ROWS_ARGMAX above).
+// The decomposition is the default one of ssd_gemm_wf for (M, N, K); ssd_gemm_wf_argmax_parts returns how many candidates
+// per token row it writes (= workgroups), so the caller can size part_val / part_idx [M][part_stride >= that].
+// M <= 32 (decode / verify / tree-step rows); replaces F.linear + logits.argmax(-1) (reference ssd/layers/embed_head.py:
+// 88-116 + ssd/layers/sampler.py:15-20 / ssd/utils/verify.py:34).
+// ---------------------------------------------------------------------------------------------------------------------
+static void argmax_head_cfg(int M, int N, int K, int* nt, int* waves, int* tpw) {
+  const int groups = N / 16, KT = K / 32;
+  if (M <= 16) {
+    ssd_pick_skinny_cfg(groups, KT, false, nt, waves, tpw);
+    return;
+  }
+  // two token tiles: the generic choice of ssd_gemm_wf
+  int n = (groups >= 2048 && groups % 2 == 0) ? 2 : 1;
+  int w = 16;
+  while (w > 1 && KT / w < 4) w >>= 1;
+  const int blocks = groups / n;
+  if (blocks >= 1024 && w > 8) w = 8;
+  if (blocks >= 512 && blocks < 2048 && w > 4 && KT / 4 >= 4) w = 4;
+  *nt = n; *waves = w; *tpw = 1;
+}
+
+extern "C" int ssd_gemm_wf_argmax_parts(int M, int N, int K) {
+  if (M <= 0 || M > 32 || (N & 15) || (K & 31) || N <= 0 || K <= 0) return SSD_ERR_SHAPE;
+  int nt, waves, tpw;
+  argmax_head_cfg(M, N, K, &nt, &waves, &tpw);
+  const int ntiles = (N / 16) / nt;
+  return (ntiles + tpw - 1) / tpw;
+}
+
+extern "C" int ssd_gemm_wf_argmax(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K,
+                                  int ldy, float* part_val, int32_t* part_idx, int part_stride, void* stream) {
+  if (M <= 0 || M > 32 || (N & 15) || (K & 31) || N <= 0 || K <= 0) return SSD_ERR_SHAPE;
+  if (!part_val || !part_idx) return SSD_ERR_ARG;
+  int nt, waves, tpw;
+  argmax_head_cfg(M, N, K, &nt, &waves, &tpw);
+  if (((N / 16) % nt) != 0) return SSD_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (M <= 16) {
+    if (nt == 1) return launch_t<1, 1, EPI_ROWS_ARGMAX>(x_frag, w_frag, bias, y, M, N, K, ldy, waves, tpw, st, part_val, part_idx, part_stride);
+    if (nt == 2) return launch_t<1, 2, EPI_ROWS_ARGMAX>(x_frag, w_frag, bias, y, M, N, K, ldy, waves, tpw, st, part_val, part_idx, part_stride);
+    return launch_t<1, 4, EPI_ROWS_ARGMAX>(x_frag, w_frag, bias, y, M, N, K, ldy, waves, tpw, st, part_val, part_idx, part_stride);
+  }
+  if (nt == 1) return launch_t<2, 1, EPI_ROWS_ARGMAX>(x_frag, w_frag, bias, y, M, N, K, ldy, waves, tpw, st, part_val, part_idx, part_stride);
+  return launch_t<2, 2, EPI_ROWS_ARGMAX>(x_frag, w_frag, bias, y, M, N, K, ldy, waves, tpw, st, part_val, part_idx, part_stride);
 }

@@ -173,3 +173,119 @@ extern "C" int ssd_fork_topf(const void* logits, long ld, int V, const int64_t* 
                      (const bf16_t*)logits, ld, V, returned_tokens, counts, offsets, K, mq, out);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Argmax from the LM-head GEMM's per-workgroup candidates (gemm.hip EPI_ROWS_ARGMAX: part_val / part_idx
+// [row * part_stride + p], p < nparts) -- and, in the same launch, what the loop does with the token next:
+//   plain    out[row] (+ out2[row], + out3[row * out3_stride]: the tree step's next input ids and its [T][K] token table)
+//   verify   ssd_verify_greedy's accept / recovery / packed row of each sequence (reference ssd/utils/verify.py:28-48)
+//   advance  ssd_draft_advance's "append token, bump position, recompute slot" of the chained draft forwards
+// One wave per token row; (max value, lowest index) -- identical to an argmax over the stored bf16 logits.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ ArgBest parts_row_argmax(const float* __restrict__ pv, const int* __restrict__ pi, int nparts, int lane) {
+  ArgBest best = {-INFINITY, 0x7fffffff};
+  for (int p = lane; p < nparts; p += 64) best = better(best, ArgBest{pv[p], pi[p]});
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = better(best, ArgBest{__shfl_xor(best.v, o, 64), __shfl_xor(best.i, o, 64)});
+  if (best.i == 0x7fffffff) best.i = 0;     // nothing comparable in the row (all NaN / -inf): never emit the sentinel
+  return best;
+}
+
+__global__ void __launch_bounds__(256)
+argmax_parts_kernel(const float* __restrict__ part_val, const int* __restrict__ part_idx, int nparts, long part_stride, int T,
+                    long idx_offset, int64_t* __restrict__ out, int64_t* __restrict__ out2, int64_t* __restrict__ out3,
+                    long out3_stride, float* __restrict__ out_val) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= T) return;
+  const ArgBest r = parts_row_argmax(part_val + (size_t)row * part_stride, part_idx + (size_t)row * part_stride, nparts, lane);
+  if (lane == 0) {
+    const int64_t tok = (int64_t)r.i + idx_offset;
+    if (out) out[row] = tok;
+    if (out2) out2[row] = tok;
+    if (out3) out3[(size_t)row * out3_stride] = tok;
+    if (out_val) out_val[row] = r.v;
+  }
+}
+
+extern "C" int ssd_argmax_parts(const float* part_val, const int32_t* part_idx, int nparts, long part_stride, int T, long idx_offset,
+                                int64_t* out, int64_t* out2, int64_t* out3, long out3_stride, float* out_val, void* stream) {
+  if (T <= 0 || nparts <= 0 || part_stride < nparts || !part_val || !part_idx) return SSD_ERR_SHAPE;
+  hipLaunchKernelGGL(argmax_parts_kernel, dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, part_val, part_idx, nparts,
+                     part_stride, T, idx_offset, out, out2, out3, out3_stride, out_val);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
+// one workgroup per sequence, one wave per verified row (K + 1 <= 16)
+__global__ void __launch_bounds__(1024)
+argmax_parts_verify_kernel(const float* __restrict__ part_val, const int* __restrict__ part_idx, int nparts, long part_stride,
+                           const int64_t* __restrict__ spec, int K, int64_t* __restrict__ preds, int32_t* __restrict__ accept_len,
+                           int64_t* __restrict__ recovery, int64_t* __restrict__ packed) {
+  __shared__ int64_t sp[16];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = b * (K + 1) + w;
+  const ArgBest r = parts_row_argmax(part_val + (size_t)row * part_stride, part_idx + (size_t)row * part_stride, nparts, lane);
+  if (lane == 0) { sp[w] = r.i; if (preds) preds[row] = r.i; }
+  __syncthreads();
+  if (w != 0) return;
+  bool mismatch = false;
+  if (lane < K) mismatch = spec[(size_t)b * (K + 1) + lane + 1] != sp[lane];
+  const unsigned long long mask = __ballot(mismatch);
+  const int n = mask ? (int)__builtin_ctzll(mask) : K;
+  if (lane == 0) {
+    accept_len[b] = n;
+    recovery[b] = sp[n];
+  }
+  if (packed) {
+    int64_t* prow = packed + (size_t)b * (K + 3);
+    if (lane == 0) { prow[0] = n; prow[1] = sp[n]; }
+    if (lane <= K) prow[2 + lane] = spec[(size_t)b * (K + 1) + lane];
+  }
+}
+
+extern "C" int ssd_argmax_parts_verify(const float* part_val, const int32_t* part_idx, int nparts, long part_stride,
+                                       const int64_t* speculations, int B, int K, int64_t* preds, int32_t* accept_len,
+                                       int64_t* recovery, int64_t* packed, void* stream) {
+  if (B <= 0 || K < 0 || K > 15 || nparts <= 0 || part_stride < nparts || !part_val || !part_idx) return SSD_ERR_SHAPE;
+  hipLaunchKernelGGL(argmax_parts_verify_kernel, dim3(B), dim3(64 * (K + 1)), 0, (hipStream_t)stream, part_val, part_idx, nparts,
+                     part_stride, speculations, K, preds, accept_len, recovery, packed);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
+// ONE workgroup (the step counter is shared by all sequences); waves walk the B rows
+__global__ void __launch_bounds__(1024)
+argmax_parts_advance_kernel(const float* __restrict__ part_val, const int* __restrict__ part_idx, int nparts, long part_stride,
+                            int64_t* __restrict__ next, int64_t* __restrict__ input_ids, int64_t* __restrict__ positions,
+                            int32_t* __restrict__ slots, int32_t* __restrict__ ctx, const int32_t* __restrict__ block_tables,
+                            int max_blocks, int bs, int64_t* __restrict__ spec, int K, int32_t* step, int B) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int s = *step;
+  __syncthreads();
+  for (int b = w; b < B; b += nw) {
+    const ArgBest r = parts_row_argmax(part_val + (size_t)b * part_stride, part_idx + (size_t)b * part_stride, nparts, lane);
+    if (lane == 0) {
+      const int64_t tok = r.i;
+      next[b] = tok;
+      if (s + 1 <= K) spec[(size_t)b * (K + 1) + s + 1] = tok;
+      input_ids[b] = tok;
+      const long pos = positions[b] + 1;
+      positions[b] = pos;
+      ctx[b] += 1;
+      const int blk = block_tables[(size_t)b * max_blocks + (int)(pos / bs)];
+      slots[b] = blk >= 0 ? blk * bs + (int)(pos % bs) : -1;
+    }
+  }
+  if (threadIdx.x == 0) *step = s + 1;
+}
+
+extern "C" int ssd_argmax_parts_advance(const float* part_val, const int32_t* part_idx, int nparts, long part_stride, int64_t* next,
+                                        int64_t* input_ids, int64_t* positions, int32_t* slots, int32_t* context_lens,
+                                        const int32_t* block_tables, int max_blocks, int block_size, int64_t* spec, int K,
+                                        int32_t* step, int B, void* stream) {
+  if (B <= 0 || B > 1024 || nparts <= 0 || part_stride < nparts || !part_val || !part_idx) return SSD_ERR_SHAPE;
+  const int waves = B < 16 ? B : 16;
+  hipLaunchKernelGGL(argmax_parts_advance_kernel, dim3(1), dim3(64 * waves), 0, (hipStream_t)stream, part_val, part_idx, nparts,
+                     part_stride, next, input_ids, positions, slots, context_lens, block_tables, max_blocks, block_size, spec, K,
+                     step, B);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}

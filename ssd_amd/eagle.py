@@ -26,6 +26,7 @@ class HipEagleDraft(HipDecoder):
         assert kw.get("tp_size", 1) == 1, "the draft model is not tensor-parallel"
         super().__init__(cfg, **kw)
         self.use_parts = False
+        self.argmax_fused = False        # the draft-vocabulary head is scattered into target-vocabulary columns: argmax reads the logits
         dev, T, h = self.device, self.max_tokens, self.h
         self.A = cfg.eagle_taps * cfg.d_model_target        # width of the target activations fc projects
         self.Vd = cfg.draft_vocab_size

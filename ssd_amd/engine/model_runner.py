@@ -124,11 +124,15 @@ class ModelRunner:
         peer-access path can then only kill a helper, never this process.  Otherwise RCCL carries all collectives."""
         import os
         m = self.model
+        # why the one-shot collective is (not) in use: reported by bench.py's `collective` object -- a fall-back to RCCL must
+        # be visible in the numbers' provenance, never silent
+        self.custom_ar_status = "not applicable (no tensor-parallel collectives on this runner)"
         if not m.use_coll or self.is_draft:
             return
         if want is None:
             want = os.environ.get("SSD_CUSTOM_AR", "1") != "0"
         if not want:
+            self.custom_ar_status = "disabled (SSD_CUSTOM_AR=0 / custom_ar=False): RCCL"
             return
         from ssd_amd.utils import custom_ar as CA
         world = dist.get_world_size(self.tp_group)
@@ -139,10 +143,14 @@ class ModelRunner:
                 flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.tp_group)
                 if int(flag.item()) != 1:
+                    self.custom_ar_status = ("self-validation FAILED on " + ("this rank" if not ok else "another rank")
+                                             + ": fell back to RCCL")
                     return
             m.custom_ar = CA.OneShotAllReduce(self.tp_group, self.device)
-        except Exception:
+            self.custom_ar_status = "validated on every rank" if world > 1 else "single rank (nothing to validate)"
+        except Exception as e:
             m.custom_ar = None
+            self.custom_ar_status = f"set-up raised {type(e).__name__}: {e}: fell back to RCCL"
 
     def _ensure_stochastic(self) -> None:
         """Buffers of the temperature > 0 path (allocated on first use: the benchmark configs are greedy)."""
@@ -311,6 +319,11 @@ class ModelRunner:
             else:
                 H.sample_rows(lg, V, B, V, self.d_temps, 1, self.d_rng, 1, self.d_next)
             H.rng_advance(self.d_rng)
+        elif chain and self.model.has_argmax_parts(B):
+            # argmax from the LM head's candidates + the chain advance: one launch
+            self.model.argmax_advance(B, self.d_next, self.d_ids, self.d_pos, self.d_slots, self.d_ctx, self.d_bt, self.max_blocks,
+                                      self.block_size, self.d_spec, self.K, self.d_step)
+            return
         else:
             self.model.argmax(B, self.d_next)
         if chain:
@@ -336,7 +349,10 @@ class ModelRunner:
                            boost_idx_q=self.d_boost if boost else None, **boost)
             H.rng_advance(self.d_rng)
             return
-        if greedy_tail:
+        if greedy_tail and self.K + 1 <= 16 and self.model.has_argmax_parts(T):
+            # LM head -> [argmax from its candidates + accept / reject] : the verify graph's tail is two launches
+            self.model.argmax_verify(B, self.K, self.d_ids, self.d_next, self.d_accept, self.d_recovery, self.d_packed)
+        elif greedy_tail:
             self.model.argmax(T, self.d_next)
             H.verify_greedy(self.d_next, self.d_ids, B, self.K, self.d_accept, self.d_recovery, self.d_packed)
 
@@ -722,6 +738,10 @@ class ModelRunner:
             else:
                 H.sample_rows(lg, V, T, V, self.d_temps, mq, self.d_rng, 4, self.d_next)
             H.rng_advance(self.d_rng)
+        elif self.model.has_argmax_parts(T):
+            # one launch writes the tokens, the next step's input ids and column d of the [T][K] token table
+            self.model.argmax(T, self.d_next, self.d_ids, self.d_tree_tokens.view(-1)[d:], self.K)
+            return
         else:
             self.model.argmax(T, self.d_next)
         self.d_ids[:T].copy_(self.d_next[:T])

@@ -44,6 +44,12 @@ SIGNATURES = {
     "ssd_attn_paged": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                        c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int,
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "ssd_gemm_wf_argmax_parts": [c_int, c_int, c_int],
+    "ssd_gemm_wf_argmax": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
+    "ssd_argmax_parts": [c_void_p, c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p],
+    "ssd_argmax_parts_verify": [c_void_p, c_void_p, c_int, c_long, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "ssd_argmax_parts_advance": [c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                 c_int, c_void_p, c_int, c_void_p, c_int, c_void_p],
     "ssd_argmax_rows": [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "ssd_argmax_rows_val": [c_void_p, c_long, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p],
     "ssd_argmax_merge": [c_void_p, c_void_p, c_int, c_int, c_long, c_long, c_void_p, c_void_p, c_void_p],

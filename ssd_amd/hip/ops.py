@@ -146,6 +146,39 @@ def attn_paged(q_rows, k_cache, v_cache, block_tables, max_blocks, context_lens,
                                          _p(ws_o), _p(ws_ml), _p(out_rows), _p(out_frag), _stream()), "ssd_attn_paged")
 
 
+def gemm_argmax_nparts(M: int, N: int, K: int) -> int:
+    """Candidates per token row that gemm_argmax writes for this shape (= its workgroups); host-side query."""
+    n = load_library().ssd_gemm_wf_argmax_parts(M, N, K)
+    if n <= 0:
+        _check(n if n < 0 else -1, "ssd_gemm_wf_argmax_parts")
+    return n
+
+
+def gemm_argmax(x_frag, w_frag, y, M: int, N: int, K: int, ldy: int, part_val, part_idx, part_stride: int, bias=None):
+    """LM head: logits rows + per-workgroup argmax candidates [M][part_stride] (csrc/gemm.hip EPI_ROWS_ARGMAX)."""
+    _check(load_library().ssd_gemm_wf_argmax(_p(x_frag), _p(w_frag), _p(bias), _p(y), M, N, K, ldy, _p(part_val), _p(part_idx),
+                                             part_stride, _stream()), "ssd_gemm_wf_argmax")
+
+
+def argmax_parts(part_val, part_idx, nparts: int, part_stride: int, T: int, out=None, out2=None, out3=None, out3_stride: int = 0,
+                 out_val=None, idx_offset: int = 0):
+    _check(load_library().ssd_argmax_parts(_p(part_val), _p(part_idx), nparts, part_stride, T, idx_offset, _p(out), _p(out2), _p(out3),
+                                           out3_stride, _p(out_val), _stream()), "ssd_argmax_parts")
+
+
+def argmax_parts_verify(part_val, part_idx, nparts: int, part_stride: int, speculations, B: int, K: int, accept_len, recovery,
+                        packed=None, preds=None):
+    _check(load_library().ssd_argmax_parts_verify(_p(part_val), _p(part_idx), nparts, part_stride, _p(speculations), B, K, _p(preds),
+                                                  _p(accept_len), _p(recovery), _p(packed), _stream()), "ssd_argmax_parts_verify")
+
+
+def argmax_parts_advance(part_val, part_idx, nparts: int, part_stride: int, next_ids, input_ids, positions, slots, context_lens,
+                         block_tables, max_blocks, block_size, spec, K, step, B):
+    _check(load_library().ssd_argmax_parts_advance(_p(part_val), _p(part_idx), nparts, part_stride, _p(next_ids), _p(input_ids),
+                                                   _p(positions), _p(slots), _p(context_lens), _p(block_tables), max_blocks, block_size,
+                                                   _p(spec), K, _p(step), B, _stream()), "ssd_argmax_parts_advance")
+
+
 def argmax_rows(logits, ld: int, T: int, V: int, out, out2=None):
     _check(load_library().ssd_argmax_rows(_p(logits), ld, T, V, _p(out), _p(out2), _stream()), "ssd_argmax_rows")
 

@@ -120,6 +120,15 @@ class HipDecoder:
         st = min(T, max_split_tokens)
         self.ws_o = z(st * self.nh * self.max_splits * self.hd, dtype=torch.float32)
         self.ws_ml = z(st * self.nh * self.max_splits * 2, dtype=torch.float32)
+        # LM-head argmax candidates (csrc/gemm.hip EPI_ROWS_ARGMAX): one (value, index) per token row and workgroup, finished
+        # by ssd_argmax_parts* -- on the greedy path for up to 32 logit rows (decode / verify / tree step)
+        self.argmax_fused = os.environ.get("SSD_ARGMAX_FUSED", "1") != "0"
+        self.ap_rows = min(self.max_logit_rows, 32)
+        self.ap_stride = max(H.gemm_argmax_nparts(m, self.V, self.h) for m in ({1, self.ap_rows} if self.ap_rows > 16 else {1}))
+        self.ap_val = z(self.ap_rows, self.ap_stride, dtype=torch.float32)
+        self.ap_idx = z(self.ap_rows, self.ap_stride, dtype=torch.int32)
+        # (whether candidates exist for n rows is a function of n alone -- never of Python-side state, which a hipGraph replay
+        #  of compute_logits would not update)
         # vocab-parallel argmax scratch
         self.am_val = z(tp_size, self.max_logit_rows, dtype=torch.float32)
         self.am_idx = z(tp_size, self.max_logit_rows, dtype=torch.int64)
@@ -415,11 +424,63 @@ class HipDecoder:
         else:
             H.rmsnorm(self.buf_h, self.w["model.norm.weight"], self.cfg.rms_norm_eps, n, self.h, res_in=self.buf_res,
                       out_frag=self.buf_lastf, gather=gather)
-        self._gemm(self.buf_lastf, self.h, self.w["lm_head.weight"], self.V, self.logits, n, self.V)
+        if self._ap_ok(n):
+            H.gemm_argmax(self.buf_lastf, self.w["lm_head.weight"], self.logits, n, self.V, self.h, self.V, self.ap_val, self.ap_idx,
+                          self.ap_stride)
+        else:
+            self._gemm(self.buf_lastf, self.h, self.w["lm_head.weight"], self.V, self.logits, n, self.V)
         return n
 
-    def argmax(self, n: int, out: torch.Tensor, out2: torch.Tensor | None = None) -> None:
-        """Greedy tokens of logits[:n] over the FULL vocabulary (identical on every TP rank)."""
+    def _ap_ok(self, n: int) -> bool:
+        """compute_logits(n) leaves argmax candidates for its n rows."""
+        return self.argmax_fused and n <= self.ap_rows
+
+    def _ap_parts(self, n: int) -> int:
+        return H.gemm_argmax_nparts(n, self.V, self.h)
+
+    def has_argmax_parts(self, n: int) -> bool:
+        """compute_logits(n) leaves argmax candidates and the vocabulary is not sharded (the fused tails apply)."""
+        return self._ap_ok(n) and not self.use_coll
+
+    def argmax_verify(self, B: int, K: int, speculations, preds, accept_len, recovery, packed) -> None:
+        """argmax of the B*(K+1) verify rows + greedy accept / reject (utils/verify.py:28-48) in one launch (TP = 1)."""
+        assert self.has_argmax_parts(B * (K + 1))
+        H.argmax_parts_verify(self.ap_val, self.ap_idx, self._ap_parts(B * (K + 1)), self.ap_stride, speculations, B, K, accept_len, recovery,
+                              packed, preds=preds)
+
+    def argmax_advance(self, B: int, next_ids, input_ids, positions, slots, context_lens, block_tables, max_blocks, block_size,
+                       spec, K, step) -> None:
+        """argmax of the B decode rows + the device-side chain advance (csrc/misc.hip draft_advance) in one launch."""
+        assert self.has_argmax_parts(B)
+        H.argmax_parts_advance(self.ap_val, self.ap_idx, self._ap_parts(B), self.ap_stride, next_ids, input_ids, positions, slots,
+                               context_lens, block_tables, max_blocks, block_size, spec, K, step, B)
+
+    def argmax(self, n: int, out: torch.Tensor, out2: torch.Tensor | None = None, out3: torch.Tensor | None = None,
+               out3_stride: int = 0) -> None:
+        """Greedy tokens of logits[:n] over the FULL vocabulary (identical on every TP rank).  out3 (optional): a third
+        destination written with a row stride (the tree step's [T][K] token table; only with candidates available)."""
+        if self._ap_ok(n):          # candidates from the LM-head epilogue: a few thousand per row instead of V logits
+            np_ = self._ap_parts(n)
+            if not self.use_coll:
+                H.argmax_parts(self.ap_val, self.ap_idx, np_, self.ap_stride, n, out, out2, out3, out3_stride)
+                return
+            assert out3 is None
+            R = self.max_logit_rows
+            if self.custom_ar is not None:
+                idx_l = self.am_pack_l[:R]
+                val_l = self.am_pack_l[R:].view(torch.float32)[:R]
+                H.argmax_parts(self.ap_val, self.ap_idx, np_, self.ap_stride, n, idx_l, out_val=val_l, idx_offset=self.tp_rank * self.V)
+                self.custom_ar.all_gather_words(self.am_pack_l, self.am_pack, self.am_words)
+                vals = self.am_pack.view(-1)[R:].view(torch.float32)
+                H.argmax_merge(vals, self.am_pack, self.tp_size, n, 2 * self.am_words, out, out2, stride_idx=self.am_words)
+                return
+            H.argmax_parts(self.ap_val, self.ap_idx, np_, self.ap_stride, n, self.am_idx_l, out_val=self.am_val_l,
+                           idx_offset=self.tp_rank * self.V)
+            dist.all_gather_into_tensor(self.am_val.view(-1), self.am_val_l, group=self.tp_group)
+            dist.all_gather_into_tensor(self.am_idx.view(-1), self.am_idx_l, group=self.tp_group)
+            H.argmax_merge(self.am_val, self.am_idx, self.tp_size, n, R, out, out2)
+            return
+        assert out3 is None
         if not self.use_coll:
             H.argmax_rows(self.logits, self.V, n, self.V, out, out2)
             return
