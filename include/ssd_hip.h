@@ -219,6 +219,13 @@ int ssd_verify_ratio(const void* logits_p, long ld_p, const void* logits_q, long
 int ssd_fork_topf(const void* logits_rows, long ld, int V, const int64_t* returned_tokens, const int32_t* counts,
                   const int32_t* offsets, int B, int K, int mq, int64_t* out, void* stream);
 
+/* Speculation-cache lookup -- the tensor compare of DraftRunner.hit_cache_and_respond, ssd/engine/draft_runner.py:215-252.
+ * The cache of a round has Bc * W entries: entry c = b * W + i has key (cache_seq[b], cache_j[c], cache_forks[c]) =
+ * (sequence id, glue position of branch i, fork token of branch i).  out_idx[r] (int32[B]) = first entry equal to request key
+ * r = req_keys[r][0..2] (int64 [B][3]: seq id, accepted length - 1, recovery token), or -1. */
+int ssd_cache_lookup(const int64_t* req_keys, const int64_t* cache_seq, const int32_t* cache_j, const int64_t* cache_forks,
+                     int B, int Bc, int W, int32_t* out_idx, void* stream);
+
 /* Device-side replacement for the host loop body of SpeculatorSync.speculate --
  * ssd/engine/speculator_sync.py:47-66 (+ runner_helpers.py:59-75): append the sampled token, bump
  * position / context length, recompute the KV slot from the block table. */

@@ -198,6 +198,18 @@ class OracleRunner:
         return sfx, rec
 
     # ---- draft-server operations of asynchronous speculation (explicit arrays, no Sequence objects) ----
+    def cache_index(self, seq_ids, jlists):
+        return torch.tensor(list(seq_ids), dtype=torch.int64), torch.tensor([list(j) for j in jlists], dtype=torch.int32)
+
+    def cache_lookup(self, keys, cache_seq, cache_j, forks):
+        """The reference's vectorized membership test (ssd/engine/draft_runner.py:215-252): first matching entry or -1."""
+        req = torch.tensor([list(k) for k in keys], dtype=torch.int64)                      # [B, 3]
+        W = forks.shape[1]
+        ck = torch.stack([cache_seq.repeat_interleave(W), cache_j.reshape(-1).to(torch.int64), forks.reshape(-1)], dim=1)   # [Bc*W, 3]
+        match = (req.unsqueeze(1) == ck.unsqueeze(0)).all(dim=2)                            # [B, Bc*W]
+        first = match.float().argmax(dim=1).to(torch.int32)
+        return torch.where(match.any(dim=1), first, torch.full_like(first, -1))
+
     def zeros_tokens(self, B, K):
         return torch.zeros(B, K, dtype=torch.int64)
 

@@ -79,7 +79,7 @@ def probe(tp: int, M: int, grp, dev):
         rows.append((name, us, mb, per_fwd))
         print(f"  {name:46s} {us:8.2f} us  {mb:8.1f} MB  {mb / us if us else 0:6.2f} TB/s   x{per_fwd:4d} = {us * per_fwd / 1e3:7.3f} ms", flush=True)
 
-    print(f"==== TP = {tp}: per-rank shard of Llama-3.1-70B, M = {M} verify rows, ctx {ctx}; {m.weight_bytes() / L / 1e6:.0f} MB per layer ====")
+    print(f"==== TP = {tp}: per-rank shard of Llama-3.1-70B, M = {M} verify rows, ctx {ctx} ====")
     NL = 80
     row(f"qkv+RoPE+KV store [{m.qkv_n}x{m.h}]", timed(lambda li: m.launch_qkv(li, M, r.d_pos, r.d_slots, pre_normed=True), L), m.qkv_n * m.h * 2 / 1e6, NL)
     row(f"attention (nh {m.nh}, nkv {m.nkv}, {waves} waves, {splits} splits)",
@@ -106,7 +106,7 @@ def probe(tp: int, M: int, grp, dev):
     emb = rows[6][1]
     per_layer = (body - tail - emb) / L
     proj = (per_layer * NL + tail + emb) / 1e3
-    gb = (m.weight_bytes() / L * NL + (m.V * m.h * 2)) / 1e9
+    gb = sum(mb * n for _, _, mb, n in rows[:6] if mb > 1.0) / 1e3 + m.V * m.h * 2 / 1e9      # layer matrices x 80 + LM head
     print(f"  sum of kinds x 80 layers                       {total_kinds:8.3f} ms")
     print(f"  verify body, {L} layers in one graph            {body:8.1f} us  -> per layer {per_layer:6.2f} us, tail {tail:6.1f} us")
     print(f"  PROJECTED TP = {tp} verify (80 layers, zero xGMI wait)  {proj:7.3f} ms for {gb:.2f} GB  = {gb / proj:.3f} TB/s = {gb / proj / 8.0:.3f} of 8 TB/s")

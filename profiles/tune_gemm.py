@@ -23,7 +23,7 @@ SHAPES = {
     "q32b_tp4": [(2560, 5120), (5120, 2048), (12800, 5120), (5120, 6400), (37984, 5120)],
     "q06b": [(4096, 1024), (1024, 2048), (6144, 1024), (1024, 3072), (151936, 1024)],
 }
-MS = {"1b": [1, 24], "8b": [7], "70b_tp1": [7], "70b_tp2": [7], "70b_tp4": [7], "70b_tp8": [7], "q32b_tp1": [8], "q32b_tp4": [8],
+MS = {"1b": [1, 24], "8b": [7], "70b_tp1": [7], "70b_tp2": [7], "70b_tp4": [8], "70b_tp8": [8], "q32b_tp1": [8], "q32b_tp4": [8],
       "q06b": [1, 24]}
 TPWS = (1, 2, 3, 4, 7, 8)      # consecutive tiles per workgroup (persistent variant), encoded in bits 8.. of `waves`
 if len(sys.argv) > 1:

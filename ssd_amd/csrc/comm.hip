@@ -40,6 +40,19 @@ __device__ __forceinline__ unsigned long long ld_sys64(const unsigned long long*
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Publish protocol (guide: "payload write-through, drained, then ONE flag store; the consumer polls the flag and reads the
+// payload with cache-bypassing loads"): the staged words are system-scope (write-through, sc0 sc1) stores and every reader
+// uses system-scope loads, so no cache holds a stale or an unwritten copy on either side -- what must be ordered is only
+// "all my payload stores have completed" before "my flag store is issued": every storing wave drains its store queue
+// (s_waitcnt vmcnt(0), as inline asm so the compiler cannot drop or move it), the workgroup meets, then the flags go out.
+// No release fence (an L2 write-back of everything the preceding GEMM left dirty) and no acquire fence (an L2 invalidate
+// that the NEXT GEMM would pay for): measured on MI355X with the TP = 4 shard shapes, the fused all-reduce + norm launch
+// went from 7.6 us to the figure in profiles/r03_tp_shard_per_kind.txt.
+__device__ __forceinline__ void ar_publish_barrier() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 __global__ void __launch_bounds__(AR_THREADS)
 allreduce_bf16_kernel(const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out, long n8,
                       long slot_words, ArPeers peers, int rank, int world, unsigned int* __restrict__ counters,
@@ -54,9 +67,7 @@ allreduce_bf16_kernel(const unsigned long long* __restrict__ in, unsigned long l
   const long i0 = blk * per, i1 = min(n8, i0 + per);
   unsigned long long* my = peers.slot[rank] + (long)(epoch & 1u) * slot_words;
   for (long i = i0 + threadIdx.x; i < i1; i += AR_THREADS) st_sys64(my + i, in[i]);
-  __syncthreads();
-  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system-scope release
-  __syncthreads();
+  ar_publish_barrier();
   if (threadIdx.x < world) {
     const int peer = threadIdx.x;
     __hip_atomic_store(peers.flags[peer] + blk * AR_MAX_RANKS + rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -72,8 +83,7 @@ allreduce_bf16_kernel(const unsigned long long* __restrict__ in, unsigned long l
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                                  // system-scope acquire
-    counters[blk] = epoch;
+    counters[blk] = epoch;           // (no acquire fence: every staged word is read with a system-scope load, see ar_publish_barrier)
     if (s_fail) atomicExch(err, 1u);
   }
   __syncthreads();
@@ -121,9 +131,7 @@ allreduce_add_rmsnorm_kernel(const unsigned long long* __restrict__ in, const u3
   const long hw = H >> 2;                       // 8-byte words per row
   unsigned long long* my = peers.slot[rank] + (long)(epoch & 1u) * slot_words;
   for (long i = (long)r0 * hw + threadIdx.x; i < (long)r1 * hw; i += ARN_THREADS) st_sys64(my + i, in[i]);
-  __syncthreads();
-  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-  __syncthreads();
+  ar_publish_barrier();
   if (threadIdx.x < world) {
     const int peer = threadIdx.x;
     __hip_atomic_store(peers.flags[peer] + blk * AR_MAX_RANKS + rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -136,7 +144,6 @@ allreduce_add_rmsnorm_kernel(const unsigned long long* __restrict__ in, const u3
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     counters[blk] = epoch;
     if (s_fail) atomicExch(err, 1u);
   }

@@ -114,6 +114,10 @@ static inline void ssd_pick_skinny_cfg(int groups, int KT, bool silu_pairs, int*
   } else if (groups >= 512 && KT >= 256 && groups % 2 == 0) {    // 70B-class o_proj
     n = 2; w = 8;
   }
+  // fewer workgroups than CUs (tensor-parallel shards of qkv, the drafts' qkv): a CU's pull from HBM is bounded by the bytes
+  // it has in flight (8 waves x 8 KiB ~ 30 GB/s), so an under-filled launch gets 16 waves per workgroup
+  // (profiles/r03_tp_shard_per_kind.txt: 70B qkv at TP = 4, 160 workgroups)
+  if (!silu_pairs && groups / n < 256 && KT >= 64) w = 16;
   while (w > 1 && KT / w < 2) w >>= 1;    // every wave needs a couple of k-tiles
   *nt = n; *waves = w; *tpw = t;
 }

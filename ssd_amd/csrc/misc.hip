@@ -39,6 +39,32 @@ extern "C" int ssd_draft_advance(const int64_t* next, int64_t* input_ids, int64_
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
+// Speculation-cache lookup on the draft device (reference ssd/engine/draft_runner.py:215-252: request keys compared
+// against the tensor-backed tree cache).  The cache of a round is indexed by (sequence id of row b, glue position j of branch
+// i, fork token of branch i): entry c = b * W + i.  out_idx[r] = the FIRST entry equal to request key r = (seq, j, token), or
+// -1.  One workgroup per request; nothing but this [B] int32 vector crosses to the host to decide reply-from-cache vs. JIT.
+__global__ void cache_lookup_kernel(const int64_t* __restrict__ req, const int64_t* __restrict__ cache_seq,
+                                    const int32_t* __restrict__ cache_j, const int64_t* __restrict__ cache_forks, int Bc, int W,
+                                    int32_t* __restrict__ out_idx) {
+  __shared__ int best;
+  const int r = blockIdx.x;
+  if (threadIdx.x == 0) best = 0x7fffffff;
+  __syncthreads();
+  const int64_t k_seq = req[r * 3], k_j = req[r * 3 + 1], k_tok = req[r * 3 + 2];
+  for (int c = threadIdx.x; c < Bc * W; c += blockDim.x)
+    if (cache_seq[c / W] == k_seq && (int64_t)cache_j[c] == k_j && cache_forks[c] == k_tok) atomicMin(&best, c);
+  __syncthreads();
+  if (threadIdx.x == 0) out_idx[r] = best == 0x7fffffff ? -1 : best;
+}
+
+extern "C" int ssd_cache_lookup(const int64_t* req_keys, const int64_t* cache_seq, const int32_t* cache_j,
+                                const int64_t* cache_forks, int B, int Bc, int W, int32_t* out_idx, void* stream) {
+  if (B <= 0 || Bc <= 0 || W <= 0) return SSD_ERR_SHAPE;
+  hipLaunchKernelGGL(cache_lookup_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, req_keys, cache_seq, cache_j, cache_forks, Bc,
+                     W, out_idx);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
 // Keep the draft's logits of chain step `*step` as logits_q[b][step] (SpeculatorSync collects them with torch.stack,
 // reference ssd/engine/speculator_sync.py:58,67); the step index lives on the device so the launch is graph-replayable.
 __global__ void store_step_rows_kernel(const u32x4_t* __restrict__ src, long src_ld8, u32x4_t* __restrict__ dst, int V8, int K,

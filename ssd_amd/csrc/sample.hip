@@ -182,63 +182,113 @@ extern "C" int ssd_fork_topf(const void* logits, long ld, int V, const int64_t* 
 //   advance  ssd_draft_advance's "append token, bump position, recompute slot" of the chained draft forwards
 // One wave per token row; (max value, lowest index) -- identical to an argmax over the stored bf16 logits.
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ ArgBest parts_row_argmax(const float* __restrict__ pv, const int* __restrict__ pi, int nparts, int lane) {
-  ArgBest best = {-INFINITY, 0x7fffffff};
-  for (int p = lane; p < nparts; p += 64) best = better(best, ArgBest{pv[p], pi[p]});
+// All 512 threads of a workgroup scan the candidates of up to AP_ROWS rows: every thread issues ALL its loads of all rows
+// before the first compare (a few thousand candidates per row are ONE memory round trip for the workgroup; a single wave
+// walking them took 63 dependent round trips = 40 us), then wave shuffles + one LDS stage.  res[r] = (max, lowest index).
+constexpr int AP_THREADS = 512;     // (256 VGPRs per lane: AP_ROWS x AP_UN candidates stay in registers)
+constexpr int AP_ROWS = 4;          // rows per pass (registers: AP_ROWS x AP_UN candidates in flight per thread)
+constexpr int AP_MAX_SEQ_ROWS = 16; // rows of one sequence in the verify tail (K + 1)
+constexpr int AP_UN = 8;        // candidates per thread and row in flight (covers 4096 candidates per pass)
+
+__device__ void block_parts_argmax(const float* __restrict__ part_val, const int* __restrict__ part_idx, int nparts,
+                                   long part_stride, int row0, int nrows, ArgBest* res /* shared [AP_ROWS] */,
+                                   ArgBest* sm /* shared [AP_THREADS / 64][AP_ROWS] */) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  ArgBest best[AP_ROWS];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) best = better(best, ArgBest{__shfl_xor(best.v, o, 64), __shfl_xor(best.i, o, 64)});
-  if (best.i == 0x7fffffff) best.i = 0;     // nothing comparable in the row (all NaN / -inf): never emit the sentinel
-  return best;
+  for (int r = 0; r < AP_ROWS; ++r) best[r] = ArgBest{-INFINITY, 0x7fffffff};
+  for (int base = 0; base < nparts; base += AP_THREADS * AP_UN) {
+    float v[AP_ROWS][AP_UN];
+    int ix[AP_ROWS][AP_UN];
+#pragma unroll
+    for (int r = 0; r < AP_ROWS; ++r) {
+      if (r < nrows) {           // block-uniform
+        const float* pv = part_val + (size_t)(row0 + r) * part_stride;
+        const int* pi = part_idx + (size_t)(row0 + r) * part_stride;
+#pragma unroll
+        for (int u = 0; u < AP_UN; ++u) {
+          const int p = base + u * AP_THREADS + tid;
+          const int pc = p < nparts ? p : nparts - 1;          // clamped: an unconditional load (a duplicate never changes the result)
+          v[r][u] = pv[pc];
+          ix[r][u] = pi[pc];
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < AP_ROWS; ++r) {
+      if (r < nrows) {
+#pragma unroll
+        for (int u = 0; u < AP_UN; ++u) best[r] = better(best[r], ArgBest{v[r][u], ix[r][u]});
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < AP_ROWS; ++r) {
+    if (r < nrows) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) best[r] = better(best[r], ArgBest{__shfl_xor(best[r].v, o, 64), __shfl_xor(best[r].i, o, 64)});
+      if (lane == 0) sm[w * AP_ROWS + r] = best[r];
+    }
+  }
+  __syncthreads();
+  if (tid < nrows) {
+    ArgBest b = sm[tid];
+    for (int ww = 1; ww < AP_THREADS / 64; ++ww) b = better(b, sm[ww * AP_ROWS + tid]);
+    if (b.i == 0x7fffffff) b.i = 0;       // nothing comparable in the row (all NaN / -inf): never emit the sentinel
+    res[tid] = b;
+  }
+  __syncthreads();
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(AP_THREADS)
 argmax_parts_kernel(const float* __restrict__ part_val, const int* __restrict__ part_idx, int nparts, long part_stride, int T,
-                    long idx_offset, int64_t* __restrict__ out, int64_t* __restrict__ out2, int64_t* __restrict__ out3,
-                    long out3_stride, float* __restrict__ out_val) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= T) return;
-  const ArgBest r = parts_row_argmax(part_val + (size_t)row * part_stride, part_idx + (size_t)row * part_stride, nparts, lane);
-  if (lane == 0) {
-    const int64_t tok = (int64_t)r.i + idx_offset;
+                    int rows_per_block, long idx_offset, int64_t* __restrict__ out, int64_t* __restrict__ out2,
+                    int64_t* __restrict__ out3, long out3_stride, float* __restrict__ out_val) {
+  __shared__ ArgBest res[AP_ROWS], sm[(AP_THREADS / 64) * AP_ROWS];
+  const int row0 = blockIdx.x * rows_per_block;
+  const int nrows = min(rows_per_block, T - row0);
+  block_parts_argmax(part_val, part_idx, nparts, part_stride, row0, nrows, res, sm);
+  if ((int)threadIdx.x < nrows) {
+    const int row = row0 + threadIdx.x;
+    const int64_t tok = (int64_t)res[threadIdx.x].i + idx_offset;
     if (out) out[row] = tok;
     if (out2) out2[row] = tok;
     if (out3) out3[(size_t)row * out3_stride] = tok;
-    if (out_val) out_val[row] = r.v;
+    if (out_val) out_val[row] = res[threadIdx.x].v;
   }
 }
 
 extern "C" int ssd_argmax_parts(const float* part_val, const int32_t* part_idx, int nparts, long part_stride, int T, long idx_offset,
                                 int64_t* out, int64_t* out2, int64_t* out3, long out3_stride, float* out_val, void* stream) {
   if (T <= 0 || nparts <= 0 || part_stride < nparts || !part_val || !part_idx) return SSD_ERR_SHAPE;
-  hipLaunchKernelGGL(argmax_parts_kernel, dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, part_val, part_idx, nparts,
-                     part_stride, T, idx_offset, out, out2, out3, out3_stride, out_val);
+  const int rpb = T <= 4 ? T : (T <= 64 ? 4 : AP_ROWS);     // a few rows per workgroup: more workgroups = more loads in flight
+  hipLaunchKernelGGL(argmax_parts_kernel, dim3((T + rpb - 1) / rpb), dim3(AP_THREADS), 0, (hipStream_t)stream, part_val, part_idx,
+                     nparts, part_stride, T, rpb, idx_offset, out, out2, out3, out3_stride, out_val);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
-// one workgroup per sequence, one wave per verified row (K + 1 <= 16)
-__global__ void __launch_bounds__(1024)
+// one workgroup per sequence: its K + 1 <= 16 rows
+__global__ void __launch_bounds__(AP_THREADS)
 argmax_parts_verify_kernel(const float* __restrict__ part_val, const int* __restrict__ part_idx, int nparts, long part_stride,
                            const int64_t* __restrict__ spec, int K, int64_t* __restrict__ preds, int32_t* __restrict__ accept_len,
                            int64_t* __restrict__ recovery, int64_t* __restrict__ packed) {
-  __shared__ int64_t sp[16];
-  const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int row = b * (K + 1) + w;
-  const ArgBest r = parts_row_argmax(part_val + (size_t)row * part_stride, part_idx + (size_t)row * part_stride, nparts, lane);
-  if (lane == 0) { sp[w] = r.i; if (preds) preds[row] = r.i; }
-  __syncthreads();
-  if (w != 0) return;
+  __shared__ ArgBest res[AP_MAX_SEQ_ROWS], sm[(AP_THREADS / 64) * AP_ROWS];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  for (int r0 = 0; r0 <= K; r0 += AP_ROWS)
+    block_parts_argmax(part_val, part_idx, nparts, part_stride, b * (K + 1) + r0, min(AP_ROWS, K + 1 - r0), res + r0, sm);
+  if (threadIdx.x >= 64) return;
+  if (preds && lane <= K) preds[(size_t)b * (K + 1) + lane] = res[lane].i;
   bool mismatch = false;
-  if (lane < K) mismatch = spec[(size_t)b * (K + 1) + lane + 1] != sp[lane];
+  if (lane < K) mismatch = spec[(size_t)b * (K + 1) + lane + 1] != (int64_t)res[lane].i;
   const unsigned long long mask = __ballot(mismatch);
   const int n = mask ? (int)__builtin_ctzll(mask) : K;
   if (lane == 0) {
     accept_len[b] = n;
-    recovery[b] = sp[n];
+    recovery[b] = res[n].i;
   }
   if (packed) {
     int64_t* prow = packed + (size_t)b * (K + 3);
-    if (lane == 0) { prow[0] = n; prow[1] = sp[n]; }
+    if (lane == 0) { prow[0] = n; prow[1] = res[n].i; }
     if (lane <= K) prow[2 + lane] = spec[(size_t)b * (K + 1) + lane];
   }
 }
@@ -247,24 +297,25 @@ extern "C" int ssd_argmax_parts_verify(const float* part_val, const int32_t* par
                                        const int64_t* speculations, int B, int K, int64_t* preds, int32_t* accept_len,
                                        int64_t* recovery, int64_t* packed, void* stream) {
   if (B <= 0 || K < 0 || K > 15 || nparts <= 0 || part_stride < nparts || !part_val || !part_idx) return SSD_ERR_SHAPE;
-  hipLaunchKernelGGL(argmax_parts_verify_kernel, dim3(B), dim3(64 * (K + 1)), 0, (hipStream_t)stream, part_val, part_idx, nparts,
+  hipLaunchKernelGGL(argmax_parts_verify_kernel, dim3(B), dim3(AP_THREADS), 0, (hipStream_t)stream, part_val, part_idx, nparts,
                      part_stride, speculations, K, preds, accept_len, recovery, packed);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
-// ONE workgroup (the step counter is shared by all sequences); waves walk the B rows
-__global__ void __launch_bounds__(1024)
+// ONE workgroup (the step counter is shared by all sequences) walks the B rows, AP_ROWS at a time
+__global__ void __launch_bounds__(AP_THREADS)
 argmax_parts_advance_kernel(const float* __restrict__ part_val, const int* __restrict__ part_idx, int nparts, long part_stride,
                             int64_t* __restrict__ next, int64_t* __restrict__ input_ids, int64_t* __restrict__ positions,
                             int32_t* __restrict__ slots, int32_t* __restrict__ ctx, const int32_t* __restrict__ block_tables,
                             int max_blocks, int bs, int64_t* __restrict__ spec, int K, int32_t* step, int B) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __shared__ ArgBest res[AP_ROWS], sm[(AP_THREADS / 64) * AP_ROWS];
   const int s = *step;
-  __syncthreads();
-  for (int b = w; b < B; b += nw) {
-    const ArgBest r = parts_row_argmax(part_val + (size_t)b * part_stride, part_idx + (size_t)b * part_stride, nparts, lane);
-    if (lane == 0) {
-      const int64_t tok = r.i;
+  for (int row0 = 0; row0 < B; row0 += AP_ROWS) {
+    const int nrows = min(AP_ROWS, B - row0);
+    block_parts_argmax(part_val, part_idx, nparts, part_stride, row0, nrows, res, sm);
+    if ((int)threadIdx.x < nrows) {
+      const int b = row0 + threadIdx.x;
+      const int64_t tok = res[threadIdx.x].i;
       next[b] = tok;
       if (s + 1 <= K) spec[(size_t)b * (K + 1) + s + 1] = tok;
       input_ids[b] = tok;
@@ -274,6 +325,7 @@ argmax_parts_advance_kernel(const float* __restrict__ part_val, const int* __res
       const int blk = block_tables[(size_t)b * max_blocks + (int)(pos / bs)];
       slots[b] = blk >= 0 ? blk * bs + (int)(pos % bs) : -1;
     }
+    __syncthreads();      // res / sm are reused by the next group of rows
   }
   if (threadIdx.x == 0) *step = s + 1;
 }
@@ -283,8 +335,7 @@ extern "C" int ssd_argmax_parts_advance(const float* part_val, const int32_t* pa
                                         const int32_t* block_tables, int max_blocks, int block_size, int64_t* spec, int K,
                                         int32_t* step, int B, void* stream) {
   if (B <= 0 || B > 1024 || nparts <= 0 || part_stride < nparts || !part_val || !part_idx) return SSD_ERR_SHAPE;
-  const int waves = B < 16 ? B : 16;
-  hipLaunchKernelGGL(argmax_parts_advance_kernel, dim3(1), dim3(64 * waves), 0, (hipStream_t)stream, part_val, part_idx, nparts,
+  hipLaunchKernelGGL(argmax_parts_advance_kernel, dim3(1), dim3(AP_THREADS), 0, (hipStream_t)stream, part_val, part_idx, nparts,
                      part_stride, next, input_ids, positions, slots, context_lens, block_tables, max_blocks, block_size, spec, K,
                      step, B);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;

@@ -13,8 +13,9 @@ Geometry, with P = num_tokens - 1 = position of the recovery tok
   fork              top-F_j tokens per glue position j, excluding x_{j+1} for j < K  -> MQ_LEN branches
   tree step d       branch i feeds its token at RoPE position P+j_i+1+d, KV slot P+K+1+d*MQ_LEN+i
   cache             key (seq_id, j_i, fork token_i) -> K continuation tokens of branch i
-The speculation cache lives on the draft device (tokens) with its keys mirrored on the host; a request is
-answered before the glue/tree work of the new round starts, so that work overlaps the target's verify.
+The speculation cache lives on the draft device -- tokens AND keys (fork tokens, sequence ids, glue positions); a request is
+looked up there (csrc/misc.hip ssd_cache_lookup) and answered before the glue/tree work of the new round starts, so that work
+overlaps the target's verify.
 
 EAGLE-3 drafts (config.use_eagle; reference branches at draft_runner.py:133-177,230-285,312-331,530-612,660-711):
 every draft position is shifted by -1 (KV row p holds token p+1, conditioned on the target's activation of position
@@ -90,7 +91,7 @@ class DraftServer:
         self.max_blocks = config.max_blocks
         self.j_hit = branch_positions(config.fan_out_list)
         self.j_miss = branch_positions(config.fan_out_list_miss)
-        self.cache_keys: dict[tuple[int, int, int], int] = {}
+        self._cache_index = None            # device (sequence ids [B], glue positions [B, W]) of pending_forks, built on first use
         self.cache_tokens = None            # device tensor [N, K]
         self.cache_logits = None            # device tensor [N, K, V] when the last tree was sampled (temperature > 0)
         self.eagle = bool(getattr(config, "use_eagle", False))
@@ -108,6 +109,12 @@ class DraftServer:
         work, self._parked = self._parked, None
         if work is not None:
             self._on_stream(work)
+
+    def reset(self) -> None:
+        """Forget the parked round and the speculation cache (LLMEngine.abort_all: their sequences are gone)."""
+        self._parked = None
+        self.pending_forks = self.pending_meta = self._cache_index = None
+        self.cache_tokens = self.cache_logits = self.cache_acts = None
 
     def _on_stream(self, fn):
         if self.stream is None:
@@ -157,18 +164,17 @@ class DraftServer:
             pass
 
     # ---- speculation round ----
-    def _mirror_keys(self) -> None:
-        """Bring the fork tokens of the finished round to the host and index the cache by them."""
+    def _lookup(self, keys) -> tuple[list[int], torch.Tensor | None]:
+        """Request keys against the cache of the finished round, ON THE DRAFT DEVICE (reference draft_runner.py:215-252): the
+        fork tokens never leave it; what comes back is one int32 per request -- the entry index or -1 -- which the host needs
+        anyway to choose between replying from the cache and running the JIT chain (the reference syncs on `cache_hits.all()`
+        at the same point, :246)."""
         if self.pending_forks is None:
-            return
-        forks = self.pending_forks.tolist()         # the only device read of a round, after all its work is queued
-        seq_ids, jlists = self.pending_meta
-        self.cache_keys = {}
-        width = self.pending_forks.shape[1]          # MQ_LEN, or this member's slice of it under draft data-parallelism
-        for b, row in enumerate(forks):
-            for i, tok in enumerate(row):
-                self.cache_keys.setdefault((seq_ids[b], jlists[b][i], tok), b * width + i)
-        self.pending_forks = None
+            return [-1] * len(keys), None
+        if self._cache_index is None:
+            self._cache_index = self.runner.cache_index(*self.pending_meta)
+        idx_dev = self.runner.cache_lookup(keys, self._cache_index[0], self._cache_index[1], self.pending_forks)
+        return idx_dev.tolist(), idx_dev
 
     def _speculate(self, B: int, payload: list[int], flags: int) -> None:
         K = self.K
@@ -190,8 +196,7 @@ class DraftServer:
             t_req = self._trace.mark()
         want_logits = bool(flags & P.FLAG_WANT_LOGITS)
         sample = any(t > 0 for t in temps)
-        self._mirror_keys()
-        idx = [self.cache_keys.get(tuple(k), -1) for k in keys]         # rows of MY cache shard
+        idx, idx_dev = self._lookup(keys)                                # rows of MY cache shard (-1: miss)
         hits = [1 if i >= 0 else 0 for i in idx]
         owner = [0 if h else -1 for h in hits]                           # group member that holds each row's branch
         if dp is not None:
@@ -218,7 +223,7 @@ class DraftServer:
         dev = self.runner.zeros_tokens(1, 1).device
         if serve_from_cache:
             if dp is None:
-                rows = torch.tensor([i if i >= 0 else 0 for i in idx], dtype=torch.int64, device=self.cache_tokens.device)
+                rows = idx_dev.clamp_min(0).to(torch.int64)         # stays on the device
                 tokens = self.cache_tokens[rows]
                 if not all(hits):       # "fast" backup: miss rows carry filler tokens (the reference uses random ones)
                     tokens = tokens * torch.tensor(hits, dtype=torch.int64, device=tokens.device).unsqueeze(1)
@@ -283,11 +288,13 @@ class DraftServer:
             self.cache_logits = self.runner.tree_logits(forks.numel()) if sample else None
             self.pending_forks = forks
             self.pending_meta = ([k[0] for k in keys], jl)
+            self._cache_index = self.runner.cache_index(*self.pending_meta)      # off the critical path: the target is verifying
             self.stats["rounds"] += 1
             if self._trace is not None:
                 self._trace.span("glue_fork", t_a, t_b)
                 self._trace.span(f"tree[{forks.shape[1]}x{self.K}]", t_b, self._trace.mark())
-        self.cache_keys = {}
+        self.pending_forks = None           # the finished round's cache is consumed by this request
+        self._cache_index = None
         self.cache_tokens = None
         self.cache_acts = None
         if self.deferred:

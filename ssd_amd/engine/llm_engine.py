@@ -206,6 +206,9 @@ class LLMEngine:
                 sch.draft_block_manager.deallocate(seq)
         sch.running.clear()
         sch.waiting.clear()
+        srv = getattr(self, "draft_server", None)
+        if srv is not None:         # co-located draft: its parked round and its speculation cache belong to the aborted sequences
+            srv.reset()             # (the parked glue / tree work would write draft KV into blocks that may already have new owners)
 
     def create_inference_step(self, config: Config) -> InferenceStep:
         if not config.speculate:

@@ -594,6 +594,21 @@ class ModelRunner:
     def _async_lookahead(self) -> int:
         return self.K + 1 + self.K * self.config.MQ_LEN
 
+    def cache_index(self, seq_ids, jlists):
+        """Device copy of a round's cache keys besides the fork tokens: sequence id per row, glue position per branch."""
+        return (torch.tensor(list(seq_ids), dtype=torch.int64, device=self.device),
+                torch.tensor([list(j) for j in jlists], dtype=torch.int32, device=self.device).contiguous())
+
+    @torch.inference_mode()
+    def cache_lookup(self, keys, cache_seq: torch.Tensor, cache_j: torch.Tensor, forks: torch.Tensor) -> torch.Tensor:
+        """int32 [B] device: index b * W + i of the cache entry (seq id, j, fork token) equal to each request key, or -1
+        (csrc/misc.hip ssd_cache_lookup; reference draft_runner.py:215-252)."""
+        B = len(keys)
+        req = torch.tensor([list(k) for k in keys], dtype=torch.int64, device=self.device)
+        out = torch.empty(B, dtype=torch.int32, device=self.device)
+        H.cache_lookup(req, cache_seq, cache_j, forks.contiguous(), B, forks.shape[0], forks.shape[1], out)
+        return out
+
     def zeros_tokens(self, B: int, K: int) -> torch.Tensor:
         return torch.zeros(B, K, dtype=torch.int64, device=self.device)
 

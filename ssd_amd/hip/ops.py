@@ -203,6 +203,11 @@ def fork_topf(logits, ld: int, V: int, returned, counts, offsets, B: int, K: int
                                         _stream()), "ssd_fork_topf")
 
 
+def cache_lookup(req_keys, cache_seq, cache_j, cache_forks, B: int, Bc: int, W: int, out_idx):
+    _check(load_library().ssd_cache_lookup(_p(req_keys), _p(cache_seq), _p(cache_j), _p(cache_forks), B, Bc, W, _p(out_idx), _stream()),
+           "ssd_cache_lookup")
+
+
 def draft_advance(next_ids, input_ids, positions, slots, context_lens, block_tables, max_blocks, block_size, spec, K, step, B):
     _check(load_library().ssd_draft_advance(_p(next_ids), _p(input_ids), _p(positions), _p(slots), _p(context_lens),
                                             _p(block_tables), max_blocks, block_size, _p(spec), K, _p(step), B, _stream()),

@@ -616,3 +616,24 @@ def test_fused_gemm_with_partial_slab_prologue(H, M, K, S):
         outs.append((act, res_out))
     for a, b_ in zip(*outs):
         assert torch.equal(a.view(torch.int16), b_.view(torch.int16))
+
+
+def test_cache_lookup_equals_the_tensor_compare_of_the_reference(H):
+    """ssd_cache_lookup vs the reference's vectorized membership test (draft_runner.py:215-252, restated in
+    oracle/runner.py cache_lookup): first matching entry, -1 on a miss; duplicates, wrong-sequence and wrong-position keys."""
+    from oracle.runner import OracleRunner
+    torch.manual_seed(4)
+    Bc, W = 3, 24
+    forks = torch.randint(0, 50, (Bc, W), dtype=torch.int64)
+    forks[1, 7] = forks[1, 3]                       # duplicate token in one row ...
+    seq = torch.tensor([11, 5, 9], dtype=torch.int64)
+    cj = torch.tensor([[i // 3 for i in range(W)]] * Bc, dtype=torch.int32)
+    cj[1, 7] = cj[1, 3]                             # ... at the same glue position: the first entry wins
+    keys = [(5, int(cj[1, 3]), int(forks[1, 3])), (11, int(cj[0, 23]), int(forks[0, 23])), (9, 0, 10 ** 9), (7, 0, int(forks[0, 0])),
+            (9, int(cj[2, 5]) + 1, int(forks[2, 5])), (9, int(cj[2, 0]), int(forks[2, 0]))]
+    want = OracleRunner.cache_lookup(None, keys, seq, cj, forks).tolist()
+    assert want[0] == 1 * W + 3 and want[1] == 23 and want[2] == -1 and want[3] == -1 and want[5] == 2 * W
+    req = dev(torch.tensor([list(k) for k in keys], dtype=torch.int64))
+    out = torch.full((len(keys),), -5, dtype=torch.int32, device="cuda")
+    H.cache_lookup(req, dev(seq), dev(cj), dev(forks), len(keys), Bc, W, out)
+    assert out.cpu().tolist() == want
