@@ -254,18 +254,42 @@ def collective_probe(engine, M):
             "message_bytes": M * m.h * 2, "avg_us": round(us, 2), "backend": dist.get_backend(m.tp_group)}
 
 
+def cpu_baseline_reference(cores: int, budget: float):
+    """The REFERENCE's own engine classes on the host cores (tests/golden/make_golden.py time_reference_ar: its Scheduler,
+    AutoRegressiveStep, ModelRunner.run, LlamaForCausalLM at Llama-3.2-1B shapes, greedy AR, b = 1).  Only possible where
+    /root/reference exists (the build container); the GPU box falls back to the port below."""
+    import contextlib
+    import io
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    with contextlib.redirect_stdout(io.StringIO()):          # the reference prints every step
+        import make_golden as MG
+        r = MG.time_reference_ar(seconds=budget, threads=cores)
+    return {"value": round(r["tokens_per_s"], 3), "unit": "tokens/s", "cores": cores, "kind": "reference",
+            "sample": f"the reference's own engine classes (ssd.engine Scheduler / AutoRegressiveStep / ModelRunner.run, LlamaForCausalLM; "
+                      f"CUDA-only attention wheels replaced by the fp32 restatement), Llama-3.2-1B shapes (BASELINE configs[0]), greedy AR "
+                      f"b=1, 32-token prompt, {r['tokens']} output tokens after 3 untimed steps (torch.compile warm-up), ~{budget:.0f} s sample; "
+                      f"prefill {r['prefill_s']:.1f}s incl. compile"}
+
+
 def cpu_baseline():
-    """The oracle engine (reference modules restated on CPU) on a bounded sample of the workload:
-    Llama-3.2-1B shapes (the workload's draft model; BASELINE.json configs[0]), greedy AR decode, b=1 -> tokens/s
-    measured end to end; the 70B target does not fit host RAM, so no extrapolation is made -- a baseline, not a target."""
+    """The CPU path on a bounded sample of the workload: Llama-3.2-1B shapes (the workload's draft model; BASELINE.json
+    configs[0]), greedy AR decode, b=1 -> tokens/s.  kind "reference": the reference's own engine classes, when /root/reference
+    is importable; kind "port": the oracle engine (reference modules restated on CPU) otherwise (the GPU box).  The 70B target
+    does not fit host RAM, so no extrapolation is made -- a baseline, not a target."""
     import torch
+    # GEMV-shaped bf16 matmuls stop scaling (and then collapse) beyond a few tens of threads: on the 256-core
+    # GPU-box host, 256 threads ran ~1000x slower than 16.  Use at most 16 and report that number as `cores`.
+    cores = min(16, os.cpu_count() or 1)
+    budget = float(os.environ.get("SSD_BENCH_CPU_SECONDS", "12"))
+    if os.path.isdir("/root/reference/ssd") and os.environ.get("SSD_BENCH_CPU_KIND", "") != "port":
+        try:
+            return cpu_baseline_reference(cores, budget)
+        except Exception as e:          # fall through to the port; say why
+            print(f"[bench] reference CPU baseline unavailable ({e!r}); timing the port", file=sys.stderr)
     from oracle.runner import oracle_runner_factory
     from ssd_amd.engine.llm_engine import LLMEngine
     from ssd_amd.model_config import PRESETS
     from ssd_amd.sampling_params import SamplingParams
-    # GEMV-shaped bf16 matmuls stop scaling (and then collapse) beyond a few tens of threads: on the 256-core
-    # GPU-box host, 256 threads ran ~1000x slower than 16.  Use at most 16 and report that number as `cores`.
-    cores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     cfg = PRESETS["llama-3.2-1b"]
     from ssd_amd.utils.topology import Topology
@@ -281,16 +305,15 @@ def cpu_baseline():
     eng.step(step)                                  # prefill
     t1 = time.perf_counter()
     n = 0
-    budget = float(os.environ.get("SSD_BENCH_CPU_SECONDS", "12"))
     while not eng.is_finished() and (n < 4 or time.perf_counter() - t1 < budget):
         eng.step(step)
         n += 1
     wall = time.perf_counter() - t0
     dec = n / (time.perf_counter() - t1)
     return {"value": round(dec, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"oracle engine (CPU restatement of the reference), Llama-3.2-1B shapes (the workload's draft model; "
-                      f"BASELINE configs[0]), greedy AR b=1, 32-token prompt, {n} output tokens (time-bounded sample, ~12 s), bf16 weights; "
-                      f"end-to-end wall {wall:.1f}s incl. prefill; decode-only rate reported"}
+            "sample": f"oracle engine (CPU restatement of the reference; /root/reference is not present on this box), Llama-3.2-1B shapes "
+                      f"(the workload's draft model; BASELINE configs[0]), greedy AR b=1, 32-token prompt, {n} output tokens (time-bounded "
+                      f"sample, ~{budget:.0f} s), bf16 weights; end-to-end wall {wall:.1f}s incl. prefill; decode-only rate reported"}
 
 
 def main():

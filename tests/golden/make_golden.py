@@ -988,6 +988,74 @@ def gen_ref_engine():
         print("ref_engine", r)
 
 
+def time_reference_ar(seconds: float = 12.0, prompt_len: int = 32, max_tokens: int = 512, threads: int | None = None):
+    """The REFERENCE's own engine classes -- Scheduler, BlockManager, Sequence, AutoRegressiveStep, ModelRunner.run / run_model,
+    LlamaForCausalLM, Sampler -- decoding greedily on the host cores at Llama-3.2-1B shapes (BASELINE.json configs[0]: "1B
+    autoregressive greedy b=1 on the CPU reference path"), b = 1, random weights and a random prompt.  Same harness as
+    gen_ref_engine (a ModelRunner made without __init__: no CUDA, no process group; the CUDA-only attention wheels replaced by
+    the fp32 restatement of oracle/ref_shim.py).  Used by bench.py's cpu_baseline leg when /root/reference is present
+    (kind = "reference"); returns a dict with the decode rate."""
+    import time
+    import ssd.engine.model_runner as MRM
+    from collections import deque
+    from transformers import LlamaConfig
+    from ssd.engine.block_manager import BlockManager
+    from ssd.engine.scheduler import Scheduler
+    from ssd.engine.sequence import Sequence
+    from ssd.engine.step import AutoRegressiveStep
+    from ssd.sampling_params import SamplingParams
+    if threads:
+        torch.set_num_threads(threads)
+    real_tensor = torch.tensor
+    torch.tensor = lambda *a, **k: real_tensor(*a, **{x: y for x, y in k.items() if x != "pin_memory"})
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        bs, nblocks, max_len = 256, 4, 1024
+        cfg1b = LlamaConfig(hidden_size=2048, num_hidden_layers=16, num_attention_heads=32, num_key_value_heads=8, intermediate_size=8192,
+                            vocab_size=128256, max_position_embeddings=131072, rms_norm_eps=1e-5, tie_word_embeddings=False,
+                            hidden_act="silu", head_dim=64, rope_theta=500000.0)
+        t0 = time.perf_counter()
+        tm = build(LlamaForCausalLM, cfg1b, 7, 0.02)
+        t_build = time.perf_counter() - t0
+        cfg = types.SimpleNamespace(speculate=False, speculate_k=1, async_fan_out=1, MQ_LEN=1, draft_async=False, use_eagle=False,
+                                    jit_speculate=False, verbose=False, fan_out_list=[1], fan_out_list_miss=[1], d_model_target=2048,
+                                    max_blocks=max_len // bs, max_model_len=max_len, sampler_x=None, eagle_layers=None)
+        target = _bare_runner(MRM.ModelRunner, tm, cfg1b, cfg, False, bs, nblocks)
+        Sequence.block_size = bs
+        Sequence.counter = __import__("itertools").count()
+        sch = Scheduler.__new__(Scheduler)
+        sch.max_num_seqs, sch.max_num_batched_tokens, sch.max_model_len = 1, max_len, max_len
+        sch.eos, sch.speculate, sch.F, sch.K, sch.block_size, sch.verbose, sch.draft_async = -1, False, 1, 1, bs, False, False
+        sch.fan_out_list, sch.fan_out_list_miss, sch.MQ_LEN = [1], [1], 1
+        sch.block_manager = BlockManager(nblocks, bs, is_draft=False, max_model_len=max_len)
+        sch.waiting, sch.running = deque(), deque()
+        step = AutoRegressiveStep(sch, target, types.SimpleNamespace(decode=lambda ids, **k: ""))
+        g = torch.Generator().manual_seed(0)
+        prompt = torch.randint(0, 10000, (prompt_len,), generator=g).tolist()
+        seq = Sequence(prompt, SamplingParams(temperature=0.0, max_new_tokens=max_tokens, ignore_eos=True))
+        sch.add(seq)
+        t0 = time.perf_counter()
+        batch, is_prefill = sch.schedule()
+        assert is_prefill
+        step.prefill(batch)
+        t_pre = time.perf_counter()
+        for _ in range(3):              # the first decode steps pay torch.compile (the reference's norm / RoPE / SiLU kernels): untimed
+            batch, is_prefill = sch.schedule()
+            step.decode(batch)
+        t1 = time.perf_counter()
+        n = 0
+        while not sch.is_finished() and (n < 4 or time.perf_counter() - t1 < seconds):
+            batch, is_prefill = sch.schedule()
+            step.decode(batch)
+            n += 1
+        dt = time.perf_counter() - t1
+        return {"tokens_per_s": n / dt, "tokens": n, "prefill_s": t_pre - t0, "build_s": t_build, "threads": torch.get_num_threads(),
+                "first_tokens": [int(t) for t in seq.completion_token_ids[:8]]}
+    finally:
+        torch.tensor = real_tensor
+        del torch.Tensor.cuda
+
+
 def gen_eagle_loader():
     """ssd/utils/loader.py load_model -> load_eagle_model (:64-183) on a tiny Eagle3DraftForCausalLM: (a) a checkpoint that
     ships its own embed_tokens, (b) one that borrows the target's (same hidden size).  Inputs and resulting parameters."""
@@ -1299,6 +1367,9 @@ def gen_stochastic():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ops", "logic", "llama", "qwen", "eagle", "rounds", "loadertp", "eagleloader", "refengine", "engine", "scheduler", "stochastic"]
+    if "time_reference" in which:
+        print(time_reference_ar())
+        sys.exit(0)
     if "ops" in which:
         gen_ops()
     if "logic" in which:
