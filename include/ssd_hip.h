@@ -151,6 +151,17 @@ int ssd_attn_paged(const void* q_rows, const void* k_cache, const void* v_cache,
                    int tree_mq, int tree_step, int tree_F, const int32_t* tree_jidx, int splits, int flags,
                    void* ws_o, void* ws_ml, void* out_rows, void* out_frag, void* stream);
 
+/* Attention + o_proj in ONE launch for the single-GPU drafts' decode / glue forwards: flash_attn_with_kvcache
+ * (ssd/layers/attention.py:105-111,126-131) followed by RowParallelLinear o_proj (ssd/layers/linear.py:186-199, no all-reduce
+ * at tp = 1).  One sequence, T causal (bottom-right aligned) query rows; parts = fp32 slabs [nkv][T][N], slab h = o_proj
+ * restricted to the columns of kv head h's q heads: their sum over h is o_proj(attention output), consumed exactly like
+ * ssd_gemm_parts' slabs (ssd_gemm_fused_parts / ssd_rmsnorm_parts with splits = nkv).  T * (nh / nkv) <= 32 (hd 64) or 16
+ * (hd 128), (nh / nkv) * hd <= 256, N % 128 == 0, nkv <= 16; the whole context is scanned by the 8 waves of a workgroup (use
+ * it up to ~1 K keys). */
+int ssd_attn_oproj_parts(const void* q_rows, const void* k_cache, const void* v_cache, const int32_t* block_tables,
+                         int max_blocks, const int32_t* context_lens, int T, int nh, int nkv, int hd, int block_size,
+                         float scale, const void* w_o_frag, int N, void* parts, void* stream);
+
 /* LM head on the greedy path: F.linear + logits.argmax(-1) -- ssd/layers/embed_head.py:88-116 followed by
  * ssd/layers/sampler.py:15-20 / ssd/utils/verify.py:34.  ssd_gemm_wf_argmax writes the bf16 logits rows like ssd_gemm_wf
  * (M <= 32) AND, per workgroup, the (max value, lowest index) of each token row over the features that workgroup produced

@@ -102,11 +102,18 @@ def main():
                                                    tree_K=meta.tree_K, tree_mq=meta.tree_mq, tree_step=0, tree_F=1, tree_jidx=meta.tree_jidx,
                                                    splits=splits, flags=fl, ws_o=m.ws_o, ws_ml=m.ws_ml, out_frag=m.buf_af, waves=wv), L)
                 row(f"attention ctx={ctx} waves={wv}{' rt=1' if fl else ''}{' (default)' if wv == waves and not fl else ''}", us, 2 * ctx * m.nkv * m.hd * 2 / 1e6)
-        # whole forward (all layers + head + argmax), slab path on / off
+        # attention + o_proj in one launch (round 3) vs the two launches
+        if M <= 8:
+            for ctx in (150, 640):
+                r.d_ctx[:1].fill_(ctx)
+                us = timed(lambda li: H.attn_oproj_parts(m.buf_q, m.kv_cache[li, 0], m.kv_cache[li, 1], r.d_bt, m.max_blocks, r.d_ctx, M, m.nh,
+                                                         m.nkv, m.hd, m.block_size, m.hd ** -0.5, wo(li), h, m.buf_parts_o), L)
+                row(f"attention + o_proj fused, ctx={ctx}", us, mb_o)
+        # whole forward (all layers + head + argmax): slab path off / on, fused attention + o_proj off / on, fused argmax off / on
         r.d_ctx[:1].fill_(150)
         r._ctx_hint = 1024
-        for use in ((False, True) if M <= m.max_logit_rows else ()):
-            m.use_parts = use
+        for use, ao, am in (((False, False, True), (True, False, False), (True, False, True), (True, True, True)) if M <= m.max_logit_rows else ()):
+            m.use_parts, m.fuse_attn_o, m.argmax_fused = use, ao, am
             meta = AttnMeta(H.MODE_CAUSAL, 1, M, r.d_slots, r.d_ctx, r.d_bt, q_per_seq=M, ctx_hint=1024)
 
             def fwd(_):
@@ -114,14 +121,16 @@ def main():
                 m.compute_logits(M)
                 m.argmax(M, r.d_next)
             us = timed(fwd, 1, reps=20)
-            print(f"WHOLE FORWARD M={M} use_parts={use}: {us:9.1f} us   ({m.weight_bytes() / us * 1e-6:.2f} TB/s)", flush=True)
-        m.use_parts = True
+            print(f"WHOLE FORWARD M={M} slabs={use} attn+o fused={ao} argmax fused={am}: {us:9.1f} us   ({m.weight_bytes() / us * 1e-6:.2f} TB/s)", flush=True)
+        m.use_parts, m.fuse_attn_o, m.argmax_fused = True, True, True
     # the small ops
     print("---- small ops, M = 1 ----")
     row("embedding", timed(lambda li: H.embedding(r.d_ids, m.w["model.embed_tokens.weight"], m.buf_h, 1, h), 16), 0)
     row("final rmsnorm", timed(lambda li: H.rmsnorm(m.buf_h, m.w["model.norm.weight"], 1e-5, 1, h, res_in=m.buf_res, out_frag=m.buf_lastf), 16), 0)
     row("lm head", timed(lambda li: m._gemm(m.buf_lastf, h, m.w["lm_head.weight"], m.V, m.logits, 1, m.V), 4), m.V * h * 2 / 1e6)
     row("argmax V=128256", timed(lambda li: H.argmax_rows(m.logits, m.V, 1, m.V, r.d_next), 16), 0.25)
+    row("lm head + argmax candidates", timed(lambda li: m.compute_logits(1), 4), m.V * h * 2 / 1e6)
+    row("argmax from candidates", timed(lambda li: m.argmax(1, r.d_next), 16), 0.03)
 
 
 main()

@@ -36,6 +36,10 @@ struct AttnParams {
   int splits, use_tr, p_split;
   int bs_shift;              // log2(bs); block sizes are powers of two >= 16
   float scale_log2e;
+  // attention + o_proj in one launch (attn_kernel<.., OPROJ = true>, ssd_attn_oproj_parts below)
+  const u32x4_t* ow;         // o_proj weights, fragment-major [oN][nh*HD]
+  float* oparts;             // fp32 slabs [nkv][Tq][oN]: slab h = W_o[:, columns of kv head h's q heads] . attention output of those heads
+  int oN;
 };
 
 // LDS per wave: the V tile (32 keys x HD bf16) during the scan, then the wave's partial (O fp32 [RT*16][HD],
@@ -43,7 +47,14 @@ struct AttnParams {
 template <int HD, int RT>
 constexpr int attn_region_bytes() { return RT * 16 * HD * 4 + RT * 16 * 8; }
 
-template <int HD, int RT, int KT>
+// OPROJ (single sequence, <= 32 query rows per kv head, 8 waves, no grid key-splits): workgroup (kv head h, chunk c) of a
+// grid of nkv * (oN / 128) first puts its slice of the o_proj weights in flight -- 8 row groups x the G*HD columns of kv head
+// h's q heads, one row group per wave, <= 8 KiB per wave straight to VGPRs -- then computes the attention of kv head h exactly
+// as below (the oN / 128 workgroups of a head repeat it: its K/V pages sit in one XCD's L2, workgroup id % nkv = h), leaves the
+// normalised bf16 output of its heads in LDS as an MFMA B operand and multiplies: slab h of the split-K partial sums of
+// o_proj, summed by the consumer like ssd_gemm_parts' slabs.  The weight stream hides behind the attention latency chain and
+// one kernel boundary per layer disappears (a 1B draft decode layer: 6.6 us attention + 3.9 us o_proj as two launches).
+template <int HD, int RT, int KT, bool OPROJ = false>
 __global__ void __launch_bounds__(512) attn_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int DS = HD / 32;  // k-steps of QK^T
@@ -56,8 +67,15 @@ __global__ void __launch_bounds__(512) attn_kernel(const AttnParams p) {
   // grid = (B * nkv, row-tile groups, key splits): the (sequence, kv head) index is the FASTEST grid dimension, so with 8 kv
   // heads every workgroup of one kv head -- all the row tiles of a tree step / a prefill, all key splits -- is dispatched to the
   // same XCD (workgroup id % 8) and shares that head's K/V pages in ONE L2 instead of fetching them into eight
-  const int b = blockIdx.x / p.nkv, h = blockIdx.x % p.nkv;
+  const int b = OPROJ ? 0 : (int)(blockIdx.x / p.nkv), h = blockIdx.x % p.nkv;
   const int G = p.nh / p.nkv;
+  u32x4_t wreg[OPROJ ? 8 : 1];
+  if constexpr (OPROJ) {
+    const int KTo = (p.nh * HD) >> 5, KS = (G * HD) >> 5;                   // k-tiles of o_proj's K, of one kv head's slice (<= 8)
+    const u32x4_t* wp = p.ow + ((size_t)(((blockIdx.x / p.nkv) * 8 + wave) * KTo + h * KS) << 6) + lane;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) wreg[kt] = __builtin_nontemporal_load(wp + ((size_t)min(kt, KS - 1) << 6));   // clamped: unconditional loads
+  }
   const int q0 = p.cu_q ? p.cu_q[b] : b * p.q_per_seq;
   const int Tq = p.cu_q ? (p.cu_q[b + 1] - q0) : p.q_per_seq;
   const int rows = Tq * G;
@@ -356,7 +374,14 @@ __global__ void __launch_bounds__(512) attn_kernel(const AttnParams p) {
     }
     const int tok = q0 + rho / G, head = h * G + rho % G;
     const size_t row = (size_t)tok * p.nh + head;
-    if (p.splits == 1) {
+    if constexpr (OPROJ) {
+      // x[m = token][k = (q head within the group) * HD + d] as the B operand of the o_proj product: 16-byte chunk
+      // (k / 8, m), fragment-major within this kv head's K slice
+      const float inv = L > 0.f ? 1.0f / L : 0.f;
+      const u32x2_t v = {pack_bf2(acc[0] * inv, acc[1] * inv), pack_bf2(acc[2] * inv, acc[3] * inv)};
+      const int kl = (rho % G) * HD + d;
+      reinterpret_cast<u32x2_t*>(smem + (size_t)W * REGION)[(((kl >> 3) << 4) + rho / G) * 2 + ((kl >> 2) & 1)] = v;
+    } else if (p.splits == 1) {
       const float inv = L > 0.f ? 1.0f / L : 0.f;
       const u32x2_t v = {pack_bf2(acc[0] * inv, acc[1] * inv), pack_bf2(acc[2] * inv, acc[3] * inv)};
       if (p.out_rows) *reinterpret_cast<u32x2_t*>(p.out_rows + row * HD + d) = v;
@@ -370,6 +395,25 @@ __global__ void __launch_bounds__(512) attn_kernel(const AttnParams p) {
         p.ws_ml[(row * p.splits + z) * 2] = M;
         p.ws_ml[(row * p.splits + z) * 2 + 1] = L;
       }
+    }
+  }
+  if constexpr (OPROJ) {
+    __syncthreads();
+    // slab h of o_proj: this wave's row group x the K slice of kv head h, all k-tiles already in registers
+    const int KS = (G * HD) >> 5;
+    const u32x4_t* xl = reinterpret_cast<const u32x4_t*>(smem + (size_t)W * REGION);
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+      if (kt < KS) {          // block-uniform
+        u32x4_t xb = {0u, 0u, 0u, 0u};
+        if (r16 < Tq) xb = xl[((kt * 4 + g4) << 4) + r16];
+        acc = mfma16(wreg[kt], xb, acc);
+      }
+    }
+    if (r16 < Tq) {
+      const int n = ((blockIdx.x / p.nkv) * 8 + wave) * 16 + g4 * 4;
+      *reinterpret_cast<f32x4_t*>(p.oparts + ((size_t)h * Tq + r16) * p.oN + n) = acc;
     }
   }
 }
@@ -433,6 +477,49 @@ static int attn_launch(const AttnParams& p, int B, int T, int max_q, int waves, 
   return SSD_OK;
 }
 
+// Attention of ONE sequence's T query rows (causal, bottom-right aligned: single-token decode or a K+1-row glue / verify) fused
+// with o_proj: parts receives nkv fp32 slabs [nkv][T][N] whose sum over the slabs is o_proj(attention output) -- consumed like
+// ssd_gemm_parts' slabs (ssd_gemm_fused_parts / ssd_rmsnorm_parts with splits = nkv).  Replaces ssd_attn_paged + ssd_gemm_parts
+// (reference ssd/layers/attention.py:105-111,126-131 + ssd/layers/linear.py:186-199 o_proj) for the single-GPU drafts.
+// Constraints: T * (nh / nkv) <= 32 (hd 64) or <= 16 (hd 128); (nh / nkv) * hd <= 256; N % 128 == 0; nkv <= 16; context
+// within one launch (no grid key-splits: use it for context buckets <= 1024).
+extern "C" int ssd_attn_oproj_parts(const void* q_rows, const void* k_cache, const void* v_cache, const int32_t* block_tables,
+                                    int max_blocks, const int32_t* context_lens, int T, int nh, int nkv, int hd, int block_size,
+                                    float scale, const void* w_o_frag, int N, void* parts, void* stream) {
+  if (T <= 0 || nh <= 0 || nkv <= 0 || nh % nkv || nkv > 16) return SSD_ERR_SHAPE;
+  if (hd != 64 && hd != 128) return SSD_ERR_SHAPE;
+  const int G = nh / nkv, rows = T * G;
+  if (rows > (hd == 64 ? 32 : 16) || T > 16 || G * hd > 256 || ((G * hd) & 31) || N <= 0 || (N & 127)) return SSD_ERR_SHAPE;
+  if (block_size < 16 || (block_size & (block_size - 1)) != 0 || max_blocks <= 0) return SSD_ERR_SHAPE;
+  if (!w_o_frag || !parts) return SSD_ERR_ARG;
+  AttnParams p;
+  p.q = (const bf16_t*)q_rows; p.kc = (const bf16_t*)k_cache; p.vc = (const bf16_t*)v_cache;
+  p.block_tables = block_tables; p.context_lens = context_lens; p.cu_q = nullptr; p.tree_jidx = nullptr;
+  p.ws_o = nullptr; p.ws_ml = nullptr; p.out_rows = nullptr; p.out_frag = nullptr;
+  p.max_blocks = max_blocks; p.q_per_seq = T; p.nh = nh; p.nkv = nkv; p.bs = block_size;
+  p.bs_shift = __builtin_ctz(block_size);
+  p.mode = 0; p.tree_K = 0; p.tree_mq = 1; p.tree_step = 0; p.tree_F = 1;
+  p.splits = 1; p.use_tr = 1; p.p_split = 1;
+  p.scale_log2e = scale * 1.4426950408889634f;
+  p.ow = (const u32x4_t*)w_o_frag; p.oparts = (float*)parts; p.oN = N;
+  const dim3 grid(nkv * (N / 128), 1, 1), block(512);
+  hipStream_t st = (hipStream_t)stream;
+  const int rt = rows > 16 ? 2 : 1;
+#define AO_LAUNCH(HDV, RTV)                                                                                          \
+  do {                                                                                                               \
+    const int lds = 8 * attn_region_bytes<HDV, RTV>() + 16 * 256 * 2;                                               \
+    auto kern = attn_kernel<HDV, RTV, 1, true>;                                                                      \
+    if (lds > 64 * 1024 &&                                                                                           \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) \
+      return SSD_ERR_LAUNCH;                                                                                         \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, p);                                                               \
+  } while (0)
+  if (hd == 64) { if (rt == 2) AO_LAUNCH(64, 2); else AO_LAUNCH(64, 1); }
+  else AO_LAUNCH(128, 1);
+#undef AO_LAUNCH
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
 extern "C" int ssd_attn_paged(const void* q_rows, const void* k_cache, const void* v_cache,
                               const int32_t* block_tables, int max_blocks, const int32_t* context_lens,
                               const int32_t* cu_q, int q_per_seq, int B, int T, int max_q, int nh, int nkv, int hd,
@@ -455,6 +542,7 @@ extern "C" int ssd_attn_paged(const void* q_rows, const void* k_cache, const voi
   p.mode = mode; p.tree_K = tree_K; p.tree_mq = tree_mq; p.tree_step = tree_step; p.tree_F = tree_F;
   p.splits = splits; p.use_tr = (flags & 1) ? 0 : 1; p.p_split = (flags & 2) ? 0 : 1;
   p.scale_log2e = scale * 1.4426950408889634f;
+  p.ow = nullptr; p.oparts = nullptr; p.oN = 0;
   hipStream_t st = (hipStream_t)stream;
   // flags bits 8..11: waves per workgroup that split the key range and merge in LDS (default 1; 1..8)
   int waves = (flags >> 8) & 0xf;

@@ -6,7 +6,7 @@ Reference: the use_eagle branches of ssd/engine/draft_runner.py -- :72-101 prefi
 chain (fc of the recovery activation, then self-conditioning), :538-612 the variable-length glue over
 [extend | recovery | spec] rows, :660-676 tree hidden states from the glue prenorms, :734-750 per-step prenorm hand-over
 and the cached branch activations.  The JIT chain and the K tree steps are single hipGraphs like their non-EAGLE
-counterparts; the glue has a data-dependent row count and runs eagerly (one layer: a dozen launches).
+counterparts, and so is the glue: its data-dependent row count is padded to B*(2K+1) rows with ghost rows (round 3).
 """
 from __future__ import annotations
 
@@ -53,6 +53,10 @@ class EagleDraftRunner(ModelRunner):
         self.d_cond_idx = torch.zeros(rows, dtype=torch.int64, **dev)                     # row of d_glue_pre that seeds each branch
         self.d_idx = {n: torch.zeros(self.max_decode_tokens, dtype=torch.int64, **dev) for n in ("tc_src", "tc_dst", "sp_dst", "kp1")}
         self.d_gather32 = torch.zeros(B * (K + 1), dtype=torch.int32, **dev)
+        # static inputs of the glue hipGraph
+        self.d_glue_ids = torch.zeros(B, K + 1, dtype=torch.int64, **dev)
+        self.d_prev_acts = torch.zeros(B * K, m.h, dtype=torch.bfloat16, **dev)
+        self.d_gathered = torch.zeros(B * (K + 1), m.A, dtype=torch.bfloat16, **dev)
 
     # ---- prefill: token j (of the already shifted prompt) is conditioned on fc(target activation of position j-1) ----
     @torch.inference_mode()
@@ -117,33 +121,47 @@ class EagleDraftRunner(ModelRunner):
             ids.extend(list(ext_ids[b][:counts[b]]) + [0] * (K + 1))
             slots.extend(self._slot(tb, p) for p in pos[cu[b]:cu[b + 1]])
         T, n_tc = cu[-1], len(tc_src)
-        assert T <= self.max_decode_tokens
-        self._upload(self.d_ids, ids, torch.int64)
-        self._upload(self.d_pos, pos, torch.int64)
-        self._upload(self.d_slots, slots, torch.int32)
+        # The row count is data dependent (B*(K+1) .. B*(2K+1)); the launch geometry is not: the forward always runs over
+        # T_pad = B*(2K+1) rows -- ghost rows behind the packed ones carry token 0, slot -1 (nothing stored) and belong to no
+        # sequence of cu_q (attention skips them) -- and every index list is padded to its maximum with entries that move row 0
+        # into a scratch row.  The whole glue (conditioning gather + fc, one layer, head, prenorm gather, fork) then replays as
+        # ONE hipGraph like the other draft graphs (the reference captures it too, cudagraph_helpers.py:636-774).
+        T_pad, NK = B * (2 * K + 1), B * (K + 1)
+        dump = T_pad                                   # scratch row of buf_cond behind the padded rows
+        assert T <= T_pad < m.buf_cond.shape[0] and T_pad <= self.max_decode_tokens
+        self._upload(self.d_ids, ids + [0] * (T_pad - T), torch.int64)
+        self._upload(self.d_pos, pos + [0] * (T_pad - T), torch.int64)
+        self._upload(self.d_slots, slots + [-1] * (T_pad - T), torch.int32)
         self._upload(self.d_ctx, [n + K for n in num_tokens], torch.int32)
         self._upload(self.d_cu_q, cu, torch.int32)
         self._upload_tables(tables)
-        for name, vals in (("tc_src", tc_src), ("tc_dst", tc_dst), ("sp_dst", sp_dst), ("kp1", kp1)):
+        pad = NK - n_tc
+        for name, vals in (("tc_src", tc_src + [0] * pad), ("tc_dst", tc_dst + [dump] * pad), ("sp_dst", sp_dst), ("kp1", kp1)):
             self._upload(self.d_idx[name], vals, torch.int64)
         self._upload(self.d_gather32, kp1, torch.int32)
         fl = [list(f) for f in fan_lists]
         self._upload(self.d_fan, fl, torch.int32)
         self._upload(self.d_fan_off, [[sum(f[:j]) for j in range(len(f))] for f in fl], torch.int32)
-        kp1_d = self.d_idx["kp1"][:B * (K + 1)]
-        # token ids: extend tokens came from the host, [recovery | spec] from the reply that is still on the device
-        self.d_ids.index_copy_(0, kp1_d, glue_ids.reshape(-1))
-        # conditioning rows: ONE fc over every target-conditioned row (draft_runner.py:586-587), previous prenorms on the spec rows
-        self.d_acts_in[:B * (K + 1)].copy_(eagle["acts"].reshape(B * (K + 1), -1))
-        gathered = self.d_acts_in.index_select(0, self.d_idx["tc_src"][:n_tc])
-        m.project(gathered, n_tc, self.d_tc)
-        m.buf_cond.index_copy_(0, self.d_idx["tc_dst"][:n_tc], self.d_tc[:n_tc])
-        m.buf_cond.index_copy_(0, self.d_idx["sp_dst"][:B * K], eagle["prev_acts"].reshape(B * K, -1))
-        max_q = max(counts) + K + 1
-        m.forward(self.d_ids, self.d_pos, T, self._meta("prefill", B, max_q))
-        m.compute_logits(T, gather=self.d_gather32, rows=B * (K + 1))           # only the K+1 [recovery | spec] rows feed the fork
-        torch.index_select(m.buf_pre, 0, kp1_d, out=self.d_glue_pre[:B * (K + 1)])
-        H.fork_topf(m.logits, m.V, m.V, glue_ids.contiguous(), self.d_fan, self.d_fan_off, B, K, self.mq, self.d_forks)
+        # device-resident inputs of the round, copied into the graph's static buffers
+        self.d_glue_ids[:B].copy_(glue_ids)
+        self.d_acts_in[:NK].copy_(eagle["acts"].reshape(NK, -1))
+        self.d_prev_acts[:B * K].copy_(eagle["prev_acts"].reshape(B * K, -1))
+
+        def body():
+            kp1_d = self.d_idx["kp1"][:NK]
+            # token ids: extend tokens came from the host, [recovery | spec] from the reply that is still on the device
+            self.d_ids.index_copy_(0, kp1_d, self.d_glue_ids[:B].reshape(-1))
+            # conditioning rows: ONE fc over every target-conditioned row (draft_runner.py:586-587), previous prenorms on the spec rows
+            torch.index_select(self.d_acts_in, 0, self.d_idx["tc_src"][:NK], out=self.d_gathered[:NK])
+            m.project(self.d_gathered, NK, self.d_tc)
+            m.buf_cond.index_copy_(0, self.d_idx["tc_dst"][:NK], self.d_tc[:NK])
+            m.buf_cond.index_copy_(0, self.d_idx["sp_dst"][:B * K], self.d_prev_acts[:B * K])
+            m.forward(self.d_ids, self.d_pos, T_pad, self._meta("prefill", B, 2 * K + 1))
+            m.compute_logits(T_pad, gather=self.d_gather32, rows=NK)            # only the K+1 [recovery | spec] rows feed the fork
+            torch.index_select(m.buf_pre, 0, kp1_d, out=self.d_glue_pre[:NK])
+            H.fork_topf(m.logits, m.V, m.V, self.d_glue_ids[:B], self.d_fan, self.d_fan_off, B, K, self.mq, self.d_forks)
+
+        self._launch(("eagle_glue", B), body)       # "captured": the eager warm-up run already produced this call's result
         return self.d_forks[:B].clone()
 
     # ---- tree: branch i starts from the glue prenorm of its position j_i, then conditions on its own previous step ----

@@ -44,6 +44,8 @@ SIGNATURES = {
     "ssd_attn_paged": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                        c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int,
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "ssd_attn_oproj_parts": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                             c_void_p, c_int, c_void_p, c_void_p],
     "ssd_gemm_wf_argmax_parts": [c_int, c_int, c_int],
     "ssd_gemm_wf_argmax": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "ssd_argmax_parts": [c_void_p, c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p],

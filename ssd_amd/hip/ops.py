@@ -146,6 +146,13 @@ def attn_paged(q_rows, k_cache, v_cache, block_tables, max_blocks, context_lens,
                                          _p(ws_o), _p(ws_ml), _p(out_rows), _p(out_frag), _stream()), "ssd_attn_paged")
 
 
+def attn_oproj_parts(q_rows, k_cache, v_cache, block_tables, max_blocks: int, context_lens, T: int, nh: int, nkv: int, hd: int,
+                     block_size: int, scale: float, w_o_frag, N: int, parts):
+    """One sequence's decode / glue attention fused with o_proj: fp32 slabs [nkv][T][N] (csrc/attention.hip OPROJ variant)."""
+    _check(load_library().ssd_attn_oproj_parts(_p(q_rows), _p(k_cache), _p(v_cache), _p(block_tables), max_blocks, _p(context_lens), T, nh,
+                                               nkv, hd, block_size, scale, _p(w_o_frag), N, _p(parts), _stream()), "ssd_attn_oproj_parts")
+
+
 def gemm_argmax_nparts(M: int, N: int, K: int) -> int:
     """Candidates per token row that gemm_argmax writes for this shape (= its workgroups); host-side query."""
     n = load_library().ssd_gemm_wf_argmax_parts(M, N, K)

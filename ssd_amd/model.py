@@ -102,6 +102,7 @@ class HipDecoder:
         # 256 or >= 512 groups the rows kernels are as fast or faster)
         g_ = self.h // 16
         self.use_parts = os.environ.get("SSD_PARTS", "1") != "0" and (g_ < 256 or 256 < g_ < 512)
+        self.fuse_attn_o = os.environ.get("SSD_FUSE_ATTN_O", "1") != "0"
         self._last_parts = False        # set by forward() for the compute_logits that follows it
         pt = min(T, 32)
         self.buf_parts_o = z(16 * pt * self.h, dtype=torch.float32) if self.use_parts else None
@@ -284,6 +285,14 @@ class HipDecoder:
         decode-sized T (the draft's chain / glue / tree forwards)."""
         return self.use_parts and not self.use_coll and T <= 32
 
+    def attn_o_plan(self, T: int, meta: AttnMeta, splits: int) -> bool:
+        """Attention + o_proj as ONE launch (csrc/attention.hip OPROJ variant): single-rank models on the slab path, one
+        sequence, causal decode / glue rows, context scanned inside one workgroup (bucket <= 1024)."""
+        G = self.nh // self.nkv
+        return (self.fuse_attn_o and self.parts_plan(T) and meta.mode == H.MODE_CAUSAL and meta.cu_q is None and meta.B == 1
+                and splits == 1 and T <= 16 and T * G <= (32 if self.hd == 64 else 16) and G * self.hd <= 256
+                and self.h % 128 == 0 and self.nkv <= 16)
+
     # ---- the four GEMM launches of a layer (also used one by one by bench.py's roofline timing) ----
     def fusion_plan(self, T: int) -> tuple[bool, bool]:
         """(small, norm_fuse).  T <= 16: RoPE + KV store ride the QKV epilogue (csrc/gemm_fused.hip).  The residual
@@ -341,20 +350,23 @@ class HipDecoder:
         else:
             self._gemm(self.buf_af, self.qn, w, self.h, self.buf_h, T, self.h)
 
-    def launch_gate_up(self, li: int, T: int, gemm_only: bool = False, pre_normed: bool = False, parts: bool | None = None) -> None:
+    def launch_gate_up(self, li: int, T: int, gemm_only: bool = False, pre_normed: bool = False, parts: bool | None = None,
+                       o_splits: int | None = None) -> None:
+        """o_splits: slabs o_proj left in buf_parts_o (default: the split-K GEMM's; the fused attention + o_proj leaves nkv)."""
         cfg, w = self.cfg, self.w
         p = f"model.layers.{li}."
         _, norm_fuse = self.fusion_plan(T)
         parts = self.parts_plan(T) if parts is None else parts      # o_proj left fp32 partial slabs
+        So = o_splits if o_splits is not None else (self._parts("o", T)[0] if parts else 1)
         if norm_fuse:
-            src = dict(h_parts=self.buf_parts_o, splits=self._parts("o", T)[0]) if parts else dict(h_rows=self.buf_h)
+            src = dict(h_parts=self.buf_parts_o, splits=So) if parts else dict(h_rows=self.buf_h)
             H.gemm_fused(w[p + "mlp.gate_up_proj.weight"], T, 2 * self.I, self.h, H.FEPI_SILU_FRAG,
                          res_in=self.buf_res2, res_out=self.buf_res, norm_w=w[p + "post_attention_layernorm.weight"],
                          eps=cfg.rms_norm_eps, y=self.buf_actf, waves=8, **src)     # profiles/micro/fused_probe.py: 13.2 us vs 16.4 (16 waves)
         else:
             if not gemm_only and not pre_normed:
                 if parts:
-                    H.rmsnorm_parts(self.buf_parts_o, self._parts("o", T)[0], T, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps,
+                    H.rmsnorm_parts(self.buf_parts_o, So, T, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps,
                                     T, self.h, res_in=self.buf_res, res_out=self.buf_res, out_frag=self.buf_xf)
                 else:
                     H.rmsnorm(self.buf_h, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps, T, self.h,
@@ -382,6 +394,7 @@ class HipDecoder:
         # in the same Python body, must know whether the last down_proj left rows or partial slabs
         parts = self.parts_plan(T) and meta.cu_q is None
         self._fwd_T, self._last_parts = T, parts
+        fuse_ao = parts and self.attn_o_plan(T, meta, splits)
         # tensor parallel with the one-shot collective: the all-reduce after o_proj / down_proj absorbs the residual add
         # and the RMSNorm that follow it (csrc/comm.hip), 2 launches fewer per half layer
         ar = self.custom_ar
@@ -395,17 +408,22 @@ class HipDecoder:
                 src = self.buf_res2 if self.fusion_plan(T)[1] else res
                 i = self.taps.index(li)
                 self.acts[:T, i * self.h:(i + 1) * self.h].copy_(src[:T])
-            H.attn_paged(self.buf_q, self.kv_cache[li, 0], self.kv_cache[li, 1], meta.block_tables, self.max_blocks,
-                         meta.context_lens, meta.B, T, meta.max_q, self.nh, self.nkv, self.hd, self.block_size, scale,
-                         cu_q=meta.cu_q, q_per_seq=meta.q_per_seq, mode=meta.mode, tree_K=meta.tree_K, tree_mq=meta.tree_mq,
-                         tree_step=meta.tree_step, tree_F=meta.tree_F, tree_jidx=meta.tree_jidx, splits=splits,
-                         ws_o=self.ws_o, ws_ml=self.ws_ml, out_frag=self.buf_af, waves=attn_waves)
-            self.launch_o(li, T, parts=parts)
+            if fuse_ao:
+                H.attn_oproj_parts(self.buf_q, self.kv_cache[li, 0], self.kv_cache[li, 1], meta.block_tables, self.max_blocks,
+                                   meta.context_lens, T, self.nh, self.nkv, self.hd, self.block_size, scale,
+                                   w[f"model.layers.{li}.self_attn.o_proj.weight"], self.h, self.buf_parts_o)
+            else:
+                H.attn_paged(self.buf_q, self.kv_cache[li, 0], self.kv_cache[li, 1], meta.block_tables, self.max_blocks,
+                             meta.context_lens, meta.B, T, meta.max_q, self.nh, self.nkv, self.hd, self.block_size, scale,
+                             cu_q=meta.cu_q, q_per_seq=meta.q_per_seq, mode=meta.mode, tree_K=meta.tree_K, tree_mq=meta.tree_mq,
+                             tree_step=meta.tree_step, tree_F=meta.tree_F, tree_jidx=meta.tree_jidx, splits=splits,
+                             ws_o=self.ws_o, ws_ml=self.ws_ml, out_frag=self.buf_af, waves=attn_waves)
+                self.launch_o(li, T, parts=parts)
             if fuse:
                 ar.all_reduce_add_rmsnorm(h, res, res, w[f"model.layers.{li}.post_attention_layernorm.weight"], eps, T, self.h, out_frag=xf)
             else:
                 self._allreduce(h[:T])
-            self.launch_gate_up(li, T, pre_normed=fuse, parts=parts)
+            self.launch_gate_up(li, T, pre_normed=fuse, parts=parts, o_splits=self.nkv if fuse_ao else None)
             self.launch_down(li, T, parts=parts)
             if fuse and li + 1 < L:
                 ar.all_reduce_add_rmsnorm(h, res, res, w[f"model.layers.{li + 1}.input_layernorm.weight"], eps, T, self.h, out_frag=xf)

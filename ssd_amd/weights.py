@@ -109,6 +109,22 @@ def _pair_tensor(name: str, shape, seed: int, std: float, gen_device: str, recip
     return None
 
 
+def peaky_rows(recipe: dict) -> tuple[torch.Tensor, torch.Tensor]:
+    """(draft-vocabulary ids, target-vocabulary ids) of the few tokens whose LM-head rows the "peaky" recipe scales in BOTH a
+    target and its EAGLE-3 draft.  Random models never agree, and without agreement the speculation-cache hit path, partial
+    acceptance and the extend rows of the EAGLE glue never run; with both heads favouring the same few tokens each model picks
+    one of them most of the time and the same one about a third of the time (tests/eagle_util.py uses the same construction).
+    The target ids are the draft ids pushed through the draft's d2t map, which is a function of (draft seed, vocabularies)."""
+    Vd, V = int(recipe["draft_vocab"]), int(recipe["target_vocab"])
+    gc = torch.Generator()
+    gc.manual_seed(_name_seed(int(recipe["draft_seed"]), "d2t"))
+    tgt = torch.randperm(V, generator=gc)[:Vd].sort().values          # = arange(Vd) + d2t of synthetic_tensor("d2t", ...)
+    gp = torch.Generator()
+    gp.manual_seed(int(recipe.get("seed", 99)))
+    picks = torch.randperm(Vd, generator=gp)[:int(recipe.get("peaks", 3))]
+    return picks, tgt[picks]
+
+
 def synthetic_tensor(name: str, shape, seed: int, std: float, gen_device: str, norm_jitter: float = 0.0,
                      recipe: dict | None = None) -> torch.Tensor:
     """Full (unsharded) synthetic parameter.  gen_device="cpu" gives values reproducible on any machine (tests,
@@ -130,7 +146,12 @@ def synthetic_tensor(name: str, shape, seed: int, std: float, gen_device: str, n
         if norm_jitter == 0.0:
             return torch.ones(shape, dtype=BF16, device=gen_device)
         return (1.0 + norm_jitter * torch.randn(shape, generator=g, device=gen_device, dtype=torch.float32)).to(BF16)
-    return (std * torch.randn(shape, generator=g, device=gen_device, dtype=torch.float32)).to(BF16)
+    t = std * torch.randn(shape, generator=g, device=gen_device, dtype=torch.float32)
+    if recipe is not None and recipe.get("kind") == "peaky" and name == "lm_head.weight":
+        dpicks, tpicks = peaky_rows(recipe)
+        rows = dpicks if shape[0] == int(recipe["draft_vocab"]) else tpicks
+        t[rows.to(t.device)] *= float(recipe.get("gain", 6.0))
+    return t.to(BF16)
 
 
 def shard_param(cfg: ModelConfig, name: str, w: torch.Tensor, rank: int, tp: int) -> torch.Tensor:
@@ -157,6 +178,8 @@ def synthetic_weights(cfg: ModelConfig, seed: int, std: float, rank: int = 0, tp
     if cfg.family == "eagle3":          # d2t needs the target vocabulary size; the draft is never tensor-parallel
         assert tp == 1
         recipe = dict(recipe or {}, target_vocab=cfg.vocab_size)
+        if recipe.get("kind") == "peaky":
+            assert int(recipe["draft_seed"]) == seed and int(recipe["draft_vocab"]) == cfg.draft_vocab_size, "peaky recipe: draft seed / vocabulary mismatch"
     for name, shape in param_shapes(cfg):
         w = shard_param(cfg, name, synthetic_tensor(name, shape, seed, std, gen_device, norm_jitter, recipe), rank, tp)
         yield name, (w.to(out_device) if out_device is not None else w)

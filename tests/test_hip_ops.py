@@ -637,3 +637,26 @@ def test_cache_lookup_equals_the_tensor_compare_of_the_reference(H):
     out = torch.full((len(keys),), -5, dtype=torch.int32, device="cuda")
     H.cache_lookup(req, dev(seq), dev(cj), dev(forks), len(keys), Bc, W, out)
     assert out.cpu().tolist() == want
+
+
+def test_attn_long_context_prefill_and_decode(H):
+    """Above the contexts the other tests reach (max_model_len allows 8 K prompts): a 6000-token causal prefill through the
+    page table (KV block 256, 8 waves per workgroup, two row tiles per workgroup) and, on the same cache, a 7-row verify and a
+    single-token decode at context 6000 with 12 grid key-splits + the merge kernel -- against the fp32 oracle
+    (reference ssd/layers/attention.py:90-93,105-111,126-131)."""
+    nh, nkv, hd, bs = 4, 1, 128, 256
+    L = 6000
+    kc, vc, bt, mb = make_paged(1, [L], nkv, hd, bs, seed=21)
+    torch.manual_seed(3)
+    q = torch.randn(L, nh, hd).to(BF)
+    cu = torch.tensor([0, L], dtype=torch.int32)
+    ctx = torch.tensor([L], dtype=torch.int32)
+    ref = O.attn_paged(q, kc, vc, ctx, bt, hd ** -0.5, cu_q=cu).reshape(L, nh * hd)
+    got = run_attn(H, q.view(L, -1), kc, vc, bt, mb, ctx, nh, nkv, hd, bs, cu_q=cu, splits=1, flags=8 << 8)
+    assert_close_bf16(got, ref, what="prefill 6000", **ATTN_TOL)
+    for qps, splits in ((7, 12), (1, 12), (1, 1)):
+        qd = q[:qps].contiguous()
+        cud = torch.tensor([0, qps], dtype=torch.int32)
+        refd = O.attn_paged(qd, kc, vc, ctx, bt, hd ** -0.5, cu_q=cud).reshape(qps, nh * hd)
+        gotd = run_attn(H, qd.view(qps, -1), kc, vc, bt, mb, ctx, nh, nkv, hd, bs, q_per_seq=qps, splits=splits, flags=8 << 8)
+        assert_close_bf16(gotd, refd, what=f"ctx 6000 q{qps} splits{splits}", **ATTN_TOL)
