@@ -129,6 +129,7 @@ def main():
     row("final rmsnorm", timed(lambda li: H.rmsnorm(m.buf_h, m.w["model.norm.weight"], 1e-5, 1, h, res_in=m.buf_res, out_frag=m.buf_lastf), 16), 0)
     row("lm head", timed(lambda li: m._gemm(m.buf_lastf, h, m.w["lm_head.weight"], m.V, m.logits, 1, m.V), 4), m.V * h * 2 / 1e6)
     row("argmax V=128256", timed(lambda li: H.argmax_rows(m.logits, m.V, 1, m.V, r.d_next), 16), 0.25)
+    m._last_parts = False
     row("lm head + argmax candidates", timed(lambda li: m.compute_logits(1), 4), m.V * h * 2 / 1e6)
     row("argmax from candidates", timed(lambda li: m.argmax(1, r.d_next), 16), 0.03)
 

@@ -294,6 +294,17 @@ class LLMEngine:
                     if cur > prev:
                         stream_callback(seq.seq_id, seq.completion_token_ids[prev:cur])
                         streamed[seq.seq_id] = cur
+                    elif (cur == 0 and prev == 0 and self.config.speculate and seq.recovery_token_id is not None
+                          and seq.temperature == 0):
+                        # Speculative modes keep the token a prefill produced as the sequence's "recovery token" and append it
+                        # at the START of the next speculation round (reference speculator_sync.py:33-36 / speculator_async.py:
+                        # 118-124) -- unconditionally, so it IS the first output token.  Hand it to the stream now instead of one
+                        # whole draft + verify round later (the reference's loop streams it then: its TTFT = prefill + first
+                        # round).  The token is pinned: should the sequence be preempted and prefilled again before that
+                        # round, Verifier.prefill keeps it (a re-prefill may flip a near-tie).
+                        seq.first_token_streamed = seq.recovery_token_id
+                        stream_callback(seq.seq_id, [seq.recovery_token_id])
+                        streamed[seq.seq_id] = 1
             for seq_id, token_ids in finished:
                 if stream_callback:
                     prev = streamed.get(seq_id, 0)

@@ -27,7 +27,8 @@ class Verifier(VerifierBase):
             acts = self.target_model_runner.eagle_acts(sum(len(s) for s in seqs)).clone()
         off = 0
         for seq, tok in zip(seqs, token_ids):
-            seq.recovery_token_id = tok
+            pinned = getattr(seq, "first_token_streamed", None)      # already handed to the stream (LLMEngine.generate)
+            seq.recovery_token_id = tok if (pinned is None or seq.num_completion_tokens > 0) else pinned
             if eagle:
                 off += len(seq)
                 seq.last_target_hidden_state = acts[off - 1]

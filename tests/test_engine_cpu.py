@@ -41,11 +41,18 @@ def _sd(g, tag):
     eng = LLMEngine("tiny", hf_config=mcfg(g, "t_"), draft="tiny-draft", draft_hf_config=cfg_d, speculate=True, speculate_k=K,
                     runner_factory=oracle_runner_factory(wt, wd), **COMMON)
     want = g[f"sd_{tag}_tokens"].tolist()
-    streamed = []
+    streamed, rounds_at_first = [], []
+    from ssd_amd.engine.llm_engine import METRICS
+
+    def on_tokens(sid, toks):
+        if not streamed:
+            rounds_at_first.append(len(METRICS["accepted_suffix_lens_with_recovery"]))
+        streamed.extend(toks)
     out, metrics = eng.generate([g["prompt"].tolist()], SamplingParams(temperature=0, max_new_tokens=len(want), ignore_eos=True),
-                                use_tqdm=False, stream_callback=lambda sid, toks: streamed.extend(toks))
+                                use_tqdm=False, stream_callback=on_tokens)
     assert out[0]["token_ids"] == want
     assert streamed == want
+    assert rounds_at_first == [0], "the prefill's token must reach the stream before the first speculation round"
     lens = metrics["accepted_suffix_lens_with_recovery"]
     ref_lens = [(row >= 0).sum().item() for row in g[f"sd_{tag}_suffix"]]
     assert lens == ref_lens

@@ -410,7 +410,10 @@ def test_full_size_1b_speculation_is_exact(gpu):
     # every difference from the autoregressive stream must sit on a near-tie of the autoregressive run itself
     assert_stream_matches(s, a, ar_margins, len(prompt), what="1B sync SD vs AR")
     assert_stream_matches(y, a, ar_margins, len(prompt), what="1B async SSD vs AR")
-    assert sum(lens1[:-1]) / max(1, len(lens1) - 1) >= K and sum(lens2[:-1]) / max(1, len(lens2) - 1) >= K
+    # draft == target: every round is fully accepted -- except where the single-token draft forward and the (K+1)-row verify
+    # forward, whose GEMMs sum in different orders, land on opposite sides of a near-tie (the streams were checked against the
+    # autoregressive margins above): at most one such round in a run this short
+    assert sum(1 for n in lens1[:-1] if n < K + 1) <= 1 and sum(1 for n in lens2[:-1] if n < K + 2) <= 1, (lens1, lens2)
 
 
 def test_long_generation_crosses_context_buckets(gpu):
