@@ -93,7 +93,7 @@ class BlockManager:
             # a sequence whose EVERY block is cached (a preempted sequence of exactly n * block_size tokens coming back) would
             # leave nothing to prefill and no logits to sample from -- the reference schedules that empty prefill
             # (block_manager.py:99-127, scheduler.py:69-86); here the last full block is recomputed instead (same KV values)
-            whole_seq_cached = i == seq.num_blocks - 1 and len(toks) == self.block_size
+            whole_seq_cached = i == seq.num_blocks - 1 and len(toks) == self.block_size and not missed      # every block before it hit
             if hit == -1 or self.blocks[hit].token_ids != toks or whole_seq_cached:
                 missed = True
             if missed:

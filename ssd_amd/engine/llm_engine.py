@@ -93,6 +93,7 @@ class LLMEngine:
         factory = runner_factory or hip_runner_factory
 
         self.draft_runner = None
+        self._capped_ids: set[int] = set()
         self._target_stream = None
         self.async_link = None
         self.draft_server = None
@@ -181,7 +182,10 @@ class LLMEngine:
                 return self.step(step)
         t = perf_counter()
         seqs, is_prefill = self.scheduler.schedule()
-        capped = [(s.seq_id, s.completion_token_ids) for s in self.scheduler.pop_capped()]     # stopped at max_model_len
+        capped = []
+        for s in self.scheduler.pop_capped():          # stopped at max_model_len (Scheduler._length_capped)
+            capped.append((s.seq_id, s.completion_token_ids))
+            self._capped_ids.add(s.seq_id)
         if not seqs:            # every runnable sequence was one of those
             return capped
         n = step.prefill(seqs) if is_prefill else step.decode(seqs)
@@ -319,7 +323,10 @@ class LLMEngine:
         for seq_id in sorted(outputs):
             toks = outputs[seq_id]
             text = self.tokenizer.decode(toks) if self.tokenizer is not None else ""
-            result.append({"text": text, "token_ids": toks})
+            # finish_reason (beyond the reference's two keys): "max_model_len" marks a request the scheduler had to stop before
+            # max_new_tokens / EOS because its next speculation step would not fit the model length
+            result.append({"text": text, "token_ids": toks,
+                           "finish_reason": "max_model_len" if seq_id in self._capped_ids else "stop"})
         if not stream_callback and self.config.verbose:
             self.log_metrics()
         return result, METRICS

@@ -42,6 +42,7 @@ class Scheduler:
                                                     speculate_k=self.K, max_model_len=self.max_model_len, prefix_cache=pc)
         self.waiting: deque[Sequence] = deque()
         self.running: deque[Sequence] = deque()
+        self._warned_cap = False
         self.capped: list[Sequence] = []        # finished by schedule() itself: see _length_capped
 
     def is_finished(self) -> bool:
@@ -118,6 +119,13 @@ class Scheduler:
         if seq.num_tokens + need <= self.max_model_len:
             return False
         seq.status = SequenceStatus.FINISHED
+        seq.finish_reason = "max_model_len"          # not max_new_tokens / EOS: the caller can tell a capped request from a complete one
+        if not self._warned_cap:
+            self._warned_cap = True
+            import sys
+            print(f"[ssd_amd] a request was finished at {seq.num_tokens} tokens: its next step would reserve {need} positions past "
+                  f"max_model_len = {self.max_model_len} (speculation lookahead); raise max_model_len to generate further",
+                  file=sys.stderr, flush=True)
         self.block_manager.deallocate(seq)
         if self.speculate:
             self.draft_block_manager.deallocate(seq)

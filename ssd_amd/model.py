@@ -102,6 +102,14 @@ class HipDecoder:
         # 256 or >= 512 groups the rows kernels are as fast or faster)
         g_ = self.h // 16
         self.use_parts = os.environ.get("SSD_PARTS", "1") != "0" and (g_ < 256 or 256 < g_ < 512)
+        # ssd_gemm_parts keeps a wave's whole K share in registers: <= 8 k-tiles per wave.  A shape whose (splits, waves) plan
+        # cannot meet that (e.g. h = 3072 with I = 14336 under the two-slab fused consumer) runs the rows kernels instead
+        def fits(N, K, fused):
+            S, wv = self._parts_cfg(N, K, fused)
+            return -(-(-(-(K // 32) // S)) // wv) <= 8
+        fused_possible = (not cfg.qk_norm) and self.h // 8 <= 1024          # fusion_plan(): the norm prologue exists at T = 1 only
+        if self.use_parts and not all(fits(self.h, k, f) for k in (self.qn, self.I) for f in ((False, True) if fused_possible else (False,))):
+            self.use_parts = False
         self.fuse_attn_o = os.environ.get("SSD_FUSE_ATTN_O", "1") != "0"
         self._last_parts = False        # set by forward() for the compute_logits that follows it
         pt = min(T, 32)
@@ -273,6 +281,12 @@ class HipDecoder:
             waves *= 2
         while waves > 2 and per // waves < 1:
             waves //= 2
+        # a very long K: the kernel holds a wave's whole share in registers (<= 8 k-tiles).  More slabs where the consumer is a
+        # stand-alone norm (up to the 16 the slab buffers hold); the two-slab fused consumer cannot take more -- __init__ then
+        # keeps such a model on the rows kernels
+        while not fused_consumer and S < 16 and -(-(-(-KT // S)) // waves) > 8:
+            S *= 2
+            waves = 16
         return S, waves
 
     def _parts(self, which: str, T: int) -> tuple[int, int]:
