@@ -342,3 +342,38 @@ def test_tensor_parallel_target_with_draft_group_gloo():
     assert all(got[r][0] == [] for r in range(tp, world))
     assert all(got[r][1] == got[0][1] for r in range(tp))
     assert got[0][1][0] == 0.0 and all(h == 1.0 for h in got[0][1][1:])
+
+
+import pytest
+
+
+@pytest.mark.parametrize("world,ndraft", [(5, 1), (8, 4)])
+def test_the_two_full_node_layouts_of_the_benchmark_gloo(world, ndraft):
+    """The layouts `bench.py --gpus 5` and `--gpus 8` launch (BASELINE.json configs[3]: TP 4 + one draft GPU; configs[4]: TP 4 +
+    draft x4 data-parallel), process for process, on gloo with oracle runners: every one of the four tensor-parallel target
+    ranks produces the same stream -- the autoregressive one --, the draft ranks only serve, and with draft == target every
+    request after the first is a speculation-cache hit whichever member of the draft group owns the branch.  (On the
+    one-GPU test box these layouts cannot run on the device: four and more processes whose one-shot all-reduce kernels spin
+    on each other's flags exceed what one GPU schedules concurrently -- the attempt cost the round a GPU box -- so the
+    shared-GPU bench tests stop at three ranks, tests/test_bench_gpu.py.)"""
+    got = _run_tp_and_draft_dp(world, ndraft)
+    tp = world - ndraft
+    assert tp == 4
+    assert all(got[r][0] == got[0][0] and len(got[r][0]) == 2 for r in range(tp))
+    assert all(got[r][0] == [] for r in range(tp, world))
+    assert all(got[r][1] == got[0][1] and got[r][2] == got[0][2] for r in range(tp))
+    # draft == target weights, but the target sums its row-parallel GEMMs in four shards: a near-tie may cost a hit or an
+    # accepted token now and then -- most requests still hit
+    hits = got[0][1]
+    assert hits[0] == 0.0 and sum(hits[1:]) / max(1, len(hits) - 1) >= 0.5, hits
+    # the same requests through ONE process: the same tokens up to such a near-tie
+    from oracle.runner import oracle_runner_factory
+    from ssd_amd.engine.llm_engine import LLMEngine
+    from ssd_amd.model_config import ModelConfig
+    from ssd_amd.sampling_params import SamplingParams
+    t = ModelConfig("llama", 128, 2, 8, 4, 16, 256, 256, 1e-5, 5e5, 1024, False)
+    one, _ = LLMEngine("t", hf_config=t, runner_factory=oracle_runner_factory(), max_num_seqs=2, **KW).generate(
+        PROMPTS, SamplingParams(temperature=0, max_new_tokens=14, ignore_eos=True), use_tqdm=False)
+    for a, b in zip([o["token_ids"] for o in one], got[0][0]):
+        n = next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), len(a))
+        assert len(a) == len(b) and n >= 4, (a, b)
