@@ -304,10 +304,11 @@ class HipDecoder:
         sequence, causal decode rows, context scanned inside one workgroup (bucket <= 1024).  Only while the query rows of a
         kv head fit ONE 16-row tile (the single-token chain, up to 4 rows at G = 4): the N/128 workgroups of a head each
         repeat its attention, and with two row tiles (the K+1 = 8-row glue) that costs more than the saved launch --
-        measured on the 1B draft (profiles/r03_draft_probe.txt): M = 1 forward 734 -> 718 us, M = 8 forward 838 -> 867 us."""
+        measured on the 1B draft (profiles/r03_draft_probe.txt): M = 1 forward 734 -> 718 us, M = 8 forward 838 -> 867 us.
+        (Grouped-query models only, G >= 2: the shapes the kernel was validated at on the MI355X -- G = 4 and 2.)"""
         G = self.nh // self.nkv
         return (self.fuse_attn_o and self.parts_plan(T) and meta.mode == H.MODE_CAUSAL and meta.cu_q is None and meta.B == 1
-                and splits == 1 and T * G <= 16 and G * self.hd <= 256
+                and splits == 1 and G >= 2 and T * G <= 16 and G * self.hd <= 256
                 and self.h % 128 == 0 and self.nkv <= 16)
 
     # ---- the four GEMM launches of a layer (also used one by one by bench.py's roofline timing) ----
