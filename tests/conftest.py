@@ -13,6 +13,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Tests that start SEVERAL processes on the one test GPU (ranks that spin on each other's flags in the one-shot all-reduce,
+# self-launched bench runs) go last: every single-process parity test has reported before them.
+_MULTI_PROCESS_GPU = ("test_bench_gpu.py", "test_custom_ar_gpu.py", "test_tp_one_gpu.py")
+
+
+def pytest_collection_modifyitems(config, items):
+    last = [it for it in items if any(name in it.nodeid for name in _MULTI_PROCESS_GPU)]
+    if last:
+        rest = [it for it in items if it not in last]
+        items[:] = rest + last
+
+
 @pytest.fixture(scope="session")
 def golden():
     from oracle.io import load_npz
