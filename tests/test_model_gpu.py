@@ -412,8 +412,8 @@ def test_full_size_1b_speculation_is_exact(gpu):
     assert_stream_matches(y, a, ar_margins, len(prompt), what="1B async SSD vs AR")
     # draft == target: every round is fully accepted -- except where the single-token draft forward and the (K+1)-row verify
     # forward, whose GEMMs sum in different orders, land on opposite sides of a near-tie (the streams were checked against the
-    # autoregressive margins above): at most one such round in a run this short
-    assert sum(1 for n in lens1[:-1] if n < K + 1) <= 1 and sum(1 for n in lens2[:-1] if n < K + 2) <= 1, (lens1, lens2)
+    # autoregressive margins above): at most two such rounds in a run this short (measured: one)
+    assert sum(1 for n in lens1[:-1] if n < K + 1) <= 2 and sum(1 for n in lens2[:-1] if n < K + 2) <= 2, (lens1, lens2)
 
 
 def test_long_generation_crosses_context_buckets(gpu):
