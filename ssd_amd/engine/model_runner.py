@@ -9,7 +9,8 @@ Re-designed for this hardware rather than translated:
     ssd_draft_advance -> next replay), and verification ends in ssd_verify_greedy writing one packed row per
     sequence: one host sync per speculation step instead of K+5.
   * decode / verify / tree forwards are captured once per batch size as hipGraphs over static buffers
-    (torch.cuda.CUDAGraph == hipGraph); prefill is eager, like the reference (model_runner.py:602).
+    (torch.cuda.CUDAGraph == hipGraph); a prefill shape that keeps coming back replays a graph too (the reference
+    prefills eagerly, model_runner.py:602).
 """
 from __future__ import annotations
 
