@@ -1,6 +1,6 @@
-"""Summarise the separate rocprofv3 PMC passes of profiles/collect_r02.sh (FETCH_SIZE, WRITE_SIZE, MfmaUtil/VALUBusy) into
-profiles/traffic_r02.json, which bench.py reads for `roofline.traffic` / `roofline.mfma_util`:
-    python profiles/make_traffic.py gpurun_out/evidence2
+"""Summarise the separate rocprofv3 PMC passes of profiles/collect_r0N.sh (FETCH_SIZE, WRITE_SIZE, MfmaUtil/VALUBusy) into
+profiles/traffic_r0N.json, which bench.py reads for `roofline.traffic` / `roofline.mfma_util`:
+    python profiles/make_traffic.py gpurun_out/r03 r03
 FETCH_SIZE is in KiB and, on gfx950, counts the 128-B requests of a wide coalesced stream as 64 B (MI355X_MICROARCH.md,
 HBM): HBM read bytes = 2 x FETCH_SIZE x 1024.  Algorithmic bytes of a GEMM launch = 2 N K; the matrix behind a (kernel, grid)
 row is identified from the workload's shapes (Llama-3.1-70B target + Llama-3.2-1B draft, sync k=6 = bench.py --workload c3)."""
@@ -9,6 +9,7 @@ import json
 import sys
 
 d = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/evidence2"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
 
 
 def rows(name):
@@ -28,7 +29,7 @@ KNOWN = {
     ("gemm_sp_kernel<8, 1>", 262144): ("draft down 2048x8192 (2 slabs)", 33.554),
     ("gemm_sp_kernel<2, 1>", 262144): ("draft o 2048x2048 (2 slabs)", 8.389),
 }
-out = {"source": "profiles/r02_c3_pmc_fetch.csv + r02_c3_pmc_write.csv + r02_c3_mfma.csv (separate rocprofv3 --pmc passes on "
+out = {"source": f"profiles/{rnd}_c3_pmc_fetch.csv + {rnd}_c3_pmc_write.csv + {rnd}_c3_mfma.csv (separate rocprofv3 --pmc passes on "
                  "`bench.py --workload c3`, 70B + 1B; FETCH_SIZE x2 gfx950 correction)", "per_kernel": {}}
 fetch = rows("pmc_FETCH_SIZE.csv")
 tot_read = tot_alg = 0.0
@@ -53,5 +54,5 @@ try:
                                 "expected picture; the matrix cores keep the skinny products off the VALU, they are not the bound"}
 except Exception as e:  # noqa: BLE001
     out["mfma_util"] = {"error": repr(e)}
-json.dump(out, open("profiles/traffic_r02.json", "w"), indent=1)
+json.dump(out, open(f"profiles/traffic_{rnd}.json", "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -207,16 +207,21 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
       }
     }
   }
+  if (EPI == EPI_ROWS_ARGMAX && tile + 1 == t_end) {
+    // the last tile's candidates are in: per-wave bests -> their own LDS area BEHIND the combine area, so that the barrier
+    // below (which every tile needs anyway) is the only one between them and the merge -- a second barrier per workgroup
+    // costs these ~5 us-lived workgroups a measurable share of their life
+    ArgPart* lbw = reinterpret_cast<ArgPart*>(smem + (size_t)nw * NT * MT * 64 * sizeof(f32x4_t));      // [nw][MT*16]
+    if (lane < 16) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) lbw[(wave * MT + mt) * 16 + lane] = run[mt];
+    }
+  }
   __syncthreads();   // the combine area is reused by the next tile
   }
   if (EPI == EPI_ROWS_ARGMAX) {
-    // per-wave candidates -> LDS -> one (value, index) per token row and workgroup
-    ArgPart* lb = reinterpret_cast<ArgPart*>(smem);      // [nw][MT*16]
-    if (lane < 16) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) lb[(wave * MT + mt) * 16 + lane] = run[mt];
-    }
-    __syncthreads();
+    // one (value, index) per token row and workgroup
+    const ArgPart* lb = reinterpret_cast<const ArgPart*>(smem + (size_t)nw * NT * MT * 64 * sizeof(f32x4_t));
     for (int t = threadIdx.x; t < MT * 16; t += blockDim.x) {
       if (t >= M) break;
       ArgPart b = lb[t];
@@ -238,7 +243,8 @@ static int launch_t(const void* x, const void* w, const void* bias, void* y, int
   if (tpw < 1) tpw = 1;
   const int blocks = (ntiles + tpw - 1) / tpw;
   if (EPI == EPI_ROWS_ARGMAX && (!part_val || !part_idx || part_stride < blocks)) return SSD_ERR_ARG;
-  const size_t lds = (size_t)waves * NT * MT * 64 * sizeof(f32x4_t);
+  size_t lds = (size_t)waves * NT * MT * 64 * sizeof(f32x4_t);
+  if (EPI == EPI_ROWS_ARGMAX) lds += (size_t)waves * MT * 16 * sizeof(ArgPart);      // per-wave argmax candidates behind the combine area
   auto kern = gemm_wf_kernel<MT, NT, EPI>;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
