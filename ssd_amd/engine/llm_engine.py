@@ -160,12 +160,14 @@ class LLMEngine:
                     while end.from_peer:
                         server.handle_one()
                 transport.pump = pump
-                if side is not None:
-                    # the draft's (eager, ~160 launches) prefill is enqueued AFTER the target's prefill graph has been launched
-                    # and before the host blocks on its result (ModelRunner.run), not in front of it: 1.4 ms less TTFT on c4,
-                    # same overlap on the device
+                if side is not None or os.environ.get("SSD_DEFER_DRAFT_PREFILL") == "1":        # (the switch: CPU tests of the order)
+                    # One GPU serves both models, so the draft's prefill cannot overlap the target's for free as it does on the
+                    # reference's dedicated draft GPU: enqueued first (as until round 2) its ~160 eager launches and ~2.5 ms of
+                    # kernels sit in front of / between the target's prefill kernels and delay the FIRST token by ~3 ms
+                    # (profiles/r03_c4_prefill_timeline.txt).  The command is left in the loop-back queue instead: the first
+                    # speculation request's receive pumps it (commands are served in order), i.e. it runs after the first token
+                    # has been streamed and before the first draft round needs the draft's KV.
                     transport.defer_prefill = True
-                    self.model_runner.prefill_overlap_hook = pump
             self.async_link = AsyncLink(config, self.topo, transport=transport)
             draft_blocks = self.async_link.draft_num_blocks()
 

@@ -428,9 +428,6 @@ class ModelRunner:
                     for k in [k for k in self.graphs if k[0] == "prefill"][:1]:
                         del self.graphs[k]
                 self._launch(key, body)             # "captured": the eager warm-up run already produced this call's result
-            hook = getattr(self, "prefill_overlap_hook", None)
-            if hook is not None:        # co-located draft server: its prefill is enqueued while this one runs (engine/llm_engine.py)
-                hook()
             self._log_margins(B, [(s.seq_id, len(s)) for s in seqs])
             self._sample_or_argmax(seqs, B)
             toks = self._read_tokens(B)

@@ -56,7 +56,7 @@ class AsyncLink:
         # at the first speculation request
         pump = getattr(self.tx, "pump", None)
         if pump is not None and not (eagle_acts is None and getattr(self.tx, "defer_prefill", False)):
-            pump()      # (deferred: ModelRunner.run takes the command right after launching the target's prefill)
+            pump()      # (co-located on a GPU: deferred to the first speculation request, engine/llm_engine.py)
 
     def speculate(self, keys, num_tokens, block_tables, temps, want_logits: bool = False, eagle=None):
         """-> (hits, tokens, logits_q or None).  logits_q bf16 [B, K, V] is requested only when some temperature is

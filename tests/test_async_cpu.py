@@ -52,6 +52,17 @@ def test_async_loopback_is_exact():
     assert len(m["cache_hits"]) == stats["rounds"]
 
 
+def test_deferred_draft_prefill_is_served_before_the_first_speculation_request(monkeypatch):
+    """Co-located draft on one GPU: the draft's prefill command stays queued until the first speculation request's receive pumps
+    it (engine/llm_engine.py, TTFT) -- commands are served in order, so streams, hits and acceptance are those of the eager
+    order (batch of two requests)."""
+    want, m0, s0 = run("async", same=True, bs=2)
+    monkeypatch.setenv("SSD_DEFER_DRAFT_PREFILL", "1")
+    got, m1, s1 = run("async", same=True, bs=2)
+    assert got == want and m1["cache_hits"] == m0["cache_hits"]
+    assert m1["accepted_suffix_lens_with_recovery"] == m0["accepted_suffix_lens_with_recovery"] and s1 == s0
+
+
 def test_async_same_model_hits_and_accepts_everything():
     ar, _, _ = run("ar")
     asy, m, stats = run("async", same=True)
