@@ -100,7 +100,9 @@ int ssd_gemm_parts(const void* x_frag, const void* w_frag, const void* bias, voi
  * (ssd/engine/model_runner.py:602 -> ssd/layers/linear.py:65,98,196).  Same operands and epilogues (SSD_EPI_ROWS,
  * SSD_EPI_SILU_FRAG) as ssd_gemm_wf; the x tile of a k-step is shared by a workgroup through LDS and K is split
  * across workgroups into fp32 partials in `workspace` (>= ssd_gemm_pf_workspace_bytes), summed in a fixed order.
- * N % 128 == 0, K % 128 == 0; splits <= 0 picks the default. */
+ * N % 128 == 0, K % 128 == 0; splits <= 0 picks the default.  epilogue 2 (partials only, y may be NULL, no bias): the fp32
+ * partials [splits][M][N] in `workspace` ARE the output (splits = ssd_gemm_pf_workspace_bytes(M, N, K) / (4 M N)), to be
+ * summed by ssd_rmsnorm_parts -- the add + RMSNorm that follows o_proj / down_proj -- instead of an epilogue launch. */
 int ssd_gemm_pf_workspace_bytes(int M, int N, int K, int64_t* bytes);
 int ssd_gemm_pf(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K, int ldy,
                 int epilogue, void* workspace, int64_t workspace_bytes, int splits, void* stream);

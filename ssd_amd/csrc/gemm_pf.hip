@@ -16,7 +16,10 @@
 //    fragment-major).  The partials are ~6-25 % extra traffic and mostly live in the 256 MiB Infinity Cache.
 #include "common.h"
 
-enum { PF_EPI_ROWS = 0, PF_EPI_SILU_FRAG = 1 };
+enum { PF_EPI_ROWS = 0, PF_EPI_SILU_FRAG = 1, PF_EPI_PARTIALS = 2 };
+// PF_EPI_PARTIALS: stop after the split-K GEMM -- the fp32 partials ws[z][m][n] (z < splits, slab stride M * N) are the
+// output, summed by the CONSUMER (ssd_rmsnorm_parts: the add + RMSNorm that follows o_proj / down_proj sums the slabs in the
+// same order, rounds once to bf16 like the epilogue kernel would, and goes on): one launch per GEMM less in a prefill.
 
 constexpr int PF_WAVES_DEFAULT = 4;   // waves per workgroup; the 8-wave form (NT = 2, same 16 row groups per workgroup) halves each
                                       // wave's accumulators and doubles the weight tiles in flight per workgroup
@@ -273,7 +276,8 @@ extern "C" int ssd_gemm_pf_cfg(const void* x_frag, const void* w_frag, const voi
                                int ldy, int epilogue, void* workspace, int64_t workspace_bytes, int nt, int splits,
                                void* stream) {
   if (M <= 16 || M > 128 || N <= 0 || K <= 0 || (K % (32 * PF_U))) return SSD_ERR_SHAPE;
-  if (epilogue != PF_EPI_ROWS && epilogue != PF_EPI_SILU_FRAG) return SSD_ERR_ARG;
+  if (epilogue != PF_EPI_ROWS && epilogue != PF_EPI_SILU_FRAG && epilogue != PF_EPI_PARTIALS) return SSD_ERR_ARG;
+  if (epilogue == PF_EPI_PARTIALS && bias) return SSD_ERR_ARG;
   // nt may carry the waves per workgroup in bits 8.. (0 = 4): 8 waves only with nt = 2 (same 16 row groups per workgroup)
   int waves = (nt >> 8) & 0xff;
   nt &= 0xff;
@@ -285,7 +289,7 @@ extern "C" int ssd_gemm_pf_cfg(const void* x_frag, const void* w_frag, const voi
   if (splits <= 0) { int nt_d; pf_pick(N, K, &nt_d, &splits); if (nt_d != nt) splits = 1; }
   if (splits > 16) return SSD_ERR_ARG;
   if (KT % (splits * PF_U) != 0) return SSD_ERR_ARG;
-  const int direct = splits == 1 ? (epilogue == PF_EPI_ROWS ? 1 : 2) : 0;     // unsplit K: finish inside the GEMM kernel
+  const int direct = (splits == 1 && epilogue != PF_EPI_PARTIALS) ? (epilogue == PF_EPI_ROWS ? 1 : 2) : 0;     // unsplit K: finish inside the GEMM kernel
   if (!direct && (!workspace || workspace_bytes < (int64_t)splits * M * N * 4)) return SSD_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)workspace;
@@ -295,7 +299,7 @@ extern "C" int ssd_gemm_pf_cfg(const void* x_frag, const void* w_frag, const voi
   if (mt <= 4) rc = nt == 4 ? pf_launch<4, 4>(PF_ARGS) : pf_launch<4, 2>(PF_ARGS);
   else rc = nt == 4 ? pf_launch<8, 4>(PF_ARGS) : pf_launch<8, 2>(PF_ARGS);
 #undef PF_ARGS
-  if (rc != SSD_OK || direct) return rc;
+  if (rc != SSD_OK || direct || epilogue == PF_EPI_PARTIALS) return rc;
   if (epilogue == PF_EPI_ROWS) {
     const size_t items = (size_t)M * N / 4;
     hipLaunchKernelGGL((gemm_pf_epilogue_kernel<PF_EPI_ROWS>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, ws,

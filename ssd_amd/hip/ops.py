@@ -11,6 +11,7 @@ import torch
 from .lib import load_library, SsdHipError
 
 EPI_ROWS, EPI_SILU_FRAG, EPI_ROWS_F32 = 0, 1, 2
+PF_EPI_PARTIALS = 2          # ssd_gemm_pf only: leave the split-K partials in the workspace for ssd_rmsnorm_parts
 MODE_CAUSAL, MODE_TREE = 0, 1
 
 

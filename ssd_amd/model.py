@@ -111,6 +111,7 @@ class HipDecoder:
         if self.use_parts and not all(fits(self.h, k, f) for k in (self.qn, self.I) for f in ((False, True) if fused_possible else (False,))):
             self.use_parts = False
         self.fuse_attn_o = os.environ.get("SSD_FUSE_ATTN_O", "1") != "0"
+        self.pf_parts = os.environ.get("SSD_PF_PARTS", "1") != "0"
         self._last_parts = False        # set by forward() for the compute_logits that follows it
         pt = min(T, 32)
         self.buf_parts_o = z(16 * pt * self.h, dtype=torch.float32) if self.use_parts else None
@@ -217,6 +218,17 @@ class HipDecoder:
         else:
             H.gemm(xf, w, y, m, N, K, ldy, epi, bias)
 
+    def _pf_partials_ok(self, T: int, N: int, K: int) -> bool:
+        """o_proj / down_proj of ONE prefill chunk may leave their split-K partials in the workspace for the norm that follows."""
+        return self.pf_parts and not self.use_coll and 32 < T <= 128 and self._pf_eligible(N, K) and self._ws_pf is not None
+
+    def _gemm_pf_partials(self, xf, K, w, N, T) -> int:
+        """Prefill GEMM stopped after its split-K stage (csrc/gemm_pf.hip PF_EPI_PARTIALS): fp32 slabs [S][T][N] in the workspace;
+        returns S.  The consumer is ssd_rmsnorm_parts -- one launch per GEMM less."""
+        S = H.gemm_pf_workspace_bytes(T, N, K) // (4 * T * N)
+        H.gemm_pf(xf, w, None, T, N, K, N, self._ws_pf, epilogue=H.PF_EPI_PARTIALS)
+        return S
+
     def _gemm(self, xf, K, w, N, y, T, ldy, epi=H.EPI_ROWS, bias=None):
         if T <= 128:
             self._gemm_chunk(xf, K, w, N, y, T, ldy, epi, bias)
@@ -322,7 +334,7 @@ class HipDecoder:
         return small, small and not self.use_coll and T * self.h // 8 <= 1024
 
     def launch_qkv(self, li: int, T: int, positions, slot_mapping, gemm_only: bool = False, pre_normed: bool = False,
-                   parts: bool | None = None) -> None:
+                   parts: bool | None = None, pf_src: int = 0) -> None:
         """gemm_only: skip the separate add+RMSNorm / RoPE launches of the unfused variants (kernel timing).
         pre_normed: buf_xf / buf_res already hold this layer's normalised input and residual (written by the fused
         all-reduce + add + RMSNorm that closed the previous layer)."""
@@ -342,7 +354,10 @@ class HipDecoder:
             return
         # residual is None on layer 0 (llama3.py:187-190): residual := embeddings, x := norm(embeddings)
         if not gemm_only and not pre_normed:
-            if parts:
+            if pf_src:       # the previous layer's down_proj left pf_src split-K slabs [pf_src][T][h] in the prefill workspace
+                H.rmsnorm_parts(self._ws_pf, pf_src, T, w[p + "input_layernorm.weight"], cfg.rms_norm_eps, T, self.h,
+                                res_in=res, res_out=res, out_frag=xf)
+            elif parts:
                 H.rmsnorm_parts(self.buf_parts_d, self._parts("d", T)[0], T, w[p + "input_layernorm.weight"], cfg.rms_norm_eps, T, self.h,
                                 res_in=res, res_out=res, out_frag=xf)
             else:
@@ -360,16 +375,20 @@ class HipDecoder:
                             self.hd, self.block_size, q_norm_w=w.get(p + "self_attn.q_norm.weight"),
                             k_norm_w=w.get(p + "self_attn.k_norm.weight"), eps=cfg.rms_norm_eps, qkv_perm=1)
 
-    def launch_o(self, li: int, T: int, parts: bool | None = None) -> None:
+    def launch_o(self, li: int, T: int, parts: bool | None = None, pf_partials: bool = False) -> int:
+        """Returns the number of split-K slabs left in the prefill workspace (pf_partials), else 0."""
         w = self.w[f"model.layers.{li}.self_attn.o_proj.weight"]
+        if pf_partials and self._pf_partials_ok(T, self.h, self.qn):
+            return self._gemm_pf_partials(self.buf_af, self.qn, w, self.h, T)
         if self.parts_plan(T) if parts is None else parts:
             S, wv = self._parts("o", T)
             H.gemm_parts(self.buf_af, w, T, self.h, self.qn, parts=self.buf_parts_o, splits=S, waves=wv)
         else:
             self._gemm(self.buf_af, self.qn, w, self.h, self.buf_h, T, self.h)
+        return 0
 
     def launch_gate_up(self, li: int, T: int, gemm_only: bool = False, pre_normed: bool = False, parts: bool | None = None,
-                       o_splits: int | None = None) -> None:
+                       o_splits: int | None = None, pf_src: int = 0) -> None:
         """o_splits: slabs o_proj left in buf_parts_o (default: the split-K GEMM's; the fused attention + o_proj leaves nkv)."""
         cfg, w = self.cfg, self.w
         p = f"model.layers.{li}."
@@ -383,7 +402,10 @@ class HipDecoder:
                          eps=cfg.rms_norm_eps, y=self.buf_actf, waves=8, **src)     # profiles/micro/fused_probe.py: 13.2 us vs 16.4 (16 waves)
         else:
             if not gemm_only and not pre_normed:
-                if parts:
+                if pf_src:       # o_proj left pf_src split-K slabs in the prefill workspace
+                    H.rmsnorm_parts(self._ws_pf, pf_src, T, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps,
+                                    T, self.h, res_in=self.buf_res, res_out=self.buf_res, out_frag=self.buf_xf)
+                elif parts:
                     H.rmsnorm_parts(self.buf_parts_o, So, T, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps,
                                     T, self.h, res_in=self.buf_res, res_out=self.buf_res, out_frag=self.buf_xf)
                 else:
@@ -391,13 +413,16 @@ class HipDecoder:
                               res_in=self.buf_res, res_out=self.buf_res, out_frag=self.buf_xf)
             self._gemm(self.buf_xf, self.h, w[p + "mlp.gate_up_proj.weight"], 2 * self.I, self.buf_actf, T, 0, epi=H.EPI_SILU_FRAG)
 
-    def launch_down(self, li: int, T: int, parts: bool | None = None) -> None:
+    def launch_down(self, li: int, T: int, parts: bool | None = None, pf_partials: bool = False) -> int:
         w = self.w[f"model.layers.{li}.mlp.down_proj.weight"]
+        if pf_partials and self._pf_partials_ok(T, self.h, self.I):
+            return self._gemm_pf_partials(self.buf_actf, self.I, w, self.h, T)
         if self.parts_plan(T) if parts is None else parts:
             S, wv = self._parts("d", T)
             H.gemm_parts(self.buf_actf, w, T, self.h, self.I, parts=self.buf_parts_d, splits=S, waves=wv)
         else:
             self._gemm(self.buf_actf, self.I, w, self.h, self.buf_h, T, self.h)
+        return 0
 
     def forward(self, input_ids: torch.Tensor, positions: torch.Tensor, T: int, meta: AttnMeta) -> None:
         """Runs all layers; leaves the final (pre-norm) hidden state in buf_h and the residual in buf_res."""
@@ -419,13 +444,15 @@ class HipDecoder:
         fuse = self.use_coll and ar is not None and self.fuse_ar_norm and ar.fits_rows(T, self.h)
         eps, res, xf = cfg.rms_norm_eps, self.buf_res, self.buf_xf
         L = cfg.num_layers
+        pf_d = 0            # split-K slabs the previous layer's down_proj left for this layer's input norm (single-chunk prefill)
         for li in range(L):
-            self.launch_qkv(li, T, positions, meta.slot_mapping, pre_normed=fuse and li > 0, parts=parts)
+            self.launch_qkv(li, T, positions, meta.slot_mapping, pre_normed=fuse and li > 0, parts=parts, pf_src=pf_d)
             if self.taps is not None and li in self.taps:
                 # launch_qkv has just written x + residual: to buf_res2 on the fused-prologue path, to buf_res otherwise
                 src = self.buf_res2 if self.fusion_plan(T)[1] else res
                 i = self.taps.index(li)
                 self.acts[:T, i * self.h:(i + 1) * self.h].copy_(src[:T])
+            pf_o = 0
             if fuse_ao:
                 H.attn_oproj_parts(self.buf_q, self.kv_cache[li, 0], self.kv_cache[li, 1], meta.block_tables, self.max_blocks,
                                    meta.context_lens, T, self.nh, self.nkv, self.hd, self.block_size, scale,
@@ -436,13 +463,14 @@ class HipDecoder:
                              cu_q=meta.cu_q, q_per_seq=meta.q_per_seq, mode=meta.mode, tree_K=meta.tree_K, tree_mq=meta.tree_mq,
                              tree_step=meta.tree_step, tree_F=meta.tree_F, tree_jidx=meta.tree_jidx, splits=splits,
                              ws_o=self.ws_o, ws_ml=self.ws_ml, out_frag=self.buf_af, waves=attn_waves)
-                self.launch_o(li, T, parts=parts)
+                pf_o = self.launch_o(li, T, parts=parts, pf_partials=not parts)
             if fuse:
                 ar.all_reduce_add_rmsnorm(h, res, res, w[f"model.layers.{li}.post_attention_layernorm.weight"], eps, T, self.h, out_frag=xf)
             else:
                 self._allreduce(h[:T])
-            self.launch_gate_up(li, T, pre_normed=fuse, parts=parts, o_splits=self.nkv if fuse_ao else None)
-            self.launch_down(li, T, parts=parts)
+            self.launch_gate_up(li, T, pre_normed=fuse, parts=parts, o_splits=self.nkv if fuse_ao else None, pf_src=pf_o)
+            # (the last layer's down_proj keeps its epilogue: compute_logits' last-token gather reads rows)
+            pf_d = self.launch_down(li, T, parts=parts, pf_partials=not parts and li + 1 < L)
             if fuse and li + 1 < L:
                 ar.all_reduce_add_rmsnorm(h, res, res, w[f"model.layers.{li + 1}.input_layernorm.weight"], eps, T, self.h, out_frag=xf)
             else:

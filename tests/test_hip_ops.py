@@ -660,3 +660,33 @@ def test_attn_long_context_prefill_and_decode(H):
         refd = O.attn_paged(qd, kc, vc, ctx, bt, hd ** -0.5, cu_q=cud).reshape(qps, nh * hd)
         gotd = run_attn(H, qd.view(qps, -1), kc, vc, bt, mb, ctx, nh, nkv, hd, bs, q_per_seq=qps, splits=splits, flags=8 << 8)
         assert_close_bf16(gotd, refd, what=f"ctx 6000 q{qps} splits{splits}", **ATTN_TOL)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 8192, 8192), (100, 8192, 7168), (40, 4096, 14336), (128, 1024, 512)])
+def test_prefill_partials_consumed_by_the_norm_equal_epilogue_then_norm(H, M, N, K):
+    """PF_EPI_PARTIALS (round 3): o_proj / down_proj of a single-chunk prefill leave their split-K partials in the workspace and
+    the add + RMSNorm that follows sums them (ssd_rmsnorm_parts) -- bit-identical to the epilogue launch + ssd_rmsnorm it
+    replaces (same slab order, same single rounding to bf16), for the default split counts incl. the unsplit case."""
+    torch.manual_seed(M + N + K)
+    x = torch.randn(M, K).to(BF)
+    w = (torch.randn(N, K) * 0.03).to(BF)
+    res = torch.randn(M, N).to(BF)
+    nw = (1 + 0.1 * torch.randn(N)).to(BF)
+    xf, wf = to_frag_dev(x), to_frag_dev(w)
+    nbytes = H.gemm_pf_workspace_bytes(M, N, K)
+    S = nbytes // (4 * M * N)
+    assert S >= 1 and S * 4 * M * N == nbytes
+    ws = torch.full((nbytes // 4 + 64,), float("nan"), dtype=torch.float32, device="cuda")
+    # reference: GEMM with its epilogue -> rows, then add + norm
+    y = torch.zeros(M, N, dtype=BF, device="cuda")
+    H.gemm_pf(xf, wf, y, M, N, K, N, ws)
+    r0, o0 = torch.zeros(M, N, dtype=BF, device="cuda"), torch.zeros(H.frag_numel(M, N), dtype=BF, device="cuda")
+    H.rmsnorm(y, dev(nw), 1e-5, M, N, res_in=dev(res), res_out=r0, out_frag=o0)
+    # partials only -> the norm sums them
+    ws.fill_(float("nan"))
+    H.gemm_pf(xf, wf, None, M, N, K, N, ws, epilogue=H.PF_EPI_PARTIALS)
+    r1, o1 = torch.zeros(M, N, dtype=BF, device="cuda"), torch.zeros(H.frag_numel(M, N), dtype=BF, device="cuda")
+    H.rmsnorm_parts(ws, S, M, dev(nw), 1e-5, M, N, res_in=dev(res), res_out=r1, out_frag=o1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(ws[:S * M * N]).all()
+    assert torch.equal(r0.view(torch.int16), r1.view(torch.int16)) and torch.equal(o0.view(torch.int16), o1.view(torch.int16))
