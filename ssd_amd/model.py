@@ -112,6 +112,7 @@ class HipDecoder:
             self.use_parts = False
         self.fuse_attn_o = os.environ.get("SSD_FUSE_ATTN_O", "1") != "0"
         self.pf_parts = os.environ.get("SSD_PF_PARTS", "1") != "0"
+        self._prefill_waves = int(os.environ.get("SSD_ATTN_PREFILL_WAVES", "0"))
         self._last_parts = False        # set by forward() for the compute_logits that follows it
         pt = min(T, 32)
         self.buf_parts_o = z(16 * pt * self.h, dtype=torch.float32) if self.use_parts else None
@@ -268,6 +269,8 @@ class HipDecoder:
         groups = -(-row_tiles // 2) if row_tiles > 8 else row_tiles       # csrc/attention.hip attn_launch
         base = max(1, groups * meta.B * self.nkv)
         waves = max(1, min(8, 512 // base))
+        if meta.cu_q is not None and self._prefill_waves:       # prefill: tuning override (SSD_ATTN_PREFILL_WAVES)
+            waves = self._prefill_waves
         ctx = self.ctx_bucket(meta.ctx_hint if meta.ctx_hint > 0 else self.max_model_len)
         splits = 1 if ctx <= 1024 else max(1, min(self.max_splits, ctx // 512))
         if base >= 256 or T > self.max_split_tokens:
