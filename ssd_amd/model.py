@@ -269,8 +269,8 @@ class HipDecoder:
         groups = -(-row_tiles // 2) if row_tiles > 8 else row_tiles       # csrc/attention.hip attn_launch
         base = max(1, groups * meta.B * self.nkv)
         waves = max(1, min(8, 512 // base))
-        if meta.cu_q is not None:       # prefill: at least 4 waves split a workgroup's keys (c4 TTFT 30.92 -> 30.68 ms; 8: 30.74)
-            waves = self._prefill_waves or max(waves, 4)
+        if meta.cu_q is not None and self._prefill_waves:       # prefill: tuning override (SSD_ATTN_PREFILL_WAVES).  Measured on c4:
+            waves = self._prefill_waves                         # TTFT 30.92 ms (default, 2 waves) / 30.68 (4) / 30.74 (8): within noise, not adopted
         ctx = self.ctx_bucket(meta.ctx_hint if meta.ctx_hint > 0 else self.max_model_len)
         splits = 1 if ctx <= 1024 else max(1, min(self.max_splits, ctx // 512))
         if base >= 256 or T > self.max_split_tokens:
