@@ -27,13 +27,15 @@ constexpr int PF_U = 4;      // k-steps of W in flight per wave; every K split i
 
 // direct: 0 = write fp32 partials for the epilogue kernel; 1 / 2 = the K range is not split, finish in place
 // (1: rows bf16 + bias, 2: SiLU(gate) * up -> fragment-major) and skip the workspace round trip.
-template <int MT, int NT, int UU, int DIRECT, int PF_WAVES>
-__global__ void __launch_bounds__(64 * PF_WAVES, PF_WAVES == 4 ? 2 : 1)
+// BPS = k-steps per workgroup barrier: the x ring holds two PHASES of BPS k-steps each (one being read, one being staged).
+template <int MT, int NT, int UU, int DIRECT, int PF_WAVES, int BPS = 1>
+__global__ void __launch_bounds__(64 * PF_WAVES, PF_WAVES <= 4 ? 2 : 1)
 gemm_pf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, float* __restrict__ ws,
                int M, int N, int K, int kt_per_split, int mt_valid, const bf16_t* __restrict__ bias,
                void* __restrict__ Yv, int ldy) {
-  __shared__ u32x4_t xs[2][MT][64];                      // ring of two k-steps, MT fragment tiles each
+  __shared__ u32x4_t xs[2 * BPS][MT][64];                // ring of two phases of BPS k-steps, MT fragment tiles per k-step
   constexpr int U = UU;                                   // W k-steps in flight per wave (nk is a multiple of it)
+  static_assert(UU % (2 * BPS) == 0, "an even number of phases per unrolled pass");
   constexpr int FPW = (MT + PF_WAVES - 1) / PF_WAVES;     // x fragment tiles each wave fetches per k-step
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -60,7 +62,7 @@ gemm_pf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, f
     xp[f] = Xf + (((size_t)src * KT + kz0) << 6) + lane;
   }
 
-  u32x4_t a[U][NT], xr[2][FPW];
+  u32x4_t a[U][NT], xr[2][BPS][FPW];
   auto load_w = [&](u32x4_t (&d)[NT], int kt) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) d[nt] = __builtin_nontemporal_load(wp + nt * wstride + ((size_t)kt << 6));
@@ -83,28 +85,38 @@ gemm_pf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, f
     }
   };
 
-  // prologue: x(0) -> LDS slot 0; x(1), x(2) in registers; W(0..U-1) in flight.
+  // prologue: phase 0 of x -> LDS half 0; phases 1 and 2 in registers; W(0..U-1) in flight.
   // Every load in the loop is issued unconditionally (tail iterations re-read the last k-step instead of being
   // predicated off), so the number of loads in flight is static and the compiler can wait for exactly the one it
   // needs (s_waitcnt vmcnt(n > 0)) instead of draining the queue at every k-step.
-  load_x(xr[0], 0);
+  const int klast = nk - 1;
+#pragma unroll
+  for (int b = 0; b < BPS; ++b) load_x(xr[0][b], b);
 #pragma unroll
   for (int u = 0; u < U; ++u) load_w(a[u], u);
-  load_x(xr[1], 1);
-  stage_x(xr[0], 0);
-  load_x(xr[0], 2);          // nk >= U >= 4 > 2
+#pragma unroll
+  for (int b = 0; b < BPS; ++b) load_x(xr[1][b], BPS + b);          // nk >= U >= 2 * BPS
+#pragma unroll
+  for (int b = 0; b < BPS; ++b) stage_x(xr[0][b], b);
+#pragma unroll
+  for (int b = 0; b < BPS; ++b) load_x(xr[0][b], min(2 * BPS + b, klast));
   __syncthreads();
-  const int klast = nk - 1;
   for (int kt = 0; kt < nk; kt += U) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < U; u += BPS) {
       const int k = kt + u;
-      // x(k+1) registers (parity (k+1)&1, loaded two k-steps ago) -> the other ring slot, whose last readers
-      // finished before the previous barrier; then the freed registers fetch x(k+3)
-      stage_x(xr[(u + 1) & 1], (u + 1) & 1);
-      load_x(xr[(u + 1) & 1], min(k + 3, klast));
-      compute(a[u], u & 1);
-      load_w(a[u], min(k + U, klast));
+      const int par = (u / BPS) & 1;          // ring half of this phase (compile-time after unrolling)
+      // the registers of parity par^1 hold the NEXT phase (loaded two phases ago) -> the other ring half, whose last
+      // readers finished before the previous barrier; then the freed registers fetch the phase three ahead
+#pragma unroll
+      for (int b = 0; b < BPS; ++b) stage_x(xr[par ^ 1][b], (par ^ 1) * BPS + b);
+#pragma unroll
+      for (int b = 0; b < BPS; ++b) load_x(xr[par ^ 1][b], min(k + 3 * BPS + b, klast));
+#pragma unroll
+      for (int b = 0; b < BPS; ++b) {
+        compute(a[u + b], par * BPS + b);
+        load_w(a[u + b], min(k + b + U, klast));
+      }
       __syncthreads();
     }
   }
@@ -216,31 +228,42 @@ gemm_pf_epilogue_kernel(const float* __restrict__ ws, const bf16_t* __restrict__
 
 template <int MT, int NT, int DIRECT>
 static int pf_launch_d(const void* x, const void* w, float* ws, int M, int N, int K, int splits, const void* bias, void* y,
-                       int ldy, int waves, hipStream_t st) {
+                       int ldy, int waves, int uu, int bps, hipStream_t st) {
   const int KT = K >> 5;
   dim3 grid(N / (16 * NT * waves), splits);
   const int nk = KT / splits;
-#define PF_GO(UU, WV)                                                                                                    \
-  hipLaunchKernelGGL((gemm_pf_kernel<MT, NT, UU, DIRECT, WV>), grid, dim3(64 * WV), 0, st, (const u32x4_t*)w,            \
-                     (const u32x4_t*)x, ws, M, N, K, nk, (M + 15) / 16, (const bf16_t*)bias, y, ldy)
-  // the narrow tile (NT = 2) has the registers to keep 8 k-steps of W in flight per wave
+  // W k-steps in flight per wave: the narrow tile (NT = 2) has the registers for 8; nk must be a multiple
+  if (uu <= 0) uu = (NT <= 2 && nk % 8 == 0) ? 8 : PF_U;
+  if (nk % uu != 0 || bps < 1) return SSD_ERR_ARG;
+  bool launched = false;
+#define PF_GO(UU, WV, B)                                                                                                 \
+  if (!launched && uu == UU && waves == WV && bps == B) {                                                                \
+    launched = true;                                                                                                     \
+    hipLaunchKernelGGL((gemm_pf_kernel<MT, NT, UU, DIRECT, WV, B>), grid, dim3(64 * WV), 0, st, (const u32x4_t*)w,       \
+                       (const u32x4_t*)x, ws, M, N, K, nk, (M + 15) / 16, (const bf16_t*)bias, y, ldy);                  \
+  }
+  PF_GO(4, 4, 1)
+  if constexpr (NT == 1 && MT == 8 && DIRECT != 2) {     // 64-row (4 waves) / 128-row (8 waves) tiles: twice the workgroups per split
+    PF_GO(8, 4, 1) PF_GO(8, 4, 2) PF_GO(8, 8, 1) PF_GO(8, 8, 2)
+  }
   if constexpr (NT == 2) {
-    if (waves == 8) { if (nk % 8 == 0) PF_GO(8, 8); else PF_GO(PF_U, 8); }
-    else if (nk % 8 == 0) PF_GO(8, 4);
-    else PF_GO(PF_U, 4);
-  } else {
-    PF_GO(PF_U, 4);
+    PF_GO(8, 4, 1) PF_GO(4, 8, 1) PF_GO(8, 8, 1)
+    if constexpr (MT == 8) {     // the full prefill chunk (65..128 rows): two k-steps per barrier, 3..7-wave workgroups (so that
+      PF_GO(8, 4, 2) PF_GO(8, 8, 2)                                        // row groups x splits can land on a multiple of 256 CUs)
+      PF_GO(8, 3, 1) PF_GO(8, 3, 2) PF_GO(8, 5, 1) PF_GO(8, 5, 2) PF_GO(8, 6, 2) PF_GO(8, 7, 1) PF_GO(8, 7, 2)
+    }
   }
 #undef PF_GO
+  if (!launched) return SSD_ERR_ARG;
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
 template <int MT, int NT>
 static int pf_launch(const void* x, const void* w, float* ws, int M, int N, int K, int splits, int direct, const void* bias,
-                     void* y, int ldy, int waves, hipStream_t st) {
-  if (direct == 1) return pf_launch_d<MT, NT, 1>(x, w, ws, M, N, K, splits, bias, y, ldy, waves, st);
-  if (direct == 2) return pf_launch_d<MT, NT, 2>(x, w, ws, M, N, K, splits, bias, y, ldy, waves, st);
-  return pf_launch_d<MT, NT, 0>(x, w, ws, M, N, K, splits, bias, y, ldy, waves, st);
+                     void* y, int ldy, int waves, int uu, int bps, hipStream_t st) {
+  if (direct == 1) return pf_launch_d<MT, NT, 1>(x, w, ws, M, N, K, splits, bias, y, ldy, waves, uu, bps, st);
+  if (direct == 2) return pf_launch_d<MT, NT, 2>(x, w, ws, M, N, K, splits, bias, y, ldy, waves, uu, bps, st);
+  return pf_launch_d<MT, NT, 0>(x, w, ws, M, N, K, splits, bias, y, ldy, waves, uu, bps, st);
 }
 
 // Default decomposition, from profiles/r02_pf_probe.txt (MI355X, M = 128, us): the narrow tile (nt = 2) everywhere --
@@ -264,6 +287,19 @@ static void pf_pick(int N, int K, int* nt_out, int* splits_out, int* waves_out =
   if (waves_out) *waves_out = waves;
 }
 
+// Refinements for the full chunk (65..128 rows), from profiles/r03_pf_probe.txt (all bit-identical to the plain form: the K order
+// inside a split does not change): two k-steps per barrier whenever the split is a multiple of 8 k-steps (3-12 % everywhere), and
+// 5-wave workgroups (160 rows) when that puts exactly a multiple of 256 workgroups on the 256 CUs -- 70B qkv: 10240 rows x 4 splits
+// = 256 workgroups, 46.2 us against 49.9 us with 160 eight-wave workgroups.
+static void pf_refine(int M, int N, int K, int splits, int* waves, int* bps) {
+  *bps = 1;
+  if (M <= 64) return;
+  const int nk = (K >> 5) / splits;
+  if (nk % 8 != 0) return;
+  *bps = 2;
+  if (N % (16 * 2 * 5) == 0 && ((N / (16 * 2 * 5)) * splits) % 256 == 0) *waves = 5;
+}
+
 extern "C" int ssd_gemm_pf_workspace_bytes(int M, int N, int K, int64_t* bytes) {
   if (!bytes || M <= 0 || N <= 0 || K <= 0 || N % (16 * 2 * PF_WAVES_DEFAULT) != 0) return SSD_ERR_ARG;
   int nt, splits;
@@ -278,12 +314,17 @@ extern "C" int ssd_gemm_pf_cfg(const void* x_frag, const void* w_frag, const voi
   if (M <= 16 || M > 128 || N <= 0 || K <= 0 || (K % (32 * PF_U))) return SSD_ERR_SHAPE;
   if (epilogue != PF_EPI_ROWS && epilogue != PF_EPI_SILU_FRAG && epilogue != PF_EPI_PARTIALS) return SSD_ERR_ARG;
   if (epilogue == PF_EPI_PARTIALS && bias) return SSD_ERR_ARG;
-  // nt may carry the waves per workgroup in bits 8.. (0 = 4): 8 waves only with nt = 2 (same 16 row groups per workgroup)
+  // nt may carry the launch shape above its low byte: waves per workgroup in bits 8..15 (0 = 4; 7 or 8 only with nt = 2),
+  // W k-steps in flight per wave in bits 16..23 (0 = default), k-steps per barrier in bits 24..27 (0 = 1)
   int waves = (nt >> 8) & 0xff;
+  const int uu = (nt >> 16) & 0xff;
+  int bps = (nt >> 24) & 0xf;
   nt &= 0xff;
   if (waves == 0) waves = PF_WAVES_DEFAULT;
-  if (nt != 2 && nt != 4) return SSD_ERR_ARG;
-  if (waves != 4 && !(waves == 8 && nt == 2)) return SSD_ERR_ARG;
+  if (bps == 0) bps = 1;
+  if (nt != 1 && nt != 2 && nt != 4) return SSD_ERR_ARG;
+  if (nt == 1 && (epilogue == PF_EPI_SILU_FRAG || M <= 64)) return SSD_ERR_ARG;
+  if (waves != 4 && !(waves >= 3 && waves <= 8 && nt <= 2)) return SSD_ERR_ARG;
   if (N % (16 * nt * waves) != 0) return SSD_ERR_SHAPE;
   const int KT = K >> 5;
   if (splits <= 0) { int nt_d; pf_pick(N, K, &nt_d, &splits); if (nt_d != nt) splits = 1; }
@@ -295,9 +336,9 @@ extern "C" int ssd_gemm_pf_cfg(const void* x_frag, const void* w_frag, const voi
   float* ws = (float*)workspace;
   const int mt = (M + 15) / 16;
   int rc;
-#define PF_ARGS x_frag, w_frag, ws, M, N, K, splits, direct, bias, y, ldy, waves, st
+#define PF_ARGS x_frag, w_frag, ws, M, N, K, splits, direct, bias, y, ldy, waves, uu, bps, st
   if (mt <= 4) rc = nt == 4 ? pf_launch<4, 4>(PF_ARGS) : pf_launch<4, 2>(PF_ARGS);
-  else rc = nt == 4 ? pf_launch<8, 4>(PF_ARGS) : pf_launch<8, 2>(PF_ARGS);
+  else rc = nt == 4 ? pf_launch<8, 4>(PF_ARGS) : nt == 2 ? pf_launch<8, 2>(PF_ARGS) : pf_launch<8, 1>(PF_ARGS);
 #undef PF_ARGS
   if (rc != SSD_OK || direct || epilogue == PF_EPI_PARTIALS) return rc;
   if (epilogue == PF_EPI_ROWS) {
@@ -315,8 +356,11 @@ extern "C" int ssd_gemm_pf_cfg(const void* x_frag, const void* w_frag, const voi
 extern "C" int ssd_gemm_pf(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K,
                            int ldy, int epilogue, void* workspace, int64_t workspace_bytes, int splits, void* stream) {
   if (N <= 0 || K <= 0 || N % (16 * 2 * PF_WAVES_DEFAULT) != 0) return SSD_ERR_SHAPE;
-  int nt, s, waves;
+  int nt, s, waves, bps;
   pf_pick(N, K, &nt, &s, &waves);
   if (splits > 0) { s = splits; waves = 4; }
-  return ssd_gemm_pf_cfg(x_frag, w_frag, bias, y, M, N, K, ldy, epilogue, workspace, workspace_bytes, nt | (waves << 8), s, stream);
+  if (s > 16 || (K >> 5) % s != 0) return SSD_ERR_ARG;
+  pf_refine(M, N, K, s, &waves, &bps);
+  return ssd_gemm_pf_cfg(x_frag, w_frag, bias, y, M, N, K, ldy, epilogue, workspace, workspace_bytes,
+                         nt | (waves << 8) | (bps << 24), s, stream);
 }

@@ -142,6 +142,41 @@ def test_gemm_prefill_vs_oracle(H, M, N, K, splits):
     assert torch.equal(y2.view(torch.int16), y.view(torch.int16))          # deterministic
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(128, 26880, 512, 2), (97, 26880, 256, 1), (128, 10240, 2048, 4)])
+def test_gemm_prefill_launch_shapes_are_bit_identical(H, M, N, K, splits):
+    """The launch-shape variants of csrc/gemm_pf.hip (3..8 waves per workgroup, one or two 16-row groups per wave, one or two
+    k-steps per barrier) only change WHO computes a tile, never the K order inside a split: every variant must equal the plain
+    4-wave form bit for bit, and that one the oracle.  (The 5-wave form is the default for the 70B qkv matrix, 10240 rows.)"""
+    torch.manual_seed(N + K)
+    x = torch.randn(M, K).to(BF)
+    w = (torch.randn(N, K) * 0.05).to(BF)
+    xf, wf = to_frag_dev(x), to_frag_dev(w)
+    ws = torch.zeros(16 * M * N, dtype=torch.float32, device="cuda")
+
+    def run(nt):
+        y = torch.full((M, N), float("nan"), dtype=BF, device="cuda")
+        H.gemm_pf(xf, wf, y, M, N, K, N, ws, splits=splits, nt=nt)
+        return y
+
+    base = run(2 | 4 << 8 | 8 << 16 | 1 << 24)
+    assert_close_bf16(base, O.linear(x, w), max_ulp=1, max_frac=0.03, rel_floor=2 ** -7, what="prefill gemm rows")
+    tried = 0
+    for ntile, waves_list in ((2, (3, 4, 5, 6, 7, 8)), (1, (4, 8))):
+        for waves in waves_list:
+            if N % (16 * ntile * waves):
+                continue
+            for bps in (1, 2):
+                if (ntile, waves, bps) in ((2, 6, 1),):
+                    continue                      # not instantiated
+                y = run(ntile | waves << 8 | 8 << 16 | bps << 24)
+                assert torch.equal(y.view(torch.int16), base.view(torch.int16)), (ntile, waves, bps)
+                tried += 1
+    assert tried >= 8
+    ydef = torch.full((M, N), float("nan"), dtype=BF, device="cuda")
+    H.gemm_pf(xf, wf, ydef, M, N, K, N, ws, splits=splits)           # the default launch shape for this split count
+    assert torch.equal(ydef.view(torch.int16), base.view(torch.int16))
+
+
 @pytest.mark.parametrize("M,splits", [(40, 0), (128, 0), (100, 1), (128, 1)])
 def test_gemm_prefill_silu_epilogue(H, M, splits):
     torch.manual_seed(M)
