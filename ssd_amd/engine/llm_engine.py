@@ -282,6 +282,7 @@ class LLMEngine:
             dist.broadcast_object_list([("generate", prompts, sampling_params)], src=0, group=self.topo.ctl_group)
         for k, v in _fresh_metrics().items():
             METRICS[k] = v
+        self._capped_ids.clear()            # finish reasons are per generate() call
         if not isinstance(sampling_params, list):
             sampling_params = [sampling_params] * len(prompts)
         for prompt, sp in zip(prompts, sampling_params):
