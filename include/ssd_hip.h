@@ -136,6 +136,13 @@ int ssd_rope_store_kv(const void* qkv_rows, const int64_t* positions, const floa
                       const int32_t* slot_mapping, void* q_out_rows, void* k_cache, void* v_cache,
                       const void* q_norm_w, const void* k_norm_w, float eps, int T, int nh, int nkv, int hd,
                       int block_size, int qkv_perm, void* stream);
+/* Same, with the QKV rows given as `splits` fp32 split-K slabs parts[s][T][(nh+2nkv)*hd] of the prefill GEMM (ssd_gemm_pf with
+ * epilogue 2): a value is bf16(slab 0 + slab 1 + ...), what the GEMM's own epilogue (the F.linear store, ssd/layers/linear.py:98)
+ * would have written -- bit-identical to ssd_gemm_pf rows + ssd_rope_store_kv, one launch less per prefill layer. */
+int ssd_rope_store_kv_parts(const float* parts, int splits, const int64_t* positions, const float* cos_sin,
+                            const int32_t* slot_mapping, void* q_out_rows, void* k_cache, void* v_cache,
+                            const void* q_norm_w, const void* k_norm_w, float eps, int T, int nh, int nkv, int hd,
+                            int block_size, int qkv_perm, void* stream);
 
 /* Attention.forward, all branches -- ssd/layers/attention.py:73-134.
  *   mode 0: causal, bottom-right aligned over context_lens (prefill :90-93, verify/glue :105-111,

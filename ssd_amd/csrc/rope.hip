@@ -9,7 +9,12 @@
 // The reference's slot semantics are kept: slot = block_id * block_size + pos_in_block.
 #include "common.h"
 
-__global__ void rope_store_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ positions,
+// PARTS: the QKV rows are not materialised -- the prefill GEMM (gemm_pf.hip, PF_EPI_PARTIALS) left S fp32 split-K slabs
+// parts[s][t][n]; a row's value is bf16(slab 0 + slab 1 + ... in that order), exactly what gemm_pf_epilogue_kernel would have
+// stored, so the result is bit-identical to "epilogue launch, then this kernel" with one launch less per layer.
+template <bool PARTS>
+__global__ void rope_store_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ parts, int S, size_t slab,
+                                  const int64_t* __restrict__ positions,
                                   const float* __restrict__ cos_sin, const int32_t* __restrict__ slots,
                                   bf16_t* __restrict__ q_out, bf16_t* __restrict__ k_cache,
                                   bf16_t* __restrict__ v_cache, const bf16_t* __restrict__ qn_w,
@@ -20,6 +25,23 @@ __global__ void rope_store_kernel(const bf16_t* __restrict__ qkv, const int64_t*
   const int v_items = nkv * (hd >> 3);
   const int row_w = (nh + 2 * nkv) * hd;
   const bf16_t* row = qkv + (size_t)t * row_w;
+  // 8 consecutive columns of row t as fp32 values of bf16 numbers
+  auto load8 = [&](int col, float (&x)[8]) {
+    if (PARTS) {
+      const float* src = parts + (size_t)t * row_w + col;
+      f32x4_t lo = *reinterpret_cast<const f32x4_t*>(src), hi = *reinterpret_cast<const f32x4_t*>(src + 4);
+      for (int z = 1; z < S; ++z) {
+        lo += *reinterpret_cast<const f32x4_t*>(src + (size_t)z * slab);
+        hi += *reinterpret_cast<const f32x4_t*>(src + (size_t)z * slab + 4);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { x[j] = round_bf(lo[j]); x[4 + j] = round_bf(hi[j]); }
+    } else {
+      const u32x4_t a = *reinterpret_cast<const u32x4_t*>(row + col);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { x[2 * j] = bf2f(a[j] & 0xffffu); x[2 * j + 1] = bf2f(a[j] >> 16); }
+    }
+  };
   const long pos = positions[t];
   const int slot = slots ? slots[t] : -1;
   const float* cs = cos_sin + (size_t)pos * hd;
@@ -31,17 +53,12 @@ __global__ void rope_store_kernel(const bf16_t* __restrict__ qkv, const int64_t*
     if (it < rot_items) {
       const int head = it / c16, c = it % c16;
       const bool is_q = head < nh;
-      const bf16_t* src = row + (size_t)head * hd;  // q heads then k heads are contiguous in qkv
+      const int src = head * hd;                    // q heads then k heads are contiguous in qkv
       // perm: the QKV GEMM wrote q/k heads in the rotation-paired order (layout.hip): chunk c of the first half
       // and its partner chunk of the second half are adjacent
-      const u32x4_t a = *reinterpret_cast<const u32x4_t*>(src + (perm ? c * 16 : c * 8));
-      const u32x4_t b = *reinterpret_cast<const u32x4_t*>(src + (perm ? c * 16 + 8 : half + c * 8));
       float x1[8], x2[8];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        x1[2 * j] = bf2f(a[j] & 0xffffu); x1[2 * j + 1] = bf2f(a[j] >> 16);
-        x2[2 * j] = bf2f(b[j] & 0xffffu); x2[2 * j + 1] = bf2f(b[j] >> 16);
-      }
+      load8(src + (perm ? c * 16 : c * 8), x1);
+      load8(src + (perm ? c * 16 + 8 : half + c * 8), x2);
       const bf16_t* nw = is_q ? qn_w : kn_w;
       if (nw) {  // per-head RMSNorm, rounded to bf16 before the rotation (separate kernels in the reference)
         float ss = 0.f;
@@ -76,22 +93,54 @@ __global__ void rope_store_kernel(const bf16_t* __restrict__ qkv, const int64_t*
     } else if (kv_base >= 0) {
       const int vi = it - rot_items;
       const int kvh = vi / (hd >> 3), c = vi % (hd >> 3);
-      const u32x4_t v = *reinterpret_cast<const u32x4_t*>(row + (size_t)(nh + nkv + kvh) * hd + c * 8);
+      u32x4_t v;
+      if (PARTS) {
+        float xv[8];
+        load8((nh + nkv + kvh) * hd + c * 8, xv);
+        v = u32x4_t{pack_bf2(xv[0], xv[1]), pack_bf2(xv[2], xv[3]), pack_bf2(xv[4], xv[5]), pack_bf2(xv[6], xv[7])};
+      } else {
+        v = *reinterpret_cast<const u32x4_t*>(row + (size_t)(nh + nkv + kvh) * hd + c * 8);
+      }
       *reinterpret_cast<u32x4_t*>(v_cache + (size_t)(kv_base + (long)kvh * bs) * hd + c * 8) = v;
     }
   }
+}
+
+static int rope_store_launch(const void* qkv_rows, const float* parts, int S, const int64_t* positions, const float* cos_sin,
+                             const int32_t* slot_mapping, void* q_out_rows, void* k_cache, void* v_cache,
+                             const void* q_norm_w, const void* k_norm_w, float eps, int T, int nh, int nkv,
+                             int hd, int block_size, int qkv_perm, void* stream) {
+  if (T <= 0 || nh <= 0 || nkv <= 0 || (hd != 64 && hd != 128 && hd != 256) || block_size <= 0) return SSD_ERR_SHAPE;
+  const int items = (nh + nkv) * (hd / 16) + nkv * (hd / 8);
+  int threads = ((items + 63) / 64) * 64;
+  if (threads > 512) threads = 512;
+  const size_t slab = (size_t)T * (nh + 2 * nkv) * hd;
+  if (parts)
+    hipLaunchKernelGGL(rope_store_kernel<true>, dim3(T), dim3(threads), 0, (hipStream_t)stream, (const bf16_t*)nullptr, parts, S,
+                       slab, positions, cos_sin, slot_mapping, (bf16_t*)q_out_rows, (bf16_t*)k_cache, (bf16_t*)v_cache,
+                       (const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w, eps, nh, nkv, hd, block_size, qkv_perm);
+  else
+    hipLaunchKernelGGL(rope_store_kernel<false>, dim3(T), dim3(threads), 0, (hipStream_t)stream, (const bf16_t*)qkv_rows,
+                       (const float*)nullptr, 0, slab, positions, cos_sin, slot_mapping, (bf16_t*)q_out_rows, (bf16_t*)k_cache,
+                       (bf16_t*)v_cache, (const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w, eps, nh, nkv, hd, block_size, qkv_perm);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
 extern "C" int ssd_rope_store_kv(const void* qkv_rows, const int64_t* positions, const float* cos_sin,
                                  const int32_t* slot_mapping, void* q_out_rows, void* k_cache, void* v_cache,
                                  const void* q_norm_w, const void* k_norm_w, float eps, int T, int nh, int nkv,
                                  int hd, int block_size, int qkv_perm, void* stream) {
-  if (T <= 0 || nh <= 0 || nkv <= 0 || (hd != 64 && hd != 128 && hd != 256) || block_size <= 0) return SSD_ERR_SHAPE;
-  const int items = (nh + nkv) * (hd / 16) + nkv * (hd / 8);
-  int threads = ((items + 63) / 64) * 64;
-  if (threads > 512) threads = 512;
-  hipLaunchKernelGGL(rope_store_kernel, dim3(T), dim3(threads), 0, (hipStream_t)stream, (const bf16_t*)qkv_rows,
-                     positions, cos_sin, slot_mapping, (bf16_t*)q_out_rows, (bf16_t*)k_cache, (bf16_t*)v_cache,
-                     (const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w, eps, nh, nkv, hd, block_size, qkv_perm);
-  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+  if (!qkv_rows) return SSD_ERR_ARG;
+  return rope_store_launch(qkv_rows, nullptr, 0, positions, cos_sin, slot_mapping, q_out_rows, k_cache, v_cache, q_norm_w, k_norm_w,
+                           eps, T, nh, nkv, hd, block_size, qkv_perm, stream);
+}
+
+// Same, reading the QKV rows from `splits` fp32 split-K slabs [splits][T][(nh + 2 nkv) * hd] (ssd_gemm_pf with PF_EPI_PARTIALS).
+extern "C" int ssd_rope_store_kv_parts(const float* parts, int splits, const int64_t* positions, const float* cos_sin,
+                                       const int32_t* slot_mapping, void* q_out_rows, void* k_cache, void* v_cache,
+                                       const void* q_norm_w, const void* k_norm_w, float eps, int T, int nh, int nkv,
+                                       int hd, int block_size, int qkv_perm, void* stream) {
+  if (!parts || splits < 1 || splits > 16) return SSD_ERR_ARG;
+  return rope_store_launch(nullptr, parts, splits, positions, cos_sin, slot_mapping, q_out_rows, k_cache, v_cache, q_norm_w,
+                           k_norm_w, eps, T, nh, nkv, hd, block_size, qkv_perm, stream);
 }

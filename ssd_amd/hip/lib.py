@@ -41,6 +41,8 @@ SIGNATURES = {
     "ssd_gemm_pf_cfg": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int, c_int, c_void_p],
     "ssd_rope_store_kv": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "ssd_rope_store_kv_parts": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "ssd_attn_paged": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                        c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int,
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],

@@ -113,6 +113,14 @@ def rope_store_kv(qkv_rows, positions, cos_sin, slot_mapping, q_out, k_cache, v_
                                             block_size, qkv_perm, _stream()), "ssd_rope_store_kv")
 
 
+def rope_store_kv_parts(parts, splits: int, positions, cos_sin, slot_mapping, q_out, k_cache, v_cache, T, nh, nkv, hd, block_size,
+                        q_norm_w=None, k_norm_w=None, eps: float = 0.0, qkv_perm: int = 0):
+    """rope_store_kv over the prefill GEMM's fp32 split-K slabs [splits][T][(nh + 2 nkv) * hd] (gemm_pf, PF_EPI_PARTIALS)."""
+    _check(load_library().ssd_rope_store_kv_parts(_p(parts), splits, _p(positions), _p(cos_sin), _p(slot_mapping), _p(q_out),
+                                                  _p(k_cache), _p(v_cache), _p(q_norm_w), _p(k_norm_w), eps, T, nh, nkv, hd,
+                                                  block_size, qkv_perm, _stream()), "ssd_rope_store_kv_parts")
+
+
 def rows_to_frag_qkv(src, dst, nh: int, nkv: int, hd: int, K: int):
     _check(load_library().ssd_rows_to_frag_qkv(_p(src), _p(dst), nh, nkv, hd, K, _stream()), "ssd_rows_to_frag_qkv")
 

@@ -223,6 +223,10 @@ class HipDecoder:
         """o_proj / down_proj of ONE prefill chunk may leave their split-K partials in the workspace for the norm that follows."""
         return self.pf_parts and not self.use_coll and 32 < T <= 128 and self._pf_eligible(N, K) and self._ws_pf is not None
 
+    @staticmethod
+    def _pf_splits(T: int, N: int, K: int) -> int:
+        return H.gemm_pf_workspace_bytes(T, N, K) // (4 * T * N)
+
     def _gemm_pf_partials(self, xf, K, w, N, T) -> int:
         """Prefill GEMM stopped after its split-K stage (csrc/gemm_pf.hip PF_EPI_PARTIALS): fp32 slabs [S][T][N] in the workspace;
         returns S.  The consumer is ssd_rmsnorm_parts -- one launch per GEMM less."""
@@ -369,6 +373,14 @@ class HipDecoder:
         if small or (16 < T <= 32 and not cfg.qk_norm):      # T in 17..32 (tree-decode step): the two-token-tile variant
             H.gemm_fused(w[p + "self_attn.qkv_proj.weight"], T, self.qkv_n, self.h, H.FEPI_QKV_ROPE, x_frag=xf,
                          bias=w.get(p + "self_attn.qkv_proj.bias"), **rope)
+        elif (not gemm_only and w.get(p + "self_attn.qkv_proj.bias") is None and self._pf_partials_ok(T, self.qkv_n, self.h)
+              and self._pf_splits(T, self.qkv_n, self.h) > 1):
+            # single-chunk prefill of a big QKV matrix: its split-K slabs stay in the workspace and the RoPE / KV-store kernel
+            # sums them (bit-identical to the GEMM's epilogue launch + rope_store_kv; one launch less per layer)
+            S = self._gemm_pf_partials(xf, self.h, w[p + "self_attn.qkv_proj.weight"], self.qkv_n, T)
+            H.rope_store_kv_parts(self._ws_pf, S, positions, self.cos_sin, slot_mapping, self.buf_q, kc, vc, T, self.nh, self.nkv,
+                                  self.hd, self.block_size, q_norm_w=w.get(p + "self_attn.q_norm.weight"),
+                                  k_norm_w=w.get(p + "self_attn.k_norm.weight"), eps=cfg.rms_norm_eps, qkv_perm=1)
         else:
             self._gemm(xf, self.h, w[p + "self_attn.qkv_proj.weight"], self.qkv_n, self.buf_qkv, T, self.qkv_n,
                        bias=w.get(p + "self_attn.qkv_proj.bias"))

@@ -278,6 +278,59 @@ def test_rope_store_golden(H, golden):
     assert torch.equal(LY.kv_hnd_to_nhd(vc).view(torch.int16), vref.view(torch.int16))
 
 
+@pytest.mark.parametrize("qk_norm,perm", [(False, 1), (True, 1), (False, 0)])
+def test_rope_store_from_prefill_partials_equals_rows(H, qk_norm, perm):
+    """ssd_rope_store_kv_parts (round 3): the prefill QKV GEMM leaves its split-K slabs in the workspace and the RoPE / KV-store
+    kernel sums them -- bit-identical to the GEMM's epilogue launch followed by ssd_rope_store_kv, both on hand-made slabs (incl.
+    -0.0 sums and skipped slots) and behind the real GEMM at its default split count."""
+    torch.manual_seed(11 + perm)
+    T, nh, nkv, hd, bs, nb, S = 100, 8, 2, 128, 16, 8, 4
+    N = (nh + 2 * nkv) * hd
+    parts = torch.randn(S, T, N) * 0.5
+    parts[:, 3, :64] = -0.0                                   # a -0.0 + -0.0 + ... sum must stay -0.0 like the epilogue's
+    parts[1:, 5, :] = 0.0
+    rows = parts[0].clone()
+    for z in range(1, S):
+        rows = rows + parts[z]                                # fp32, slab order
+    rows = rows.to(BF)
+    qn, kn = ((1 + 0.1 * torch.randn(hd)).to(BF), (1 + 0.1 * torch.randn(hd)).to(BF)) if qk_norm else (None, None)
+    pos = torch.randint(0, 250, (T,), dtype=torch.int64)
+    cache = O.make_cos_sin_cache(hd, 256, 5e5)
+    slots = torch.randperm(nb * bs)[:T].to(torch.int32)
+    slots[7] = -1
+
+    def run(fn, src, *extra):
+        q_out = torch.zeros(T, nh * hd, dtype=BF, device="cuda")
+        kc = torch.zeros(nb, nkv, bs, hd, dtype=BF, device="cuda")
+        vc = torch.zeros_like(kc)
+        fn(src, *extra, dev(pos), dev(cache), dev(slots), q_out, kc, vc, T, nh, nkv, hd, bs,
+           q_norm_w=None if qn is None else dev(qn), k_norm_w=None if kn is None else dev(kn), eps=1e-6, qkv_perm=perm)
+        torch.cuda.synchronize()
+        return [t.view(torch.int16) for t in (q_out, kc, vc)]
+
+    a = run(H.rope_store_kv, dev(rows))
+    b = run(H.rope_store_kv_parts, dev(parts.contiguous()), S)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    # behind the real prefill GEMM (default split count of this shape)
+    M, K = T, 2048
+    x = torch.randn(M, K).to(BF)
+    w = (torch.randn(N, K) * 0.03).to(BF)
+    xf, wf = to_frag_dev(x), to_frag_dev(w)
+    nbytes = H.gemm_pf_workspace_bytes(M, N, K)
+    Sd = nbytes // (4 * M * N)
+    assert Sd > 1
+    ws = torch.full((nbytes // 4 + 64,), float("nan"), dtype=torch.float32, device="cuda")
+    y = torch.zeros(M, N, dtype=BF, device="cuda")
+    H.gemm_pf(xf, wf, y, M, N, K, N, ws)
+    a = run(H.rope_store_kv, y)
+    ws.fill_(float("nan"))
+    H.gemm_pf(xf, wf, None, M, N, K, N, ws, epilogue=H.PF_EPI_PARTIALS)
+    b = run(H.rope_store_kv_parts, ws, Sd)
+    for x_, y_ in zip(a, b):
+        assert torch.equal(x_, y_)
+
+
 def test_rope_head_norm(H):
     torch.manual_seed(3)
     T, nh, nkv, hd, bs, nb = 5, 8, 2, 128, 16, 4
