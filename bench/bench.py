@@ -27,7 +27,6 @@ from random import randint, seed
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ssd_amd import LLM, SamplingParams  # noqa: E402
-from ssd_amd.engine.llm_engine import METRICS  # noqa: E402
 
 LLAMA = {"1": ("Llama-3.2-1B-Instruct", "llama-3.2-1b"), "3": ("Llama-3.2-3B-Instruct", "llama-3.2-3b"),
          "8": ("Llama-3.1-8B-Instruct", "llama-3.1-8b"), "70": ("Llama-3.1-70B-Instruct", "llama-3.1-70b")}

@@ -18,7 +18,6 @@ single-rounding form (verified bit-exact against the compiled modules on CPU, se
 """
 from __future__ import annotations
 
-import math
 import torch
 
 BF16 = torch.bfloat16

@@ -4,7 +4,6 @@ forward with the slab path on / off.  Each number = hipGraph of the 16 layers' l
     python profiles/micro/draft_probe.py > gpurun_out/draft_probe.txt"""
 import os
 import sys
-import time
 
 import torch
 

@@ -9,7 +9,6 @@ scaled to 80 layers.
 import dataclasses
 import os
 import sys
-import types
 
 import torch
 import torch.distributed as dist

@@ -9,7 +9,7 @@ weights are synthetic (seeded N(0, weights_std), norm weights 1)."""
 from __future__ import annotations
 
 import os
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 
 from ssd_amd.model_config import ModelConfig, PRESETS
 

@@ -2,7 +2,6 @@
 golden vectors produced by the reference's own code.  Bit-exact for integer results; for bf16 results the
 bar is "identical up to the accumulation order": at most 1 bf16 ulp on a small fraction of elements (2 ulp for
 attention, whose P operand is bf16 as in FlashAttention).  fp32 GEMM output is checked to 1e-3 absolute."""
-import math
 
 import pytest
 import torch
