@@ -23,8 +23,11 @@ Workload (``--workload``):
   c2   Llama-3.1-8B target + 1B draft, sync k = 6 on one GPU (configs[1]).
   c5t  Qwen3-32B target + Qwen3-0.6B draft, async k = 7 f = 3 (configs[4] without the draft data-parallelism).
   c4e  Llama-3.1-70B target + its EAGLE-3 draft (one layer, h 6144, 32000-token head), async k = 7 f = 3 -- the reference's
-       `bench.py --eagle`.  Synthetic weights cannot make an EAGLE draft PREDICT its target; the "peaky" recipe (the same three
-       LM-head rows scaled in both models) makes them agree now and then, so hits, partial acceptance and extend rows occur.
+       `bench.py --eagle`.  ``--eagle-pair constructed`` (default): the target is a correlated-pair target whose head favours the
+       draft vocabulary and the draft is wired to compute the target's token map from the token it is fed
+       (ssd_amd/weights.py eagle_pair_recipe; through the engine on the CPU oracle: accepted length 3.4-3.9 of 4);
+       ``--eagle-pair peaky``: the same three LM-head rows scaled in both models (what rounds 2-3 measured: hits and partial
+       acceptance occur, accepted length ~1.05).
   tiny 2-layer toy shapes (plumbing check).
 Weights are synthetic (no checkpoints exist offline).  ``--pair correlated`` (default) builds the two models with the
 "correlated pair" recipe of ssd_amd/weights.py: real shapes, every matrix streamed in full, values constructed so that
@@ -72,6 +75,8 @@ def parse(argv=None):
     ap.add_argument("--draft-dp", type=int, default=0, help="dedicated placement: draft ranks (data-parallel tree shards); 0 = all ranks beyond the target's")
     ap.add_argument("--pair", default="correlated", choices=["correlated", "random"])
     ap.add_argument("--pair-snr", type=float, default=8.0)
+    ap.add_argument("--eagle-pair", default="constructed", choices=["constructed", "peaky"],
+                    help="c4e: how target and EAGLE-3 draft are made to agree (ssd_amd/weights.py eagle_pair_recipe / peaky_rows)")
     ap.add_argument("--input-len", type=int, default=128)
     ap.add_argument("--max-model-len", type=int, default=8192)
     ap.add_argument("--eager", action="store_true")
@@ -341,11 +346,16 @@ def main():
         # LM-head GEMM streams a [V, h] matrix either way, so bytes and kernels are unchanged
         dcfg = dataclasses.replace(dcfg, tie_word_embeddings=False)
         recipe = {"kind": "pair", "shared": min(dcfg.hidden_size, tcfg.hidden_size), "snr": args.pair_snr, "layer_gain": 0.005}
-    if args.pair == "correlated" and eagle:
-        # an EAGLE-3 draft reads the target's activations: no weight construction makes a RANDOM one predict its target, but
-        # scaling the LM-head rows of the same few tokens in both models ("peaky", ssd_amd/weights.py peaky_rows) makes them
-        # agree often enough that cache hits, partial acceptance and the extend rows of the glue all run (every matrix keeps
-        # its shape and is streamed in full)
+    if args.pair == "correlated" and eagle and args.eagle_pair == "constructed":
+        # the target is a correlated-pair target over nkv * hd shared dims whose head favours the draft vocabulary; the one-layer
+        # draft is wired to compute the target's own token map from the token it is fed (one-hot self attention, value = token
+        # half - conditioning half): ssd_amd/weights.py _eagle_pair_tensor.  Every matrix keeps its shape and is streamed in full.
+        from ssd_amd import weights as W
+        recipe = W.eagle_pair_recipe(tcfg, dataclasses.replace(dcfg, d_model_target=tcfg.hidden_size), draft_seed=1,
+                                     snr=args.pair_snr)
+    elif args.pair == "correlated" and eagle:
+        # "peaky" (rounds 2-3): the LM-head rows of the same three tokens scaled in both models (ssd_amd/weights.py peaky_rows):
+        # they agree now and then, enough for cache hits, partial acceptance and the extend rows of the glue to run
         recipe = {"kind": "peaky", "gain": 6.0, "peaks": 3, "draft_seed": 1, "draft_vocab": dcfg.draft_vocab_size,
                   "target_vocab": tcfg.vocab_size}
     # placement of the async draft.  auto: up to 4 GPUs every GPU is worth more as a tensor-parallel target rank (the draft
@@ -500,13 +510,15 @@ def main():
         "dtype": "bf16",
         "data": "synthetic token ids (random.seed(0), randint(0,10000)) + synthetic seeded weights "
                 + ("(peaky recipe: the LM-head rows of the same 3 tokens scaled x6 in the target and in its EAGLE-3 draft, so that they agree now and then)"
+                   if (recipe and eagle and recipe["kind"] == "peaky") else
+                   f"(constructed EAGLE pair, snr {args.pair_snr}: a correlated-pair target whose head favours the draft vocabulary + a draft wired to compute the target's token map)"
                    if (recipe and eagle) else
                    f"(correlated-pair recipe, snr {args.pair_snr}: real shapes, values built so draft and target mostly agree)"
                    if recipe else "(independent N(0,0.02): acceptance ~0)"),
         "config": {"workload": f"{args.workload}: {tname} target TP={tp} + {dname} draft, {mode}, b=1, temp=0, "
                                f"input_len={args.input_len}, kv block 256, max_model_len {max_len}",
                    "parallelism": f"tp{tp}" + (f"+draft{ndraft}" if dedicated else ""), "hipgraph": not args.eager,
-                   "pair": ("peaky" if recipe else "random") if eagle else args.pair, "eagle3": eagle,
+                   "pair": (("peaky" if recipe["kind"] == "peaky" else "constructed") if recipe else "random") if eagle else args.pair, "eagle3": eagle,
                    "parity": "greedy token streams bit-exact vs the reference-driven traces up to recorded near-ties (top-2 margin <= 1 bf16 "
                              "ulp); the north_star's '1e-3 abs on verify logits' is enforced on the fp32 LM-head epilogue and, at model "
                              "level, as rms|HIP - fp64 truth| <= 1.25 x rms|reference - fp64 truth| + 1e-3 (two bf16 pipelines cannot "

@@ -109,6 +109,120 @@ def _pair_tensor(name: str, shape, seed: int, std: float, gen_device: str, recip
     return None
 
 
+def eagle_pair_recipe(target: ModelConfig, draft: ModelConfig, draft_seed: int, snr: float = 8.0, layer_gain: float = 0.005,
+                      boost: float = 2.0, seed: int = 1234) -> dict:
+    """The recipe dict (config.weights_recipe) of the constructed target + EAGLE-3 draft pair: see _eagle_pair_tensor."""
+    assert draft.family == "eagle3" and draft.d_model_target == target.hidden_size
+    sig = min(draft.num_kv_heads * draft.head_dim, target.hidden_size, draft.hidden_size)
+    return {"kind": "eagle_pair", "sig": sig, "snr": snr, "layer_gain": layer_gain, "boost": boost, "seed": seed,
+            "draft_seed": draft_seed, "draft_vocab": draft.draft_vocab_size, "target_vocab": target.vocab_size,
+            "target_hidden": target.hidden_size, "draft_heads": (draft.num_heads, draft.num_kv_heads, draft.head_dim)}
+
+
+def eagle_pair_gain(recipe: dict) -> float:
+    """Gain of the shared embedding dims inside the TARGET's embedding rows (logit SNR = recipe["snr"], as in _pair_tensor)."""
+    ds, ht = int(recipe["sig"]), int(recipe["target_hidden"])
+    return float(recipe.get("snr", 8.0)) * ((ht - ds) / ds) ** 0.5 if ht > ds else 1.0
+
+
+def _eagle_pair_tensor(name: str, shape, seed: int, std: float, gen_device: str, recipe: dict) -> torch.Tensor | None:
+    """A target and its EAGLE-3 draft that AGREE by construction (round 3; the "peaky" pair only made both heads favour the same
+    three tokens).  The target is the correlated-pair target of _pair_tensor over ds = recipe["sig"] shared dims: it embeds a
+    token as [gain * E_b[tok] | noise], reads out with [H_b | noise], its layers perturb the residual stream only slightly
+    (layer_gain), so its greedy next token is mostly g(tok) = argmax_v H_b[v] . E_b[tok]; the head rows of the tokens the draft
+    vocabulary contains are scaled by recipe["boost"], so that the argmax falls inside that vocabulary.  The one-layer draft is
+    wired to compute the same g from the token it is fed, whatever its conditioning row holds:
+      * embedding [E_b[tok] | 0]; both input norms carry the weight sqrt(ds / h), so a row [x | ~0] comes out as ~[x | 0];
+      * q / k = beta * A_kvhead . E_b[tok] (the conditioning half of the 2h-wide input is ignored): a row's score with ITSELF is
+        beta^2 * sqrt(hd), with any other row ~N(0, beta^4) (RoPE leaves same-position dot products unchanged), so the softmax is
+        one-hot on the row itself;
+      * v = (token half) - (conditioning half) on the ds shared dims (ds = nkv * hd: one 128-wide slice per kv head), o_proj puts
+        the slice of the first q head of each group back in place: attention output = E_b[tok] - conditioning, and the residual
+        add of the conditioning leaves [E_b[tok] | ~0] whatever the conditioning was (fc(target taps) or the previous prenorm);
+      * the MLP is scaled down like the target's, the head is [H_b[d2t] | 0]: logits = H_b . E_b[tok] -> g(tok) within the draft
+        vocabulary.  fc copies the shared dims of the first tapped activation (divided by the target's gain), i.e. the first
+        conditioning row has the same form as a prenorm.
+    Every matrix keeps its real shape and is streamed in full; only the values are constructed."""
+    ds = int(recipe["sig"])
+    pseed = int(recipe.get("seed", 1234))
+    lg = float(recipe.get("layer_gain", 0.005))
+    V, Vd, ht = int(recipe["target_vocab"]), int(recipe["draft_vocab"]), int(recipe["target_hidden"])
+    is_draft = recipe.get("family") == "eagle3"
+
+    def randn(tag, shp):
+        g = torch.Generator(device=gen_device)
+        g.manual_seed(_name_seed(pseed, tag))
+        return torch.randn(shp, generator=g, device=gen_device, dtype=torch.float32)
+
+    def own(shp):
+        g = torch.Generator(device=gen_device)
+        g.manual_seed(_name_seed(seed, name))
+        return torch.randn(shp, generator=g, device=gen_device, dtype=torch.float32)
+
+    def draft_targets():            # target-vocabulary id of every draft-vocabulary id (d2t of the draft seed)
+        gc = torch.Generator()
+        gc.manual_seed(_name_seed(int(recipe["draft_seed"]), "d2t"))
+        return torch.randperm(V, generator=gc)[:Vd].sort().values
+
+    if (name.endswith("o_proj.weight") and not is_draft) or name.endswith("down_proj.weight"):
+        return (std * lg * own(shape)).to(BF16)
+    if not is_draft:
+        if name == "model.embed_tokens.weight":
+            h = shape[1]
+            assert shape[0] == V and h == ht and h >= ds
+            base = randn("epair.embed", (V, ds)) * eagle_pair_gain(recipe)
+            return (base if h == ds else torch.cat([base, own((V, h - ds))], dim=1)).to(BF16)
+        if name == "lm_head.weight":
+            h = shape[1]
+            base = randn("epair.head", (V, ds))
+            out = base if h == ds else torch.cat([base, own((V, h - ds))], dim=1)
+            out[draft_targets().to(out.device)] *= float(recipe.get("boost", 2.0))
+            return (out * std).to(BF16)
+        return None
+    # ---- the EAGLE-3 draft ----
+    nh, nkv, hd = (int(x) for x in recipe["draft_heads"])
+    assert ds <= nkv * hd
+    if name == "model.embed_tokens.weight":
+        h = shape[1]
+        out = torch.zeros(shape, dtype=torch.float32, device=gen_device)
+        out[:, :ds] = randn("epair.embed", (V, ds))
+        return out.to(BF16)
+    if name == "lm_head.weight":
+        out = torch.zeros(shape, dtype=torch.float32, device=gen_device)
+        out[:, :ds] = randn("epair.head", (V, ds))[draft_targets().to(gen_device)]
+        return (out * std).to(BF16)
+    if name == "fc.weight":
+        out = torch.zeros(shape, dtype=torch.float32, device=gen_device)
+        idx = torch.arange(ds, device=gen_device)
+        out[idx, idx] = 1.0 / eagle_pair_gain(recipe)          # first tap, shared dims
+        return out.to(BF16)
+    if name.endswith("input_layernorm.weight") or name.endswith("conditioning_feature_ln.weight"):
+        return torch.full(shape, (ds / shape[0]) ** 0.5, dtype=torch.float32, device=gen_device).to(BF16)
+    if name.endswith("qkv_proj.weight"):
+        h = shape[1] // 2
+        out = torch.zeros(shape, dtype=torch.float32, device=gen_device)
+        beta = (16.0 / max(hd ** 0.5 - 3.5, 1.0)) ** 0.5
+        grp = nh // nkv
+        for k in range(nkv):
+            A = randn(f"epair.A.{k}", (hd, ds)) * (beta / ds ** 0.5)
+            for i in range(k * grp, (k + 1) * grp):
+                out[i * hd:(i + 1) * hd, :ds] = A                                   # q heads of the group
+            out[(nh + k) * hd:(nh + k + 1) * hd, :ds] = A                           # its k head
+            r = torch.arange(min(hd, max(ds - k * hd, 0)), device=gen_device)
+            rows = (nh + nkv + k) * hd + r                                          # its v head: token half - conditioning half
+            out[rows, k * hd + r] = 1.0
+            out[rows, h + k * hd + r] = -1.0
+        return out.to(BF16)
+    if name.endswith("o_proj.weight"):
+        out = torch.zeros(shape, dtype=torch.float32, device=gen_device)
+        grp = nh // nkv
+        for k in range(nkv):
+            r = torch.arange(min(hd, max(ds - k * hd, 0)), device=gen_device)
+            out[k * hd + r, (k * grp) * hd + r] = 1.0
+        return out.to(BF16)
+    return None
+
+
 def peaky_rows(recipe: dict) -> tuple[torch.Tensor, torch.Tensor]:
     """(draft-vocabulary ids, target-vocabulary ids) of the few tokens whose LM-head rows the "peaky" recipe scales in BOTH a
     target and its EAGLE-3 draft.  Random models never agree, and without agreement the speculation-cache hit path, partial
@@ -131,6 +245,10 @@ def synthetic_tensor(name: str, shape, seed: int, std: float, gen_device: str, n
     oracle comparisons); "cuda" is for the multi-GB benchmark models."""
     if recipe is not None and recipe.get("kind") == "pair":
         t = _pair_tensor(name, shape, seed, std, gen_device, recipe)
+        if t is not None:
+            return t
+    if recipe is not None and recipe.get("kind") == "eagle_pair":
+        t = _eagle_pair_tensor(name, shape, seed, std, gen_device, recipe)
         if t is not None:
             return t
     g = torch.Generator(device=gen_device)
@@ -178,8 +296,12 @@ def synthetic_weights(cfg: ModelConfig, seed: int, std: float, rank: int = 0, tp
     if cfg.family == "eagle3":          # d2t needs the target vocabulary size; the draft is never tensor-parallel
         assert tp == 1
         recipe = dict(recipe or {}, target_vocab=cfg.vocab_size)
+        if recipe.get("kind") == "eagle_pair":
+            assert int(recipe["draft_seed"]) == seed and int(recipe["draft_vocab"]) == cfg.draft_vocab_size, "eagle_pair recipe: draft seed / vocabulary mismatch"
         if recipe.get("kind") == "peaky":
             assert int(recipe["draft_seed"]) == seed and int(recipe["draft_vocab"]) == cfg.draft_vocab_size, "peaky recipe: draft seed / vocabulary mismatch"
+    if recipe is not None and recipe.get("kind") == "eagle_pair":
+        recipe = dict(recipe, family=cfg.family)
     for name, shape in param_shapes(cfg):
         w = shard_param(cfg, name, synthetic_tensor(name, shape, seed, std, gen_device, norm_jitter, recipe), rank, tp)
         yield name, (w.to(out_device) if out_device is not None else w)

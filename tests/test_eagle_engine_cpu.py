@@ -40,6 +40,48 @@ def test_eagle_async_stream_is_exact_and_uses_hit_and_extend_paths():
     assert stats["requests"] == len(lens)
 
 
+def test_constructed_eagle_pair_agrees_with_its_target():
+    """weights.eagle_pair_recipe (bench.py --workload c4e): a target and an EAGLE-3 draft built so that the draft computes the
+    target's own token map from the token it is fed (one-hot self attention, value = token half - conditioning half).  Through
+    the real engine: the stream is the target's greedy stream, most speculated tokens are accepted and most requests hit the
+    speculation cache -- for two geometries (2 kv heads of 32 dims; 1 kv head, draft narrower than the target)."""
+    from oracle.runner import oracle_runner_factory
+    from ssd_amd import weights as W
+    from ssd_amd.engine.llm_engine import LLMEngine
+    from ssd_amd.model_config import ModelConfig
+    from ssd_amd.sampling_params import SamplingParams
+    from tests.eagle_util import TAPS
+    for h_t, h_d, nkv_d, V, Vd in ((128, 128, 2, 2048, 512), (256, 96, 1, 2048, 512)):
+        hd = 32
+        t = ModelConfig("llama", h_t, 4, h_t // hd, 2, hd, 2 * h_t, V, 1e-5, 5e5, 1024, False)
+        d = ModelConfig("eagle3", h_d, 1, h_d // hd, nkv_d, hd, 2 * h_d, V, 1e-5, 5e5, 1024, False, draft_vocab_size=Vd,
+                        d_model_target=h_t, eagle_taps=len(TAPS))
+        rec = W.eagle_pair_recipe(t, d, draft_seed=1)
+        assert rec["sig"] == nkv_d * hd
+        tw = W.synthetic_state_dict(t, 0, 0.1, recipe=rec)
+        dw = W.synthetic_state_dict(d, 1, 0.1, recipe=rec)
+        # the draft vocabulary's head rows are the target's shared head dims at d2t's positions; the target boosts exactly those
+        tgt = torch.arange(Vd) + dw["d2t"]
+        ds = rec["sig"]
+        a, b = dw["lm_head.weight"][:, :ds].float(), tw["lm_head.weight"][tgt, :ds].float() / rec["boost"]
+        assert torch.allclose(a, b, rtol=2e-2, atol=1e-3) and float(dw["lm_head.weight"][:, ds:].abs().max()) == 0.0
+        factory = oracle_runner_factory(weights_target=tw, weights_draft=dw)
+        prompt = [[(7 * j + 1) % V for j in range(13)]]
+        sp = SamplingParams(temperature=0, max_new_tokens=48, ignore_eos=True)
+        eng = LLMEngine("t", runner_factory=factory, **dict(ENGINE_KW, hf_config=t, max_num_seqs=1))
+        ar, _ = eng.generate(prompt, sp, use_tqdm=False)
+        eng.exit()
+        eng = LLMEngine("t", runner_factory=factory, inprocess_draft=True, **eagle_kwargs(t, d))
+        out, m = eng.generate(prompt, sp, use_tqdm=False)
+        stats = eng.draft_server.stats
+        eng.exit()
+        assert out[0]["token_ids"] == ar[0]["token_ids"]
+        assert all(int(x) in set(tgt.tolist()) for x in ar[0]["token_ids"][1:])       # the target stays inside the draft vocabulary
+        lens = m["accepted_suffix_lens_with_recovery"]
+        assert sum(lens) / len(lens) >= 2.5, lens                                       # of at most K + 1 = 4
+        assert stats["hits"] >= 0.7 * stats["requests"], stats
+
+
 def test_eagle_async_batch():
     ar, _, _ = generate("ar", bs=3, new_tokens=24)
     asy, m, stats = generate("eagle", bs=3, new_tokens=24)
