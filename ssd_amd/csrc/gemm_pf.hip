@@ -15,6 +15,7 @@
 //    atomics), adds the bias, rounds once to bf16 and applies the same epilogues as gemm.hip (rows | SiLU*mul ->
 //    fragment-major).  The partials are ~6-25 % extra traffic and mostly live in the 256 MiB Infinity Cache.
 #include "common.h"
+#include <cstdlib>
 
 enum { PF_EPI_ROWS = 0, PF_EPI_SILU_FRAG = 1, PF_EPI_PARTIALS = 2 };
 // PF_EPI_PARTIALS: stop after the split-K GEMM -- the fp32 partials ws[z][m][n] (z < splits, slab stride M * N) are the
@@ -28,7 +29,7 @@ constexpr int PF_U = 4;      // k-steps of W in flight per wave; every K split i
 // direct: 0 = write fp32 partials for the epilogue kernel; 1 / 2 = the K range is not split, finish in place
 // (1: rows bf16 + bias, 2: SiLU(gate) * up -> fragment-major) and skip the workspace round trip.
 // BPS = k-steps per workgroup barrier: the x ring holds two PHASES of BPS k-steps each (one being read, one being staged).
-template <int MT, int NT, int UU, int DIRECT, int PF_WAVES, int BPS = 1>
+template <int MT, int NT, int UU, int DIRECT, int PF_WAVES, int BPS = 1, bool BPRE = false>
 __global__ void __launch_bounds__(64 * PF_WAVES, PF_WAVES <= 4 ? 2 : 1)
 gemm_pf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, float* __restrict__ ws,
                int M, int N, int K, int kt_per_split, int mt_valid, const bf16_t* __restrict__ bias,
@@ -77,6 +78,20 @@ gemm_pf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, f
       if (xmt[f] < MT) xs[slot][xmt[f]][lane] = d[f];
   };
   auto compute = [&](const u32x4_t (&w)[NT], int slot) {
+    if constexpr (BPRE) {
+      // all MT B operands of the k-step are read from LDS first, then the MFMAs run back to back (the plain form below compiles
+      // to ds_read x2 -> s_waitcnt lgkmcnt -> 2-4 MFMAs, eight times per k-step: with one or two waves per SIMD the LDS latency is
+      // exposed every time -- see DESIGN.md section 8)
+      u32x4_t b[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) b[mt] = xs[slot][mt][lane];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = mfma16(w[nt], b[mt], acc[nt][mt]);
+      return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const u32x4_t b = xs[slot][mt][lane];
@@ -228,7 +243,7 @@ gemm_pf_epilogue_kernel(const float* __restrict__ ws, const bf16_t* __restrict__
 
 template <int MT, int NT, int DIRECT>
 static int pf_launch_d(const void* x, const void* w, float* ws, int M, int N, int K, int splits, const void* bias, void* y,
-                       int ldy, int waves, int uu, int bps, hipStream_t st) {
+                       int ldy, int waves, int uu, int bps, int bpre, hipStream_t st) {
   const int KT = K >> 5;
   dim3 grid(N / (16 * NT * waves), splits);
   const int nk = KT / splits;
@@ -236,12 +251,13 @@ static int pf_launch_d(const void* x, const void* w, float* ws, int M, int N, in
   if (uu <= 0) uu = (NT <= 2 && nk % 8 == 0) ? 8 : PF_U;
   if (nk % uu != 0 || bps < 1) return SSD_ERR_ARG;
   bool launched = false;
-#define PF_GO(UU, WV, B)                                                                                                 \
-  if (!launched && uu == UU && waves == WV && bps == B) {                                                                \
+#define PF_GO_B(UU, WV, B, PRE)                                                                                          \
+  if (!launched && uu == UU && waves == WV && bps == B && bpre == PRE) {                                                 \
     launched = true;                                                                                                     \
-    hipLaunchKernelGGL((gemm_pf_kernel<MT, NT, UU, DIRECT, WV, B>), grid, dim3(64 * WV), 0, st, (const u32x4_t*)w,       \
+    hipLaunchKernelGGL((gemm_pf_kernel<MT, NT, UU, DIRECT, WV, B, PRE != 0>), grid, dim3(64 * WV), 0, st, (const u32x4_t*)w, \
                        (const u32x4_t*)x, ws, M, N, K, nk, (M + 15) / 16, (const bf16_t*)bias, y, ldy);                  \
   }
+#define PF_GO(UU, WV, B) PF_GO_B(UU, WV, B, 0)
   PF_GO(4, 4, 1)
   if constexpr (NT == 1 && MT == 8 && DIRECT != 2) {     // 64-row (4 waves) / 128-row (8 waves) tiles: twice the workgroups per split
     PF_GO(8, 4, 1) PF_GO(8, 4, 2) PF_GO(8, 8, 1) PF_GO(8, 8, 2)
@@ -250,20 +266,22 @@ static int pf_launch_d(const void* x, const void* w, float* ws, int M, int N, in
     PF_GO(8, 4, 1) PF_GO(4, 8, 1) PF_GO(8, 8, 1)
     if constexpr (MT == 8) {     // the full prefill chunk (65..128 rows): two k-steps per barrier, 3..7-wave workgroups (so that
       PF_GO(8, 4, 2) PF_GO(8, 8, 2)                                        // row groups x splits can land on a multiple of 256 CUs)
+      PF_GO_B(8, 4, 2, 1) PF_GO_B(8, 8, 2, 1) PF_GO_B(8, 5, 2, 1)          // B operands of a k-step read from LDS up front (BPRE)
       PF_GO(8, 3, 1) PF_GO(8, 3, 2) PF_GO(8, 5, 1) PF_GO(8, 5, 2) PF_GO(8, 6, 2) PF_GO(8, 7, 1) PF_GO(8, 7, 2)
     }
   }
 #undef PF_GO
+#undef PF_GO_B
   if (!launched) return SSD_ERR_ARG;
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
 template <int MT, int NT>
 static int pf_launch(const void* x, const void* w, float* ws, int M, int N, int K, int splits, int direct, const void* bias,
-                     void* y, int ldy, int waves, int uu, int bps, hipStream_t st) {
-  if (direct == 1) return pf_launch_d<MT, NT, 1>(x, w, ws, M, N, K, splits, bias, y, ldy, waves, uu, bps, st);
-  if (direct == 2) return pf_launch_d<MT, NT, 2>(x, w, ws, M, N, K, splits, bias, y, ldy, waves, uu, bps, st);
-  return pf_launch_d<MT, NT, 0>(x, w, ws, M, N, K, splits, bias, y, ldy, waves, uu, bps, st);
+                     void* y, int ldy, int waves, int uu, int bps, int bpre, hipStream_t st) {
+  if (direct == 1) return pf_launch_d<MT, NT, 1>(x, w, ws, M, N, K, splits, bias, y, ldy, waves, uu, bps, bpre, st);
+  if (direct == 2) return pf_launch_d<MT, NT, 2>(x, w, ws, M, N, K, splits, bias, y, ldy, waves, uu, bps, bpre, st);
+  return pf_launch_d<MT, NT, 0>(x, w, ws, M, N, K, splits, bias, y, ldy, waves, uu, bps, bpre, st);
 }
 
 // Default decomposition, from profiles/r02_pf_probe.txt (MI355X, M = 128, us): the narrow tile (nt = 2) everywhere --
@@ -319,6 +337,7 @@ extern "C" int ssd_gemm_pf_cfg(const void* x_frag, const void* w_frag, const voi
   int waves = (nt >> 8) & 0xff;
   const int uu = (nt >> 16) & 0xff;
   int bps = (nt >> 24) & 0xf;
+  const int bpre = (nt >> 28) & 1;          // bit 28: B operands read up front (compiled for nt = 2, two-k-step phases, 4 / 5 / 8 waves, M > 64)
   nt &= 0xff;
   if (waves == 0) waves = PF_WAVES_DEFAULT;
   if (bps == 0) bps = 1;
@@ -336,7 +355,7 @@ extern "C" int ssd_gemm_pf_cfg(const void* x_frag, const void* w_frag, const voi
   float* ws = (float*)workspace;
   const int mt = (M + 15) / 16;
   int rc;
-#define PF_ARGS x_frag, w_frag, ws, M, N, K, splits, direct, bias, y, ldy, waves, uu, bps, st
+#define PF_ARGS x_frag, w_frag, ws, M, N, K, splits, direct, bias, y, ldy, waves, uu, bps, bpre, st
   if (mt <= 4) rc = nt == 4 ? pf_launch<4, 4>(PF_ARGS) : pf_launch<4, 2>(PF_ARGS);
   else rc = nt == 4 ? pf_launch<8, 4>(PF_ARGS) : nt == 2 ? pf_launch<8, 2>(PF_ARGS) : pf_launch<8, 1>(PF_ARGS);
 #undef PF_ARGS
@@ -361,6 +380,11 @@ extern "C" int ssd_gemm_pf(const void* x_frag, const void* w_frag, const void* b
   if (splits > 0) { s = splits; waves = 4; }
   if (s > 16 || (K >> 5) % s != 0) return SSD_ERR_ARG;
   pf_refine(M, N, K, s, &waves, &bps);
+  // SSD_PF_BPRE=1: the BPRE form of the kernel (B operands of a k-step read from LDS before its MFMAs).  Written at the very end
+  // of round 3 from the disassembly, bit-identical by construction, compiled -- but NOT yet run on a GPU,
+  // so it is off unless asked for
+  static const int want_bpre = [] { const char* e = getenv("SSD_PF_BPRE"); return e ? atoi(e) : 0; }();
+  const int bpre = (want_bpre && bps == 2 && nt == 2 && M > 64 && (waves == 4 || waves == 5 || waves == 8) && ((K >> 5) / s) % 8 == 0) ? 1 : 0;
   return ssd_gemm_pf_cfg(x_frag, w_frag, bias, y, M, N, K, ldy, epilogue, workspace, workspace_bytes,
-                         nt | (waves << 8) | (bps << 24), s, stream);
+                         nt | (waves << 8) | (bps << 24) | (bpre << 28), s, stream);
 }
