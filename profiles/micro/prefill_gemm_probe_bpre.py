@@ -1,5 +1,5 @@
-"""Prefill-chunk GEMMs at M = 128, default launch shapes: the plain kernel against its BPRE form (all B operands of a k-step read
-from LDS before its MFMAs; bit 28 of ssd_gemm_pf_cfg's nt / SSD_PF_BPRE=1).  Every output is compared bit for bit with the plain
+"""Prefill-chunk GEMMs at M = 128, default launch shapes: the plain kernel against its BPRE form (bpre1: all B operands of a k-step read
+from LDS before its MFMAs; bpre2: of both k-steps of a phase; bits 28-29 of ssd_gemm_pf_cfg's nt / SSD_PF_BPRE=1|2).  Every output is compared bit for bit with the plain
 form's.  hipGraph replays rotating over 4 weight copies (nothing L2 / MALL resident)."""
 import os
 import sys
@@ -45,7 +45,7 @@ def main():
             y = torch.zeros(M * N, device="cuda", dtype=BF)
             wsb = torch.zeros(sp * M * N + 64, dtype=torch.float32, device="cuda")
             ref, row = None, []
-            for bpre, tag in ((0, "plain"), (1, "bpre"), (0, "plain again")):
+            for bpre, tag in ((0, "plain"), (1, "bpre1"), (2, "bpre2"), (0, "plain again")):
                 nt = 2 | waves << 8 | 8 << 16 | 2 << 24 | bpre << 28
                 y.zero_(); wsb.zero_()
                 H.gemm_pf(xf, ws_[0], y, M, N, K, N, wsb, epilogue=epi, splits=sp, nt=nt)

@@ -29,7 +29,7 @@ constexpr int PF_U = 4;      // k-steps of W in flight per wave; every K split i
 // direct: 0 = write fp32 partials for the epilogue kernel; 1 / 2 = the K range is not split, finish in place
 // (1: rows bf16 + bias, 2: SiLU(gate) * up -> fragment-major) and skip the workspace round trip.
 // BPS = k-steps per workgroup barrier: the x ring holds two PHASES of BPS k-steps each (one being read, one being staged).
-template <int MT, int NT, int UU, int DIRECT, int PF_WAVES, int BPS = 1, bool BPRE = false>
+template <int MT, int NT, int UU, int DIRECT, int PF_WAVES, int BPS = 1, int BPRE = 0>
 __global__ void __launch_bounds__(64 * PF_WAVES, PF_WAVES <= 4 ? 2 : 1)
 gemm_pf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, float* __restrict__ ws,
                int M, int N, int K, int kt_per_split, int mt_valid, const bf16_t* __restrict__ bias,
@@ -78,7 +78,7 @@ gemm_pf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, f
       if (xmt[f] < MT) xs[slot][xmt[f]][lane] = d[f];
   };
   auto compute = [&](const u32x4_t (&w)[NT], int slot) {
-    if constexpr (BPRE) {
+    if constexpr (BPRE != 0) {
       // all MT B operands of the k-step are read from LDS first, then the MFMAs run back to back (the plain form below compiles
       // to ds_read x2 -> s_waitcnt lgkmcnt -> 2-4 MFMAs, eight times per k-step: with one or two waves per SIMD the LDS latency is
       // exposed every time -- see DESIGN.md section 8)
@@ -127,10 +127,31 @@ gemm_pf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, f
       for (int b = 0; b < BPS; ++b) stage_x(xr[par ^ 1][b], (par ^ 1) * BPS + b);
 #pragma unroll
       for (int b = 0; b < BPS; ++b) load_x(xr[par ^ 1][b], min(k + 3 * BPS + b, klast));
+      if constexpr (BPRE == 2 && BPS == 2) {
+        // both k-steps' B operands are requested before the first MFMA: the second k-step's LDS latency hides behind the first's
+        // 16 MFMAs (one exposed LDS latency per phase instead of one per k-step; + 32 VGPRs)
+        u32x4_t b0[MT], b1[MT];
 #pragma unroll
-      for (int b = 0; b < BPS; ++b) {
-        compute(a[u + b], par * BPS + b);
-        load_w(a[u + b], min(k + b + U, klast));
+        for (int mt = 0; mt < MT; ++mt) b0[mt] = xs[par * BPS][mt][lane];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) b1[mt] = xs[par * BPS + 1][mt][lane];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = mfma16(a[u][nt], b0[mt], acc[nt][mt]);
+        load_w(a[u], min(k + U, klast));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = mfma16(a[u + 1][nt], b1[mt], acc[nt][mt]);
+        load_w(a[u + 1], min(k + 1 + U, klast));
+      } else {
+#pragma unroll
+        for (int b = 0; b < BPS; ++b) {
+          compute(a[u + b], par * BPS + b);
+          load_w(a[u + b], min(k + b + U, klast));
+        }
       }
       __syncthreads();
     }
@@ -254,7 +275,7 @@ static int pf_launch_d(const void* x, const void* w, float* ws, int M, int N, in
 #define PF_GO_B(UU, WV, B, PRE)                                                                                          \
   if (!launched && uu == UU && waves == WV && bps == B && bpre == PRE) {                                                 \
     launched = true;                                                                                                     \
-    hipLaunchKernelGGL((gemm_pf_kernel<MT, NT, UU, DIRECT, WV, B, PRE != 0>), grid, dim3(64 * WV), 0, st, (const u32x4_t*)w, \
+    hipLaunchKernelGGL((gemm_pf_kernel<MT, NT, UU, DIRECT, WV, B, PRE>), grid, dim3(64 * WV), 0, st, (const u32x4_t*)w, \
                        (const u32x4_t*)x, ws, M, N, K, nk, (M + 15) / 16, (const bf16_t*)bias, y, ldy);                  \
   }
 #define PF_GO(UU, WV, B) PF_GO_B(UU, WV, B, 0)
@@ -267,6 +288,7 @@ static int pf_launch_d(const void* x, const void* w, float* ws, int M, int N, in
     if constexpr (MT == 8) {     // the full prefill chunk (65..128 rows): two k-steps per barrier, 3..7-wave workgroups (so that
       PF_GO(8, 4, 2) PF_GO(8, 8, 2)                                        // row groups x splits can land on a multiple of 256 CUs)
       PF_GO_B(8, 4, 2, 1) PF_GO_B(8, 8, 2, 1) PF_GO_B(8, 5, 2, 1)          // B operands of a k-step read from LDS up front (BPRE)
+      PF_GO_B(8, 4, 2, 2) PF_GO_B(8, 8, 2, 2) PF_GO_B(8, 5, 2, 2)          // ... of both k-steps of a phase (BPRE = 2)
       PF_GO(8, 3, 1) PF_GO(8, 3, 2) PF_GO(8, 5, 1) PF_GO(8, 5, 2) PF_GO(8, 6, 2) PF_GO(8, 7, 1) PF_GO(8, 7, 2)
     }
   }
@@ -337,7 +359,7 @@ extern "C" int ssd_gemm_pf_cfg(const void* x_frag, const void* w_frag, const voi
   int waves = (nt >> 8) & 0xff;
   const int uu = (nt >> 16) & 0xff;
   int bps = (nt >> 24) & 0xf;
-  const int bpre = (nt >> 28) & 1;          // bit 28: B operands read up front (compiled for nt = 2, two-k-step phases, 4 / 5 / 8 waves, M > 64)
+  const int bpre = (nt >> 28) & 3;          // bits 28-29: B operands read up front (1: per k-step, 2: per two-k-step phase) (compiled for nt = 2, two-k-step phases, 4 / 5 / 8 waves, M > 64)
   nt &= 0xff;
   if (waves == 0) waves = PF_WAVES_DEFAULT;
   if (bps == 0) bps = 1;
@@ -384,7 +406,7 @@ extern "C" int ssd_gemm_pf(const void* x_frag, const void* w_frag, const void* b
   // of round 3 from the disassembly, bit-identical by construction, compiled -- but NOT yet run on a GPU,
   // so it is off unless asked for
   static const int want_bpre = [] { const char* e = getenv("SSD_PF_BPRE"); return e ? atoi(e) : 0; }();
-  const int bpre = (want_bpre && bps == 2 && nt == 2 && M > 64 && (waves == 4 || waves == 5 || waves == 8) && ((K >> 5) / s) % 8 == 0) ? 1 : 0;
+  const int bpre = ((want_bpre == 1 || want_bpre == 2) && bps == 2 && nt == 2 && M > 64 && (waves == 4 || waves == 5 || waves == 8) && ((K >> 5) / s) % 8 == 0) ? want_bpre : 0;
   return ssd_gemm_pf_cfg(x_frag, w_frag, bias, y, M, N, K, ldy, epilogue, workspace, workspace_bytes,
                          nt | (waves << 8) | (bps << 24) | (bpre << 28), s, stream);
 }
