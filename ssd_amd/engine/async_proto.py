@@ -134,6 +134,18 @@ class DistTransport:
         return t.to(self.device)
 
 
+def to_device(values, dtype, device) -> torch.Tensor:
+    """Small host list -> device tensor WITHOUT blocking the host on the device stream.  `torch.tensor(list, device="cuda")`
+    is a pageable H2D copy: the host waits until everything queued on the current stream -- e.g. a whole glue + tree round
+    -- has finished.  A pinned source (torch's caching host allocator keeps the block alive until the copy's stream has
+    passed it) + non_blocking copy returns at once."""
+    t = torch.tensor(values, dtype=dtype)
+    device = torch.device(device)
+    if device.type != "cuda":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 class LoopbackTransport:
     """Both endpoints in one process: messages are queued; a receive on the target side first lets the draft
     server consume everything pending (``pump``).  Used to exercise the draft server on a single GPU."""

@@ -226,7 +226,7 @@ class DraftServer:
                 rows = idx_dev.clamp_min(0).to(torch.int64)         # stays on the device
                 tokens = self.cache_tokens[rows]
                 if not all(hits):       # "fast" backup: miss rows carry filler tokens (the reference uses random ones)
-                    tokens = tokens * torch.tensor(hits, dtype=torch.int64, device=tokens.device).unsqueeze(1)
+                    tokens = tokens * P.to_device(hits, torch.int64, tokens.device).unsqueeze(1)
                 if want_logits and self.cache_logits is not None:
                     logits_q = self.cache_logits[rows]          # [B, K, V]: the q the hit branch was sampled from
                 if eagle is not None:
@@ -256,7 +256,7 @@ class DraftServer:
         else:
             tokens = self.runner.zeros_tokens(B, K)
         if lead:
-            resp = torch.cat([torch.tensor(hits, dtype=torch.int64, device=tokens.device), tokens.reshape(-1)])
+            resp = torch.cat([P.to_device(hits, torch.int64, tokens.device), tokens.reshape(-1)])
             self.tx.send_tensor(resp)
             if want_logits:
                 # rows that are neither hits nor JIT-drafted never take the ratio path (verify.py:57-62): zeros will do
@@ -270,7 +270,7 @@ class DraftServer:
             t_a = self._trace.mark() if self._trace is not None else None
             fan = [self.config.fan_out_list if h else self.config.fan_out_list_miss for h in hits]
             jl = [self.j_hit if h else self.j_miss for h in hits]
-            glue_ids = torch.cat([torch.tensor(rec, dtype=torch.int64, device=tokens.device).unsqueeze(1), tokens], dim=1)
+            glue_ids = torch.cat([P.to_device(rec, torch.int64, tokens.device).unsqueeze(1), tokens], dim=1)
             if eagle is not None:
                 forks = self.runner.draft_glue_fork(glue_ids, num_tokens, tables, fan, eagle=eagle)
             else:

@@ -192,7 +192,10 @@ class LLMEngine:
         seqs, is_prefill = self.scheduler.schedule()
         capped = []
         for s in self.scheduler.pop_capped():          # stopped at max_model_len (Scheduler._length_capped)
-            capped.append((s.seq_id, s.completion_token_ids))
+            toks = s.completion_token_ids
+            if s.first_token_streamed is not None:      # streamed at the prefill, capped before the round that appends it:
+                toks = toks + [s.first_token_streamed]  # the result must carry what the stream already delivered
+            capped.append((s.seq_id, toks))
             self._capped_ids.add(s.seq_id)
         if not seqs:            # every runnable sequence was one of those
             return capped
@@ -212,6 +215,7 @@ class LLMEngine:
     def abort_all(self) -> None:
         """Drop every queued / running request and return its KV blocks (benchmarks that stop a request mid-generation)."""
         sch = self.scheduler
+        self._drain_loopback()      # queued draft commands (a deferred prefill) run while their blocks still have their owners
         for seq in list(sch.running):
             sch.block_manager.deallocate(seq)
             if sch.draft_block_manager is not None:
@@ -221,6 +225,15 @@ class LLMEngine:
         srv = getattr(self, "draft_server", None)
         if srv is not None:         # co-located draft: its parked round and its speculation cache belong to the aborted sequences
             srv.reset()             # (the parked glue / tree work would write draft KV into blocks that may already have new owners)
+
+    def _drain_loopback(self) -> None:
+        """Co-located draft server: serve every command still queued in the loop-back transport (a draft prefill deferred to
+        the first speculation request that never came: generate() cut short by max_steps, abort_all).  Left queued, it would run
+        at the NEXT request against draft blocks that may have new owners by then."""
+        link = getattr(self, "async_link", None)
+        pump = getattr(getattr(link, "tx", None), "pump", None) if link is not None else None
+        if pump is not None:
+            pump()
 
     def create_inference_step(self, config: Config) -> InferenceStep:
         if not config.speculate:
@@ -328,6 +341,7 @@ class LLMEngine:
                     pbar.update(1)
         if pbar:
             pbar.close()
+        self._drain_loopback()
         result = []
         for seq_id in sorted(outputs):
             toks = outputs[seq_id]

@@ -23,6 +23,7 @@ from ssd_amd.model import HipDecoder, AttnMeta
 from ssd_amd.model_config import ModelConfig
 from ssd_amd import weights as W
 from ssd_amd.utils.graphs import capture
+from ssd_amd.engine.async_proto import to_device
 
 
 class ModelRunner:
@@ -597,15 +598,15 @@ class ModelRunner:
 
     def cache_index(self, seq_ids, jlists):
         """Device copy of a round's cache keys besides the fork tokens: sequence id per row, glue position per branch."""
-        return (torch.tensor(list(seq_ids), dtype=torch.int64, device=self.device),
-                torch.tensor([list(j) for j in jlists], dtype=torch.int32, device=self.device).contiguous())
+        return (to_device(list(seq_ids), torch.int64, self.device),
+                to_device([list(j) for j in jlists], torch.int32, self.device).contiguous())
 
     @torch.inference_mode()
     def cache_lookup(self, keys, cache_seq: torch.Tensor, cache_j: torch.Tensor, forks: torch.Tensor) -> torch.Tensor:
         """int32 [B] device: index b * W + i of the cache entry (seq id, j, fork token) equal to each request key, or -1
         (csrc/misc.hip ssd_cache_lookup; reference draft_runner.py:215-252)."""
         B = len(keys)
-        req = torch.tensor([list(k) for k in keys], dtype=torch.int64, device=self.device)
+        req = to_device([list(k) for k in keys], torch.int64, self.device)
         out = torch.empty(B, dtype=torch.int32, device=self.device)
         H.cache_lookup(req, cache_seq, cache_j, forks.contiguous(), B, forks.shape[0], forks.shape[1], out)
         return out

@@ -35,6 +35,9 @@ class Sequence:
         self.draft_block_table: list[int] = []
         self.last_spec_step_accepted_len = -1
         self.recovery_token_id: int | None = None
+        # the prefill's token once LLMEngine.generate handed it to the stream ahead of the first speculation round; consumed
+        # (cleared) by the append that puts it into the sequence -- a LATER preemption must not resurrect it
+        self.first_token_streamed: int | None = None
         self.temperature = sp.temperature
         self.draft_temperature = sp.draft_temperature
         self.max_new_tokens = sp.max_new_tokens
@@ -96,6 +99,7 @@ class Sequence:
         self.token_ids.append(token_id)
         self.last_token = token_id
         self.num_tokens += 1
+        self.first_token_streamed = None
 
     # -- speculation bookkeeping: the (K+1)-token lookahead is applied and rolled back around one
     #    speculate+verify round exactly as SpecDecodeStep.decode does (ssd/engine/step.py:97-145) --

@@ -27,8 +27,11 @@ class Verifier(VerifierBase):
             acts = self.target_model_runner.eagle_acts(sum(len(s) for s in seqs)).clone()
         off = 0
         for seq, tok in zip(seqs, token_ids):
-            pinned = getattr(seq, "first_token_streamed", None)      # already handed to the stream (LLMEngine.generate)
-            seq.recovery_token_id = tok if (pinned is None or seq.num_completion_tokens > 0) else pinned
+            # already handed to the stream (LLMEngine.generate) and not yet appended: a re-prefill (preemption before the
+            # first round) must not flip it.  The pin is cleared by Sequence.append_token, so a sequence preempted AFTER its
+            # first round -- whose completion count restarts at 0 -- takes the freshly computed token
+            pinned = seq.first_token_streamed
+            seq.recovery_token_id = tok if pinned is None else pinned
             if eagle:
                 off += len(seq)
                 seq.last_target_hidden_state = acts[off - 1]

@@ -249,6 +249,59 @@ def test_eagle_preemption_reprefills_with_fresh_activations():
     assert shifted >= 1
 
 
+def test_streaming_does_not_change_a_preempted_sequence():
+    """the token streamed at the prefill is pinned only until the round that appends it.  A sequence
+    preempted LATER restarts its completion count at 0; honouring the stale pin there put the first completion token in
+    place of the freshly computed one.  Same pool-too-small set-up as above, with and without a stream callback: the
+    results must be identical, and every streamed first token must be the result's first token."""
+    from oracle.runner import oracle_runner_factory
+    from ssd_amd.engine.llm_engine import LLMEngine
+    from ssd_amd.sampling_params import SamplingParams
+    t, d = eagle_cfgs()
+    tw, dw = peaky_weights(t, d)
+    prompts = [[(5 * i + 3 * j + 2) % 256 for j in range(20 + 6 * i)] for i in range(3)]
+    base = dict(kvcache_block_size=16, max_model_len=256, max_num_batched_tokens=256)
+    runs = []
+    for streaming in (False, True):
+        eng = LLMEngine("t", runner_factory=oracle_runner_factory(weights_target=tw, weights_draft=dw), inprocess_draft=True,
+                        **eagle_kwargs(t, d, bs=3, num_kvcache_blocks=9, num_draft_kvcache_blocks=40, **base))
+        preempted, first = [], {}
+        orig = eng.scheduler.preempt
+
+        def spy(seq, orig=orig, preempted=preempted):
+            preempted.append(seq.seq_id)
+            return orig(seq)
+        eng.scheduler.preempt = spy
+
+        def cb(seq_id, toks, first=first):
+            first.setdefault(seq_id, toks[0])
+        got, _ = eng.generate(prompts, SamplingParams(temperature=0, max_new_tokens=30, ignore_eos=True), use_tqdm=False,
+                              stream_callback=cb if streaming else None)
+        assert preempted, "the pool was meant to be too small"
+        runs.append([o["token_ids"] for o in got])
+        if streaming:
+            assert len(first) == 3
+    assert runs[0] == runs[1], "streaming changed the tokens of a preempted sequence"
+
+
+def test_streamed_token_of_a_length_capped_sequence_is_in_its_result():
+    """ADVICE r3 (low): prompt + lookahead > max_model_len -> the scheduler finishes the sequence before its first round;
+    the token the stream already delivered at the prefill must be in the returned token_ids."""
+    from oracle.runner import oracle_runner_factory
+    from ssd_amd.engine.llm_engine import LLMEngine
+    from ssd_amd.sampling_params import SamplingParams
+    t, d = eagle_cfgs()
+    tw, dw = peaky_weights(t, d)
+    base = dict(kvcache_block_size=16, max_model_len=64, max_num_batched_tokens=256)
+    eng = LLMEngine("t", runner_factory=oracle_runner_factory(weights_target=tw, weights_draft=dw), inprocess_draft=True,
+                    **eagle_kwargs(t, d, bs=1, num_kvcache_blocks=16, num_draft_kvcache_blocks=40, **base))
+    seen = []
+    got, _ = eng.generate([[(3 * j + 1) % 256 for j in range(62)]], SamplingParams(temperature=0, max_new_tokens=30, ignore_eos=True),
+                          use_tqdm=False, stream_callback=lambda sid, toks: seen.extend(toks))
+    assert got[0]["finish_reason"] == "max_model_len"
+    assert seen == got[0]["token_ids"] and len(seen) == 1
+
+
 def test_glue_layout_matches_the_reference_mask_construction():
     """ssd_amd.engine.eagle_runner.glue_layout against the reference's construction of the same packed batch, restated
     here with the reference's own tensor formulas (draft_runner.py:555-566 lengths and offsets, :568-576 the extend /
