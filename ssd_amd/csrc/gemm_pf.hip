@@ -78,20 +78,6 @@ gemm_pf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, f
       if (xmt[f] < MT) xs[slot][xmt[f]][lane] = d[f];
   };
   auto compute = [&](const u32x4_t (&w)[NT], int slot) {
-    if constexpr (BPRE != 0) {
-      // all MT B operands of the k-step are read from LDS first, then the MFMAs run back to back (the plain form below compiles
-      // to ds_read x2 -> s_waitcnt lgkmcnt -> 2-4 MFMAs, eight times per k-step: with one or two waves per SIMD the LDS latency is
-      // exposed every time -- see DESIGN.md section 8)
-      u32x4_t b[MT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) b[mt] = xs[slot][mt][lane];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = mfma16(w[nt], b[mt], acc[nt][mt]);
-      return;
-    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const u32x4_t b = xs[slot][mt][lane];
@@ -129,7 +115,10 @@ gemm_pf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, f
       for (int b = 0; b < BPS; ++b) load_x(xr[par ^ 1][b], min(k + 3 * BPS + b, klast));
       if constexpr (BPRE == 2 && BPS == 2) {
         // both k-steps' B operands are requested before the first MFMA: the second k-step's LDS latency hides behind the first's
-        // 16 MFMAs (one exposed LDS latency per phase instead of one per k-step; + 32 VGPRs)
+        // 16 MFMAs (one exposed LDS latency per phase instead of one per k-step; + 32 VGPRs).  The plain form compiles to
+        // ds_read x2 -> s_waitcnt lgkmcnt -> 2-4 MFMAs, eight times per k-step.  Same MFMA order per accumulator: bit-identical.
+        // Measured on MI355X (profiles/r04_pf_probe_bpre.txt): 1-6 % on every 70B / 8B matrix at M = 100 / 128 (gate_up 155 -> 151 us,
+        // qkv 47.5 -> 46.4, o 32.1 -> 30.6), TTFT 30.1 -> 29.1 ms; a one-k-step variant (BPRE = 1) was no better and is gone
         u32x4_t b0[MT], b1[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) b0[mt] = xs[par * BPS][mt][lane];
@@ -287,8 +276,7 @@ static int pf_launch_d(const void* x, const void* w, float* ws, int M, int N, in
     PF_GO(8, 4, 1) PF_GO(4, 8, 1) PF_GO(8, 8, 1)
     if constexpr (MT == 8) {     // the full prefill chunk (65..128 rows): two k-steps per barrier, 3..7-wave workgroups (so that
       PF_GO(8, 4, 2) PF_GO(8, 8, 2)                                        // row groups x splits can land on a multiple of 256 CUs)
-      PF_GO_B(8, 4, 2, 1) PF_GO_B(8, 8, 2, 1) PF_GO_B(8, 5, 2, 1)          // B operands of a k-step read from LDS up front (BPRE)
-      PF_GO_B(8, 4, 2, 2) PF_GO_B(8, 8, 2, 2) PF_GO_B(8, 5, 2, 2)          // ... of both k-steps of a phase (BPRE = 2)
+      PF_GO_B(8, 4, 2, 2) PF_GO_B(8, 8, 2, 2) PF_GO_B(8, 5, 2, 2)          // B operands of both k-steps of a phase read up front (BPRE = 2)
       PF_GO(8, 3, 1) PF_GO(8, 3, 2) PF_GO(8, 5, 1) PF_GO(8, 5, 2) PF_GO(8, 6, 2) PF_GO(8, 7, 1) PF_GO(8, 7, 2)
     }
   }
@@ -359,7 +347,7 @@ extern "C" int ssd_gemm_pf_cfg(const void* x_frag, const void* w_frag, const voi
   int waves = (nt >> 8) & 0xff;
   const int uu = (nt >> 16) & 0xff;
   int bps = (nt >> 24) & 0xf;
-  const int bpre = (nt >> 28) & 3;          // bits 28-29: B operands read up front (1: per k-step, 2: per two-k-step phase) (compiled for nt = 2, two-k-step phases, 4 / 5 / 8 waves, M > 64)
+  const int bpre = (nt >> 28) & 3;          // bits 28-29: 2 = B operands of a two-k-step phase read up front (compiled for nt = 2, two-k-step phases, 4 / 5 / 8 waves, M > 64)
   nt &= 0xff;
   if (waves == 0) waves = PF_WAVES_DEFAULT;
   if (bps == 0) bps = 1;
@@ -402,11 +390,10 @@ extern "C" int ssd_gemm_pf(const void* x_frag, const void* w_frag, const void* b
   if (splits > 0) { s = splits; waves = 4; }
   if (s > 16 || (K >> 5) % s != 0) return SSD_ERR_ARG;
   pf_refine(M, N, K, s, &waves, &bps);
-  // SSD_PF_BPRE=1: the BPRE form of the kernel (B operands of a k-step read from LDS before its MFMAs).  Written at the very end
-  // of round 3 from the disassembly, bit-identical by construction, compiled -- but NOT yet run on a GPU,
-  // so it is off unless asked for
-  static const int want_bpre = [] { const char* e = getenv("SSD_PF_BPRE"); return e ? atoi(e) : 0; }();
-  const int bpre = ((want_bpre == 1 || want_bpre == 2) && bps == 2 && nt == 2 && M > 64 && (waves == 4 || waves == 5 || waves == 8) && ((K >> 5) / s) % 8 == 0) ? want_bpre : 0;
+  // B operands of a two-k-step phase read from LDS up front (BPRE = 2) wherever that form exists; SSD_PF_BPRE=0 selects the plain
+  // loop (A/B measurements: profiles/r04_pf_probe_bpre.txt, every output bit-identical)
+  static const int want_bpre = [] { const char* e = getenv("SSD_PF_BPRE"); return e ? atoi(e) : 2; }();
+  const int bpre = (want_bpre == 2 && bps == 2 && nt == 2 && M > 64 && (waves == 4 || waves == 5 || waves == 8) && ((K >> 5) / s) % 8 == 0) ? 2 : 0;
   return ssd_gemm_pf_cfg(x_frag, w_frag, bias, y, M, N, K, ldy, epilogue, workspace, workspace_bytes,
                          nt | (waves << 8) | (bps << 24) | (bpre << 28), s, stream);
 }
