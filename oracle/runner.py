@@ -43,6 +43,17 @@ class OracleRunner:
         # (seq_id, absolute position of the decided token) -> top-2 logit margin of that greedy decision; tests use it
         # to tell a legitimate near-tie flip from a real divergence of the HIP engine
         self.margin_log: dict[tuple[int, int], float] = {}
+        # draft-side greedy decisions in the order they were taken: (kind, gaps) with kind in "chain" (synchronous K-step chain,
+        # [K, B]), "jit" ([K, B]), "glue" (fork rows, [B, K+1]: smallest gap between consecutive logits among the F + 1 largest
+        # that the fork may pick from) and "tree" ([K, B * MQ]); gaps in logit units.  tests/lockstep.py uses them to tell a
+        # draft near-tie that flipped on the GPU from a real divergence of the speculation
+        self.decision_gaps: list[tuple[str, torch.Tensor]] = []
+        self.log_decisions = False      # switched on by the lock-step tests only (the CPU baseline leg of bench.py times this runner)
+
+    @staticmethod
+    def _gap(lg, top: int = 2):
+        v = lg.float().topk(top, dim=-1).values
+        return (v[..., :-1] - v[..., 1:]).min(dim=-1).values
 
     def _log_margins(self, lg, keys):
         top = lg.float().topk(2, dim=-1).values
@@ -167,6 +178,8 @@ class OracleRunner:
             cur = self._pick(lg, seqs)
             spec[:, k + 1] = torch.tensor(cur)
         self._lq = torch.stack(lq, dim=1)
+        if self.log_decisions:
+            self.decision_gaps.append(("chain", torch.stack([self._gap(l) for l in lq])))
         if bool((self._temps(seqs) > 0).any()):
             # the reference's (K+1)-th draft forward (speculator_sync.py:47-56; deferred to deposit_pending here) goes through
             # run() and its Sampler too: one more exponential draw per logit, discarded.  The oracle consumes it at the same
@@ -268,6 +281,8 @@ class OracleRunner:
             out[:, i] = torch.tensor(cur)
         self._lq = torch.stack(lq, dim=1)
         self._jit_acts = torch.stack(pres, dim=1) if pres else None
+        if self.log_decisions:
+            self.decision_gaps.append(("jit", torch.stack([self._gap(l) for l in lq])))
         return out
 
     def jit_acts(self, B):
@@ -327,6 +342,10 @@ class OracleRunner:
                   context_lens=torch.tensor([n + K for n in num_tokens], dtype=torch.int32), block_tables=self._bt_from(tables),
                   cu_q=torch.arange(B + 1, dtype=torch.int32) * (K + 1))
         lg = self._logits(self.model.forward(glue_ids.reshape(-1), torch.tensor(pos), ctx)).view(B, K + 1, -1)
+        if self.log_decisions:
+            ex = lg.clone()         # the fork never picks the token that follows in the chain (async_spec_helpers.py:45-52)
+            ex[:, :-1, :] = ex[:, :-1, :].scatter(2, glue_ids[:, 1:].unsqueeze(2), float("-inf"))
+            self.decision_gaps.append(("glue", self._gap(ex, max(max(f) for f in fan_lists) + 1)))
         return O.fork_topf(lg, glue_ids, fan_lists)
 
     @torch.inference_mode()
@@ -361,6 +380,8 @@ class OracleRunner:
             toks = O.argmax_rows(lg) if t is None else O.sample(lg, t, self.config.sampler_x, self.config.async_fan_out)
             tl.append(lg)
             out[:, d] = toks
+        if self.log_decisions:
+            self.decision_gaps.append(("tree", torch.stack([self._gap(l) for l in tl])))
         self._tree_lq = torch.stack(tl, dim=1) if t is not None else None
         self._tree_acts = torch.stack(pres, dim=1) if pres else None
         return out
