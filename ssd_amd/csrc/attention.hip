@@ -57,6 +57,8 @@ constexpr int attn_region_bytes() { return RT * 16 * HD * 4 + RT * 16 * 8; }
 template <int HD, int RT, int KT, bool OPROJ = false>
 __global__ void __launch_bounds__(512) attn_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KTS = OPROJ ? 7 : 6;        // trace slot (profiling builds only)
+  KTRACE(KTS, 0);
   constexpr int DS = HD / 32;  // k-steps of QK^T
   constexpr int DT = HD / 16;  // 16-wide output d tiles
   constexpr int REGION = attn_region_bytes<HD, RT>();
@@ -192,6 +194,7 @@ __global__ void __launch_bounds__(512) attn_kernel(const AttnParams p) {
       if constexpr (PIPE_K) issue_k(k0 + j * stride, ca[j], cb[j], kreg[j]);
       issue_v(k0 + j * stride, ca[j], cb[j], vreg[j]);
     }
+  KTRACE(KTS, 1);
 
   for (; k0 < kmax; k0 += KT * stride) {
 #pragma unroll
@@ -309,6 +312,7 @@ __global__ void __launch_bounds__(512) attn_kernel(const AttnParams p) {
   }
 
   // ---- epilogue ----
+  KTRACE(KTS, 2);
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     lsum[rt] += __shfl_xor(lsum[rt], 16, 64);
@@ -357,6 +361,7 @@ __global__ void __launch_bounds__(512) attn_kernel(const AttnParams p) {
     }
   }
   __syncthreads();
+  KTRACE(KTS, 3);
   for (int item = threadIdx.x; item < RT * 16 * (HD / 4); item += blockDim.x) {
     const int lr = item / (HD / 4), d = (item % (HD / 4)) * 4;
     const int rho = tile_base * 16 + lr;
@@ -397,6 +402,7 @@ __global__ void __launch_bounds__(512) attn_kernel(const AttnParams p) {
       }
     }
   }
+  KTRACE(KTS, 4);
   if constexpr (OPROJ) {
     __syncthreads();
     // slab h of o_proj: this wave's row group x the K slice of kv head h, all k-tiles already in registers
@@ -415,6 +421,7 @@ __global__ void __launch_bounds__(512) attn_kernel(const AttnParams p) {
       const int n = ((blockIdx.x / p.nkv) * 8 + wave) * 16 + g4 * 4;
       *reinterpret_cast<f32x4_t*>(p.oparts + ((size_t)h * Tq + r16) * p.oN + n) = acc;
     }
+    KTRACE(KTS, 5);
   }
 }
 
@@ -552,3 +559,5 @@ extern "C" int ssd_attn_paged(const void* q_rows, const void* k_cache, const voi
   const int rt1 = (flags >> 2) & 1;
   return hd == 128 ? attn_launch<128>(p, B, T, max_q, waves, rt1, st) : attn_launch<64>(p, B, T, max_q, waves, rt1, st);
 }
+
+KT_DEFINE_SETTER(attention)

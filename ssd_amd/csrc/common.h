@@ -121,3 +121,31 @@ static inline void ssd_pick_skinny_cfg(int groups, int KT, bool silu_pairs, int*
   while (w > 1 && KT / w < 2) w >>= 1;    // every wave needs a couple of k-tiles
   *nt = n; *waves = w; *tpw = t;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// In-kernel timeline (profiling builds only: `make trace` -> _lib/libssdhip_trace.so with -DSSD_KTRACE; the product library
+// contains none of it).  KTRACE(slot, i): thread 0 of every workgroup stores the chip-wide 100 MHz clock (s_memrealtime) into
+// buf[slot][workgroup][i]; a later launch of the same slot overwrites an earlier one (all layers are alike: the last layer's
+// launch is what a probe reads).  profiles/ktrace_probe.py turns the marks into a per-kernel ramp profile: dispatch skew,
+// time to the first weight tile, time after the last, boundary to the next kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+#ifdef SSD_KTRACE
+#define KT_MARKS 8
+#define KT_MAXWG 4096
+#define KT_SLOTS 32
+static __device__ unsigned long long* kt_dev_buf;       // one copy per translation unit (no -fgpu-rdc): ssd_ktrace_set_<tu>
+__device__ __forceinline__ void kt_mark(int slot, int i) {
+  if (threadIdx.x == 0 && kt_dev_buf) {
+    const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (wg < KT_MAXWG) kt_dev_buf[((size_t)slot * KT_MAXWG + wg) * KT_MARKS + i] = wall_clock64();
+  }
+}
+#define KTRACE(slot, i) kt_mark((slot), (i))
+#define KT_DEFINE_SETTER(tu)                                                                                         \
+  extern "C" int ssd_ktrace_set_##tu(void* p) {                                                                      \
+    return hipMemcpyToSymbol(HIP_SYMBOL(kt_dev_buf), &p, sizeof(p)) == hipSuccess ? 0 : -1;                          \
+  }
+#else
+#define KTRACE(slot, i) ((void)0)
+#define KT_DEFINE_SETTER(tu)
+#endif

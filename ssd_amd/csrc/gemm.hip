@@ -40,6 +40,8 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
                const bf16_t* __restrict__ bias, void* __restrict__ Yv, int M, int N, int K, int ldy, int tpw,
                float* __restrict__ part_val, int* __restrict__ part_idx, int part_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KTS = EPI == EPI_SILU_FRAG ? 8 : 9;        // trace slot (profiling builds only)
+  KTRACE(KTS, 0);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nw = blockDim.x >> 6;
@@ -139,7 +141,9 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) red[((wave * ITEMS) + nt * MT + mt) * 64 + lane] = acc[nt][mt];
+  KTRACE(KTS, 4);      // (of the workgroup's LAST tile)
   __syncthreads();
+  KTRACE(KTS, 5);
 
   const int mcol = lane & 15;   // D column j  -> token row m
   const int nrow = (lane >> 4) * 4;  // D rows i = nrow + r -> output feature n
@@ -230,6 +234,7 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
       part_idx[(size_t)t * part_stride + blockIdx.x] = b.i;
     }
   }
+  KTRACE(KTS, 6);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -375,3 +380,5 @@ extern "C" int ssd_gemm_wf_argmax(const void* x_frag, const void* w_frag, const 
   if (nt == 1) return launch_t<2, 1, EPI_ROWS_ARGMAX>(x_frag, w_frag, bias, y, M, N, K, ldy, waves, tpw, st, part_val, part_idx, part_stride);
   return launch_t<2, 2, EPI_ROWS_ARGMAX>(x_frag, w_frag, bias, y, M, N, K, ldy, waves, tpw, st, part_val, part_idx, part_stride);
 }
+
+KT_DEFINE_SETTER(gemm)

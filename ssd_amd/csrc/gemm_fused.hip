@@ -80,6 +80,8 @@ __device__ __forceinline__ void fused_load_x32(const FusedParams& p, int mm, int
 template <int NT, int EPI, bool XNORM, int FUSED_MAXC>
 __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KTS = !XNORM ? 2 : (EPI == FEPI_QKV_ROPE ? 0 : 1);      // trace slot (profiling builds only)
+  KTRACE(KTS, 0);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nw = blockDim.x >> 6;
@@ -140,6 +142,7 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
     }
     pre_ok = true;
   }
+  KTRACE(KTS, 1);
   if (XNORM) {
     // ---- prologue: x32 = h + res kept in registers; per-chunk sums of squares -> per-row rs (fixed order) ->
     //      x^ = bf16(x32 * rs * w) into the LDS image; residual slice written to res_out ----
@@ -186,6 +189,7 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
       }
     }
     __syncthreads();
+    KTRACE(KTS, 2);
     // every wave reduces the chunk sums of all M rows itself (same order as ssd_rmsnorm: lane-strided partials, then the
     // xor tree) and keeps rs in its own LDS row: no second workgroup barrier
     float* rsbuf = ssbuf + total + wave * 16;           // behind the chunk sums
@@ -226,6 +230,7 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
       }
     }
     __syncthreads();
+    KTRACE(KTS, 3);
   }
 
   auto xfrag = [&](int buf, int u, int kt) -> u32x4_t {
@@ -267,7 +272,9 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
   f32x4_t* cred = reinterpret_cast<f32x4_t*>(smem);   // [nw][NT][64]
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) cred[(wave * NT + nt) * 64 + lane] = acc[nt];
+  KTRACE(KTS, 4);
   __syncthreads();
+  KTRACE(KTS, 5);
   const int nrow = q4 * 4;
   const int m = mcol;
 
@@ -363,6 +370,7 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
       }
     }
   }
+  KTRACE(KTS, 6);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -617,3 +625,5 @@ extern "C" int ssd_gemm_fused_parts(const void* h_parts, int splits, const void*
   return fused_impl(nullptr, nullptr, (const float*)h_parts, splits, res_in, res_out, norm_w, eps, w_frag, bias, M, N, K, epilogue,
                     y, ldy, positions, cos_sin, slots, q_out, k_cache, v_cache, nh, nkv, hd, block_size, nt, waves, stream);
 }
+
+KT_DEFINE_SETTER(gemm_fused)

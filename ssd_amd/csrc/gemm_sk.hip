@@ -122,6 +122,8 @@ __global__ void __launch_bounds__(1024)
 gemm_sp_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, const bf16_t* __restrict__ bias,
                bf16_t* __restrict__ Y, float* __restrict__ P, int M, int N, int K, int ldy) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int KTS = K > N ? 5 : 4;        // trace slot (profiling builds only): down_proj / o_proj
+  KTRACE(KTS, 0);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nw = blockDim.x >> 6;
@@ -145,6 +147,7 @@ gemm_sp_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, c
       if (mt * 16 + (lane & 15) < M) b[i][mt] = xp[mt * xstride + ((size_t)kt << 6)];    // padding token rows are not loaded
     }
   }
+  KTRACE(KTS, 1);
   f32x4_t acc[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -157,7 +160,9 @@ gemm_sp_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, c
   f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);        // [nw][MT][64]
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) red[(wave * MT + mt) * 64 + lane] = acc[mt];
+  KTRACE(KTS, 2);
   __syncthreads();
+  KTRACE(KTS, 3);
   if (wave >= MT) return;                                  // wave mt finishes m-tile mt
   const int mt = wave;
   f32x4_t s = {0.f, 0.f, 0.f, 0.f};
@@ -174,6 +179,7 @@ gemm_sp_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, c
     const u32x2_t v = {pack_bf2(s[0], s[1]), pack_bf2(s[2], s[3])};
     *reinterpret_cast<u32x2_t*>(Y + (size_t)m * ldy + n) = v;
   }
+  KTRACE(KTS, 4);
 }
 
 // parts: fp32 [splits][M][N] slabs (y must be null) or null (splits must be 1; bf16 rows into y, + bias).
@@ -206,3 +212,5 @@ extern "C" int ssd_gemm_parts(const void* x_frag, const void* w_frag, const void
 #undef SP_LAUNCH
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
+
+KT_DEFINE_SETTER(gemm_sk)

@@ -38,6 +38,8 @@ rmsnorm_kernel(const u32x4_t* __restrict__ x, const u32x4_t* __restrict__ res_in
                u32x4_t* __restrict__ out_frag, const int32_t* __restrict__ gather, int H,
                const float* __restrict__ parts, int S, int slab_rows) {
   __shared__ float red[NORM_THREADS / 64];
+  const int KTS = parts ? 10 : 11;        // trace slot (profiling builds only)
+  KTRACE(KTS, 0);
   const int row_out = blockIdx.x;
   const int row_in = gather ? gather[row_out] : row_out;
   const int H8 = H >> 3;
@@ -98,6 +100,7 @@ rmsnorm_kernel(const u32x4_t* __restrict__ x, const u32x4_t* __restrict__ res_in
       if (out_frag) out_frag[frag_chunk(row_out, c, KT)] = o;
     }
   }
+  KTRACE(KTS, 6);
 }
 
 extern "C" int ssd_rmsnorm(const void* x_rows, const void* res_in, void* res_out, const void* weight, float eps,
@@ -197,3 +200,5 @@ extern "C" int ssd_rmsnorm_parts(const void* parts, int splits, int slab_rows, c
                        (u32x4_t*)out_frag, (const int32_t*)nullptr, H, (const float*)parts, splits, slab_rows);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
+
+KT_DEFINE_SETTER(norm)

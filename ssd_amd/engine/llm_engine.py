@@ -352,7 +352,10 @@ class LLMEngine:
                            "finish_reason": "max_model_len" if seq_id in self._capped_ids else "stop"})
         if not stream_callback and self.config.verbose:
             self.log_metrics()
-        return result, METRICS
+        # a snapshot, not the module-level dict itself (the reference returns the global: two engines run one after the other in
+        # one process then "return" the same object, and comparing their metrics compares the second run with itself -- a round-3
+        # test did exactly that)
+        return result, {k: (list(v) if isinstance(v, list) else v) for k, v in METRICS.items()}
 
     def exit(self, hard: bool = False) -> None:
         if self._followers:
