@@ -89,15 +89,58 @@ def parse(argv=None):
     return ap.parse_args(argv)
 
 
+def base_record(args) -> dict:
+    """The keys every line of this benchmark carries -- also a FAILURE record (value null + error / stage), so that whoever parses
+    "the one JSON line" learns which stage of which rank ended the run (ssd_amd/utils/watchdog.py)."""
+    return {"metric": "output tokens/sec + p50 TTFT, Llama-3-70B SSD k=7 f=3; mean accepted len" if args.workload == "c4"
+            else "output tokens/sec (speculative decoding, b=1, temp 0), with p50 TTFT and mean accepted length",
+            "value": None, "unit": "tokens/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": args.workload}}
+
+
 def self_launch(args) -> int:
-    """``python bench.py --gpus N`` outside a distributed launch: become the launcher (one rank per GPU)."""
+    """``python bench.py --gpus N`` outside a distributed launch: become the launcher (one rank per GPU).  The launcher is also the
+    last line of defence: it relays the ranks' stdout, and if the launch ends -- or outlives SSD_TOTAL_DEADLINE_S and is killed,
+    whole process group -- without a JSON line, it prints the failure record itself."""
+    import signal
+    import threading
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    return subprocess.call(cmd, env=env)
+    deadline = float(os.environ.get("SSD_TOTAL_DEADLINE_S", "3000")) + 60.0
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    seen = []
+
+    def relay():
+        for line in p.stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            t = line.strip()
+            if t.startswith("{") and '"metric"' in t:
+                seen.append(t)
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    why = None
+    try:
+        rc = p.wait(timeout=deadline)
+    except subprocess.TimeoutExpired:
+        why = f"launch exceeded {deadline:.0f} s: process group killed by the launcher"
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except Exception:
+            p.kill()
+        rc = p.wait()
+    th.join(timeout=5)
+    if not seen:
+        rec = base_record(args)
+        rec.update({"error": why or f"the launch ended with exit code {rc} without printing a result line", "failure": "launcher",
+                    "stage": "unknown (no rank left a record)", "rank": None})
+        print(json.dumps(rec), flush=True)
+    return rc if rc != 0 else (0 if seen and '"error"' not in seen[-1] else 1)
 
 
 def workload_models(name):
@@ -325,10 +368,19 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
-    import torch
-    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    # Whatever fails from here on -- an exception on any rank, a rank that dies and leaves the others waiting in a collective,
+    # a hang in code that runs for the first time on a multi-GPU box -- the run ends within a bounded time and rank 0 prints a
+    # one-line JSON failure record naming the stage (ssd_amd/utils/watchdog.py).  At N = 1 only the exception path matters.
+    from ssd_amd.utils.watchdog import RunGuard
+    guard = RunGuard(rank, world, base_record(args)).install()
+    guard.run(lambda: run(args, guard, rank, world))
+
+
+def run(args, guard, rank, world):
+    import torch
+    import torch.distributed as dist
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     from ssd_amd.engine.llm_engine import LLMEngine, METRICS
     from ssd_amd.sampling_params import SamplingParams
@@ -385,9 +437,12 @@ def main():
         kw.update(draft_async=True, async_fan_out=args.f, jit_speculate=True, inprocess_draft=not dedicated, num_draft_gpus=ndraft)
     if eagle:
         kw.update(use_eagle=True)
+    guard.stage("engine_init")
     engine = LLMEngine(tname, **kw)
     if engine.is_draft_process:             # dedicated draft GPU: serve until the target says EXIT, then join the barrier
+        guard.stage("draft_serve", guard.total_deadline)        # (waits for requests as long as the target runs)
         engine.serve()
+        guard.stage("final_barrier", 120.0)
         dist.barrier()
         dist.destroy_process_group()
         return
@@ -403,6 +458,7 @@ def main():
             torch.cuda.synchronize(dev)
 
     # ---- TTFT (chat.py:95-111 definition: generate() call -> first streamed token), p50 over a few runs ----
+    guard.stage("ttft (first prefill + first speculation round: graph captures, first collectives in graphs)")
     ttfts, ttfts_round = [], []
     for _ in range(max(1, args.ttft_samples)):
         first = []
@@ -422,6 +478,7 @@ def main():
 
     # ---- timed decode steps through the real engine ----
     total = args.warmup + args.steps
+    guard.stage("warmup_steps")
     engine.add_request(prompt, SamplingParams(temperature=0, ignore_eos=True, max_new_tokens=total * (K + 1) + 8))
     for k_ in list(METRICS):
         METRICS[k_] = [] if isinstance(METRICS[k_], list) else 0
@@ -439,6 +496,7 @@ def main():
     n0 = len(METRICS["accepted_suffix_lens_with_recovery"])
     h0 = len(METRICS["cache_hits"])
     sync_all()
+    guard.stage("timed_steps")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         engine.step(step)
@@ -458,6 +516,7 @@ def main():
     #      (llm_engine.py:215-223).  Context grows 128 -> 640 here, where the timed steps above sit at ~130-300. ----
     ref = None
     if args.ref_seqs > 0:
+        guard.stage("reference_protocol_run")
         engine.abort_all()                       # the timed request is not run to its end
         random.seed(1)
         rp = [[random.randint(0, 10000) for _ in range(args.input_len)] for _ in range(args.ref_seqs)]
@@ -539,12 +598,14 @@ def main():
         "reference_protocol": ref,
     }
     if not args.no_roofline:          # every rank launches the same sequence (shard shapes); rank 0 reports
+        guard.stage("roofline_probe")
         with torch.inference_mode():      # the engine's buffers are inference tensors (ModelRunner runs under inference_mode)
             roof = gemm_roofline(legs)
             if tp > 1:
                 out["collective"] = collective_probe(engine, K + 1)
         out["roofline"] = roof
     if rank == 0:
+        guard.stage("cpu_baseline")
         if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()
@@ -552,10 +613,15 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)
+    guard.done()                            # the line is out: nothing after this may replace it with a failure record
     engine.exit()                           # dedicated placement: tells the draft rank to leave its serve loop
     if world > 1:
+        # bounded farewell: a rank that is gone must not keep the others in the barrier / in a communicator destructor
+        import threading
+        threading.Timer(90.0, lambda: os._exit(0 if rank == 0 else 5)).start()
         dist.barrier()
         dist.destroy_process_group()
+        os._exit(0)
 
 
 if __name__ == "__main__":

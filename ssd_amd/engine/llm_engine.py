@@ -169,7 +169,10 @@ class LLMEngine:
                     # has been streamed and before the first draft round needs the draft's KV.
                     transport.defer_prefill = True
             self.async_link = AsyncLink(config, self.topo, transport=transport)
+            from ssd_amd.utils import watchdog
+            watchdog.stage("draft_hello (first send / recv on the draft p2p group)", 600.0)     # the draft rank answers once its weights are up
             draft_blocks = self.async_link.draft_num_blocks()
+            watchdog.stage("engine_init")
 
         self.tokenizer = _load_tokenizer(config.tokenizer_path or config.model)
         if self.tokenizer is not None and self.tokenizer.eos_token_id is not None:

@@ -77,6 +77,8 @@ class ModelRunner:
             gd = gen_device or ("cuda" if model_cfg.hidden_size >= 1024 else "cpu")
             src = W.synthetic_weights(model_cfg, weights_seed, config.weights_std, tp_rank, tp_size, gen_device=gd,
                                       out_device=str(device), recipe=getattr(config, "weights_recipe", None))
+        from ssd_amd.utils import watchdog
+        watchdog.stage(f"weights ({'draft' if is_draft else 'target'})")
         self.model.load_weights(src)
 
         # ---- KV cache: free * utilisation // block_bytes (reference model_runner.py:446-492) ----
@@ -85,6 +87,7 @@ class ModelRunner:
             util = memory_utilization if memory_utilization is not None else config.gpu_memory_utilization
             num_kvcache_blocks = int(free * util) // self.model.kv_block_bytes()
             if tp_size > 1:   # all ranks must agree (SPMD schedulers)
+                watchdog.stage("kv_blocks_agree (first collective on the tp group)")
                 t = torch.tensor([num_kvcache_blocks], dtype=torch.int64, device=device)
                 dist.all_reduce(t, op=dist.ReduceOp.MIN, group=tp_group)
                 num_kvcache_blocks = int(t.item())
@@ -111,6 +114,7 @@ class ModelRunner:
         self.h_packed = torch.zeros(B, self.K + 3, dtype=torch.int64).pin_memory()
         self.h_next = torch.zeros(max(self.max_decode_tokens, B), dtype=torch.int64).pin_memory()
         self._setup_custom_ar(custom_ar)
+        watchdog.stage("engine_init")           # (whatever the set-up's outcome: its stage limits end here)
         self._stage: dict = {}
         self._stage_set = 0
         self._ctx_hint = 4096
@@ -138,9 +142,11 @@ class ModelRunner:
             return
         from ssd_amd.utils import custom_ar as CA
         world = dist.get_world_size(self.tp_group)
+        from ssd_amd.utils import watchdog
         try:
             if world > 1:
                 port = int(os.environ.get("MASTER_PORT", "29531")) + 17
+                watchdog.stage("one_shot_allreduce_validation (helper processes)", 260.0)
                 ok = CA.validate_in_subprocess(self.tp_rank, world, self.device.index or 0, port)
                 flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.tp_group)
@@ -148,7 +154,9 @@ class ModelRunner:
                     self.custom_ar_status = ("self-validation FAILED on " + ("this rank" if not ok else "another rank")
                                              + ": fell back to RCCL")
                     return
+            watchdog.stage("one_shot_allreduce_ipc_exchange (hipIpc handles)", 120.0)
             m.custom_ar = CA.OneShotAllReduce(self.tp_group, self.device)
+            watchdog.stage("engine_init")
             self.custom_ar_status = "validated on every rank" if world > 1 else "single rank (nothing to validate)"
         except Exception as e:
             m.custom_ar = None

@@ -47,7 +47,13 @@ def init_process_group_if_needed(backend: str | None = None) -> tuple[int, int]:
             backend = os.environ.get("SSD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
             torch.cuda.set_device(_local_device(rank))
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        # every collective of the control plane gives up after SSD_PG_TIMEOUT_S (default 10 min: the slowest rank generates /
+        # loads its weight shard before it reaches the first one) instead of the backend's 30 min -- a dead peer must surface
+        from datetime import timedelta
+        from ssd_amd.utils import watchdog
+        watchdog.stage("process_group_init", watchdog.env_float("SSD_PG_TIMEOUT_S", 600.0) + 30.0)
+        dist.init_process_group(backend, rank=rank, world_size=world,
+                                timeout=timedelta(seconds=watchdog.env_float("SSD_PG_TIMEOUT_S", 600.0)))
     return rank, world
 
 
@@ -70,6 +76,8 @@ def resolve_topology(config, colocated_draft: bool = False) -> Topology:
                                       f"`python -m torch.distributed.run --nproc-per-node {config.num_gpus} ...`")
         return Topology(0, 1, device, "target", 0, 1)
     assert world == config.num_gpus, f"WORLD_SIZE={world} but num_gpus={config.num_gpus}"
+    from ssd_amd.utils import watchdog
+    watchdog.stage("subgroup_creation (tp / async p2p / control / draft groups)")
     if config.speculate and config.draft_async and not colocated_draft:
         D = getattr(config, "num_draft_gpus", 1)
         tp = world - D
