@@ -188,7 +188,9 @@ def _lockstep_full_size(mode: str, n_new: int):
         return hip_runner_factory(config, model_cfg, is_draft=is_draft, topo=topo, weight_source=iter((wd if is_draft else wt).items()), **k2)
 
     gpu_eng = LLMEngine("t", runner_factory=hipf, inprocess_draft=mode == "async", **kw)
-    cpu_eng = LLMEngine("t", runner_factory=oracle_runner_factory(wt, wd), inprocess_draft=mode == "async", **kw)
+    from ssd_amd.utils.topology import Topology
+    cpu_eng = LLMEngine("t", runner_factory=oracle_runner_factory(wt, wd), inprocess_draft=mode == "async",
+                        topology=Topology(0, 1, torch.device("cpu"), "target", 0, 1), **kw)      # (the oracle's tensors live on the host)
     rep = compare_lockstep(gpu_eng, cpu_eng, prompt, n_new, lambda n: SamplingParams(temperature=0, max_new_tokens=n, ignore_eos=True),
                            fan_out=3 if mode == "async" else None, what=f"8B+1B {mode}")
     gpu_eng.exit()
