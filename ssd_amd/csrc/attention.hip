@@ -72,12 +72,6 @@ __global__ void __launch_bounds__(512) attn_kernel(const AttnParams p) {
   const int b = OPROJ ? 0 : (int)(blockIdx.x / p.nkv), h = blockIdx.x % p.nkv;
   const int G = p.nh / p.nkv;
   u32x4_t wreg[OPROJ ? 8 : 1];
-  if constexpr (OPROJ) {
-    const int KTo = (p.nh * HD) >> 5, KS = (G * HD) >> 5;                   // k-tiles of o_proj's K, of one kv head's slice (<= 8)
-    const u32x4_t* wp = p.ow + ((size_t)(((blockIdx.x / p.nkv) * 8 + wave) * KTo + h * KS) << 6) + lane;
-#pragma unroll
-    for (int kt = 0; kt < 8; ++kt) wreg[kt] = __builtin_nontemporal_load(wp + ((size_t)min(kt, KS - 1) << 6));   // clamped: unconditional loads
-  }
   const int q0 = p.cu_q ? p.cu_q[b] : b * p.q_per_seq;
   const int Tq = p.cu_q ? (p.cu_q[b + 1] - q0) : p.q_per_seq;
   const int rows = Tq * G;
@@ -194,6 +188,16 @@ __global__ void __launch_bounds__(512) attn_kernel(const AttnParams p) {
       if constexpr (PIPE_K) issue_k(k0 + j * stride, ca[j], cb[j], kreg[j]);
       issue_v(k0 + j * stride, ca[j], cb[j], vreg[j]);
     }
+  if constexpr (OPROJ) {
+    // the o_proj slice is needed LAST (after the merge); until round 3 its 8 KiB per wave were the first loads of the kernel,
+    // i.e. the oldest in the in-order return queue: every wait of the attention proper -- Q, the first K / V tiles -- was a wait
+    // for an HBM round trip of weights as well (first K / V issue at +4.6 us, profiles/r04_ktrace_1b_before.txt).  Issued here,
+    // behind the first tiles, they stream while the keys are processed
+    const int KTo = (p.nh * HD) >> 5, KS = (G * HD) >> 5;                   // k-tiles of o_proj's K, of one kv head's slice (<= 8)
+    const u32x4_t* wp = p.ow + ((size_t)(((blockIdx.x / p.nkv) * 8 + wave) * KTo + h * KS) << 6) + lane;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) wreg[kt] = __builtin_nontemporal_load(wp + ((size_t)min(kt, KS - 1) << 6));   // clamped: unconditional loads
+  }
   KTRACE(KTS, 1);
 
   for (; k0 < kmax; k0 += KT * stride) {
@@ -366,17 +370,32 @@ __global__ void __launch_bounds__(512) attn_kernel(const AttnParams p) {
     const int lr = item / (HD / 4), d = (item % (HD / 4)) * 4;
     const int rho = tile_base * 16 + lr;
     if (rho >= rows) continue;
+    // all of the (<= 8) waves' partials are read first, then merged in wave order: the rolled loops were ds_read -> wait -> use
+    // per wave, twice (1.3-1.5 us of merge in a 10-13 us kernel, profiles/r04_ktrace_1b_before.txt); slots past W re-read the last
+    // wave's and are not used -- same operations in the same order, bit-identical
+    float mw[8], lw[8];
+    f32x4_t ow[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      const float* base = reinterpret_cast<const float*>(smem + (size_t)min(w, W - 1) * REGION);
+      mw[w] = base[RT * 16 * HD + lr * 2];
+      lw[w] = base[RT * 16 * HD + lr * 2 + 1];
+      ow[w] = *reinterpret_cast<const f32x4_t*>(base + lr * HD + d);
+    }
     float M = -INFINITY;
-    for (int w = 0; w < W; ++w) M = fmaxf(M, reinterpret_cast<const float*>(smem + (size_t)w * REGION)[RT * 16 * HD + lr * 2]);
+#pragma unroll
+    for (int w = 0; w < 8; ++w)
+      if (w < W) M = fmaxf(M, mw[w]);
     const float Ms = (M == -INFINITY) ? 0.f : M;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     float L = 0.f;
-    for (int w = 0; w < W; ++w) {
-      const float* base = reinterpret_cast<const float*>(smem + (size_t)w * REGION);
-      const float wt = exp2f(base[RT * 16 * HD + lr * 2] - Ms);
-      L += wt * base[RT * 16 * HD + lr * 2 + 1];
-      acc += wt * *reinterpret_cast<const f32x4_t*>(base + lr * HD + d);
-    }
+#pragma unroll
+    for (int w = 0; w < 8; ++w)
+      if (w < W) {
+        const float wt = exp2f(mw[w] - Ms);
+        L += wt * lw[w];
+        acc += wt * ow[w];
+      }
     const int tok = q0 + rho / G, head = h * G + rho % G;
     const size_t row = (size_t)tok * p.nh + head;
     if constexpr (OPROJ) {

@@ -120,15 +120,143 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
   const int kt0 = wave * U;
   const int ngroups = KT / U;
   const int nmain = ngroups > wave ? (ngroups - wave + nw - 1) / nw : 0;   // groups of this wave
+  float pre_cs[8];
+  int pre_slot = -1;
+  bool pre_ok = false;
+  constexpr bool EARLY = XNORM && FUSED_MAXC == 1;      // single-token draft decode: M * K / 8 chunks fit the workgroup's threads
+  if constexpr (EARLY) {
+    // ---- the latency-ordered front (round 4, from the in-kernel timeline profiles/r04_ktrace_1b_before.txt) ----
+    // The kernel is ONE dependency chain: x / slabs -> sum of squares -> x^ -> MFMA -> combine -> epilogue.  Vector-memory
+    // returns are counted in order (vmcnt), so the head of that chain must be the OLDEST loads in flight: issued behind the
+    // weight tiles (as until round 3) the prologue's first wait was a wait for the weights' HBM round trip as well, and the
+    // RoPE operands' positions -> cos / sin chain in front of it cost another round trip (x^ ready at +5.5 us; with 512
+    // workgroups queueing 67 MB of gate_up weights first, at +13.9 us).  Order now: [positions, slots] [residual, norm weight,
+    // S slabs] [weight group 0], all of them unconditional (clamped indices, pointer select) so that every wait is an exact
+    // vmcnt(n > 0); cos / sin are fetched after the prologue, behind the weights, and land during the MFMAs.
+    float* ssbuf = reinterpret_cast<float*>(smem);
+    const int total = M * K8;
+    const int c = min((int)threadIdx.x, total - 1);
+    const bool act = (int)threadIdx.x < total;
+    const int mm = c / K8, k8 = c % K8;
+    const int mrow = min(mcol, M - 1);
+    int64_t pos = 0;
+    if (EPI == FEPI_QKV_ROPE) { pos = p.positions[mrow]; pre_slot = p.slots[mrow]; }
+    // (a) x = h + res, norm weight.  The slabs are summed in slab order (deterministic); slots past S re-read slab S - 1 and are
+    //     not added: every load is issued, none is conditional
+    const u32x4_t e_w = *reinterpret_cast<const u32x4_t*>(p.norm_w + k8 * 8);
+    // (dummy sources sit at DIFFERENT addresses than the norm weight's own chunk: an equal address is folded into "reuse that
+    // load's value" -- a branch and a wait in front of the weight loads)
+    const u32x4_t e_res = *reinterpret_cast<const u32x4_t*>(p.res_in ? p.res_in + (size_t)mm * K + k8 * 8 : p.norm_w + (k8 ^ 1) * 8);
+    // (both x sources are read, the absent one from an L2-resident dummy: no branch separates the loads from the sched_barrier
+    // below, so the compiler cannot sink the first use -- and its wait -- in front of the weight loads, as it did with an `if`)
+    f32x4_t e_lo[8], e_hi[8];
+    const float* hp = p.h_parts ? p.h_parts + (size_t)mm * K + k8 * 8 : reinterpret_cast<const float*>(p.norm_w) + min(k8 * 4, (K >> 1) - 8);
+    const size_t slab_stride = p.h_parts ? (size_t)M * K : 0;
+    const int nslab = p.h_parts ? p.S : 0;
+#pragma unroll
+    for (int sidx = 0; sidx < 8; ++sidx) {
+      const float* src = hp + (size_t)max(0, min(sidx, nslab - 1)) * slab_stride;
+      e_lo[sidx] = *reinterpret_cast<const f32x4_t*>(src);
+      e_hi[sidx] = *reinterpret_cast<const f32x4_t*>(src + 4);
+    }
+    const u32x4_t e_h = *reinterpret_cast<const u32x4_t*>(p.h ? p.h + (size_t)mm * K + k8 * 8 : p.norm_w + (k8 ^ 2) * 8);
+    __builtin_amdgcn_sched_barrier(0);
+    // (b) weight group 0: a wave without a group (fewer groups than waves) reads an L2-resident dummy (the norm weight) instead --
+    //     an unconditional load either way
+    {
+      const bool have = nmain > 0;
+      const u32x4_t* base = have ? wp + ((size_t)kt0 << 6) : reinterpret_cast<const u32x4_t*>(p.norm_w) + (lane & 3);
+      const size_t s_nt = have ? wstride : 0, s_u = have ? 64 : 0;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wa[0][u][nt] = __builtin_nontemporal_load(base + nt * s_nt + u * s_u);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    KTRACE(KTS, 1);
+    // (c) x32, chunk sums, residual slice
+    float x32[8];
+    {
+      float hf[8];
+      f32x4_t lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+#pragma unroll
+      for (int sidx = 0; sidx < 8; ++sidx)
+        if (sidx < nslab) { lo += e_lo[sidx]; hi += e_hi[sidx]; }
+      for (int sidx = 8; sidx < nslab; ++sidx) {          // (more than 8 slabs: not a shape the engine produces)
+        const float* src = hp + (size_t)sidx * slab_stride;
+        lo += *reinterpret_cast<const f32x4_t*>(src);
+        hi += *reinterpret_cast<const f32x4_t*>(src + 4);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        hf[j] = p.h_parts ? round_bf(lo[j]) : bf2f(e_h[j >> 1] >> ((j & 1) * 16) & 0xffffu);
+        hf[4 + j] = p.h_parts ? round_bf(hi[j]) : bf2f(e_h[2 + (j >> 1)] >> ((j & 1) * 16) & 0xffffu);
+      }
+      const u32x4_t rv = p.res_in ? e_res : u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x32[2 * j] = hf[2 * j] + bf2f(rv[j] & 0xffffu);
+        x32[2 * j + 1] = hf[2 * j + 1] + bf2f(rv[j] >> 16);
+      }
+    }
+    const int cpb = (K8 + gridDim.x - 1) / gridDim.x;              // residual: workgroup b owns chunk columns [b*cpb, (b+1)*cpb)
+    if (act) {
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ss += x32[2 * j] * x32[2 * j]; ss += x32[2 * j + 1] * x32[2 * j + 1]; }
+      ssbuf[c] = ss;
+      if (p.res_out && k8 / cpb == (int)blockIdx.x) {
+        u32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = pack_bf2(x32[2 * j], x32[2 * j + 1]);
+        *reinterpret_cast<u32x4_t*>(p.res_out + (size_t)mm * K + k8 * 8) = o;
+      }
+    }
+    // (d) cos / sin of this wave's epilogue row group: `pos` (older than x) has arrived with x, so the pair is issued now and lands
+    //     with the weights (unconditional: a clamped group, read for nothing by the waves that own no row group); then the second
+    //     weight group of waves that have one
+    if (EPI == FEPI_QKV_ROPE) {
+      const int gph = p.hd >> 4;
+      const int grp = min(tile0 + min(wave, NT - 1), (p.nh + p.nkv) * gph - 1);
+      const int d = (grp % gph) * 8 + (q4 & 1) * 4;
+      const float* cs = p.cos_sin + (size_t)pos * p.hd;
+      const f32x4_t c4 = *reinterpret_cast<const f32x4_t*>(cs + d), s4 = *reinterpret_cast<const f32x4_t*>(cs + (p.hd >> 1) + d);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { pre_cs[r] = c4[r]; pre_cs[4 + r] = s4[r]; }
+      pre_ok = wave < NT && mcol < M;
+    }
+    if (nmain > 1) loadw(1, kt0 + kstep);
+    __syncthreads();
+    KTRACE(KTS, 2);
+    // every wave reduces the chunk sums of all M rows itself (same order as ssd_rmsnorm: lane-strided partials, then the
+    // xor tree) and keeps rs in its own LDS row: no second workgroup barrier
+    float* rsbuf = ssbuf + total + wave * 16;           // behind the chunk sums
+    for (int m2 = 0; m2 < M; ++m2) {
+      float t = 0.f;
+      for (int cc = lane; cc < K8; cc += 64) t += ssbuf[m2 * K8 + cc];
+      t = wave_sum(t);
+      if (lane == 0) rsbuf[m2] = 1.0f / sqrtf(t / (float)K + p.eps);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (act) {
+      const float rs = rsbuf[mm];
+      u32x4_t o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        o[j] = pack_bf2((x32[2 * j] * rs) * bf2f(e_w[j] & 0xffffu), (x32[2 * j + 1] * rs) * bf2f(e_w[j] >> 16));
+      xlds[k8 * M + mm] = o;
+    }
+    __syncthreads();
+    KTRACE(KTS, 3);
+  } else {
   // the first TWO groups of weight tiles fly while the norm prologue runs (for the 1B draft that is the whole K range:
   // one HBM round trip per wave; a kernel this short is a latency chain)
   if (nmain > 0) loadw(0, kt0);
   if (nmain > 1) loadw(1, kt0 + kstep);
   // RoPE epilogue operands of the wave that will own row group `wave` (positions -> cos/sin rows -> slot: a chain of
   // dependent L2 round trips if left to the epilogue), fetched now, behind the weight stream
-  float pre_cs[8];
-  int pre_slot = -1;
-  bool pre_ok = false;
   if (EPI == FEPI_QKV_ROPE && wave < NT && mcol < M) {
     const int grp = tile0 + wave;
     const int gph = p.hd >> 4;
@@ -233,6 +361,8 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
     KTRACE(KTS, 3);
   }
 
+  }
+
   auto xfrag = [&](int buf, int u, int kt) -> u32x4_t {
     if (!XNORM) return xg[buf][u];
     u32x4_t o = {0u, 0u, 0u, 0u};
@@ -283,11 +413,8 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
     const int KT2 = (p.N >> 1) >> 5;
     u32x2_t* out = reinterpret_cast<u32x2_t*>(p.y);
     for (int pr = wave; pr < PAIRS; pr += nw) {
-      f32x4_t g = f32x4_t{0.f, 0.f, 0.f, 0.f}, u = g;
-      for (int w = 0; w < nw; ++w) {
-        g += cred[(w * NT + 2 * pr) * 64 + lane];
-        u += cred[(w * NT + 2 * pr + 1) * 64 + lane];
-      }
+      const f32x4_t g = lds_sum_waves(cred + (2 * pr) * 64 + lane, NT * 64, nw);
+      const f32x4_t u = lds_sum_waves(cred + (2 * pr + 1) * 64 + lane, NT * 64, nw);
       const int n = ((tile0 >> 1) + pr) * 16 + nrow;
       float o[4];
 #pragma unroll
@@ -302,8 +429,7 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
     }
   } else {
     for (int nt = wave; nt < NT; nt += nw) {
-      f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      for (int w = 0; w < nw; ++w) s += cred[(w * NT + nt) * 64 + lane];
+      f32x4_t s = lds_sum_waves(cred + nt * 64 + lane, NT * 64, nw);
       const int grp = tile0 + nt;
       if (p.bias) {
 #pragma unroll
@@ -382,6 +508,7 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
 template <int NT>
 __global__ void __launch_bounds__(1024) gemm_qkv_rope_m32_kernel(const FusedParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  KTRACE(3, 0);
   constexpr int MT = 2, U = 2;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -446,13 +573,14 @@ __global__ void __launch_bounds__(1024) gemm_qkv_rope_m32_kernel(const FusedPara
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) cred[(wave * NT * MT + nt * MT + mt) * 64 + lane] = acc[nt][mt];
+  KTRACE(3, 4);
   __syncthreads();
+  KTRACE(3, 5);
   const int nrow = q4 * 4;
   const int gph = p.hd >> 4, qk_groups = (p.nh + p.nkv) * gph, half = p.hd >> 1;
   for (int item = wave; item < NT * MT; item += nw) {
     const int nt = item / MT, mt = item % MT;
-    f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    for (int w = 0; w < nw; ++w) s += cred[(w * NT * MT + item) * 64 + lane];
+    f32x4_t s = lds_sum_waves(cred + item * 64 + lane, NT * MT * 64, nw);
     const int grp = tile0 + nt;
     const int m = mt * 16 + mcol;
     if (p.bias) {
@@ -500,6 +628,7 @@ __global__ void __launch_bounds__(1024) gemm_qkv_rope_m32_kernel(const FusedPara
       }
     }
   }
+  KTRACE(3, 6);
 }
 
 template <int NT>

@@ -46,25 +46,42 @@ rmsnorm_kernel(const u32x4_t* __restrict__ x, const u32x4_t* __restrict__ res_in
   const int KT = H >> 5;
   constexpr int NORM_MAXC = NORM_MAXH / 8 / NORM_THREADS;
   float v[NORM_MAXC][8];
+  u32x4_t wreg[NORM_MAXC];      // the norm weight, fetched with the inputs (after the barrier it was one more dependent round trip)
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < NORM_MAXC; ++i) {
     const int c = threadIdx.x + i * NORM_THREADS;
     if (c < H8) {
       u32x4_t xv;
+      wreg[i] = w[c];
+      u32x4_t rv = {0u, 0u, 0u, 0u};
+      if (res_in) rv = res_in[(size_t)row_in * H8 + c];
       if (parts) {      // x = bf16(sum of the producer GEMM's S fp32 partial slabs, in slab order) -- csrc/gemm_sk.hip ssd_gemm_parts
+        // every slab's loads are issued before the first add (a rolled `for s < S` is load -> wait -> add per slab: S dependent
+        // L2 round trips in a kernel that is nothing but a latency chain, 3.8 us at S = 4); slots past S re-read slab S - 1 and
+        // are not added -- the same additions in the same order
         f32x4_t a = {0.f, 0.f, 0.f, 0.f}, b = a;
-        for (int sidx = 0; sidx < S; ++sidx) {
-          const float* src = parts + ((size_t)sidx * slab_rows + row_in) * H + c * 8;
-          a += *reinterpret_cast<const f32x4_t*>(src);
-          b += *reinterpret_cast<const f32x4_t*>(src + 4);
+        const float* src0 = parts + (size_t)row_in * H + c * 8;
+        const size_t sstride = (size_t)slab_rows * H;
+#pragma unroll
+        for (int s0 = 0; s0 < 16; s0 += 8) {
+          if (s0 < S) {
+            f32x4_t ta[8], tb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float* src = src0 + (size_t)min(s0 + j, S - 1) * sstride;
+              ta[j] = *reinterpret_cast<const f32x4_t*>(src);
+              tb[j] = *reinterpret_cast<const f32x4_t*>(src + 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (s0 + j < S) { a += ta[j]; b += tb[j]; }
+          }
         }
         xv = u32x4_t{pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(b[0], b[1]), pack_bf2(b[2], b[3])};
       } else {
         xv = x[(size_t)row_in * H8 + c];
       }
-      u32x4_t rv = {0u, 0u, 0u, 0u};
-      if (res_in) rv = res_in[(size_t)row_in * H8 + c];
       u32x4_t ro;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -88,7 +105,7 @@ rmsnorm_kernel(const u32x4_t* __restrict__ x, const u32x4_t* __restrict__ res_in
   for (int i = 0; i < NORM_MAXC; ++i) {
     const int c = threadIdx.x + i * NORM_THREADS;
     if (c < H8) {
-      const u32x4_t wv = w[c];
+      const u32x4_t wv = wreg[i];
       u32x4_t o;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
