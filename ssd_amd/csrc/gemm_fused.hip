@@ -141,25 +141,33 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
     const int mrow = min(mcol, M - 1);
     int64_t pos = 0;
     if (EPI == FEPI_QKV_ROPE) { pos = p.positions[mrow]; pre_slot = p.slots[mrow]; }
-    // (a) x = h + res, norm weight.  The slabs are summed in slab order (deterministic); slots past S re-read slab S - 1 and are
-    //     not added: every load is issued, none is conditional
-    const u32x4_t e_w = *reinterpret_cast<const u32x4_t*>(p.norm_w + k8 * 8);
-    // (dummy sources sit at DIFFERENT addresses than the norm weight's own chunk: an equal address is folded into "reuse that
-    // load's value" -- a branch and a wait in front of the weight loads)
-    const u32x4_t e_res = *reinterpret_cast<const u32x4_t*>(p.res_in ? p.res_in + (size_t)mm * K + k8 * 8 : p.norm_w + (k8 ^ 1) * 8);
-    // (both x sources are read, the absent one from an L2-resident dummy: no branch separates the loads from the sched_barrier
-    // below, so the compiler cannot sink the first use -- and its wait -- in front of the weight loads, as it did with an `if`)
+    // (a) x = h + res, norm weight: only the lanes that own a chunk load (M = 1: 4 of the 16 waves; the first version of this
+    //     front had every lane issue clamped copies -- 16 slab loads x 1024 threads in front of the weights made the kernel
+    //     SLOWER, profiles/r04_ktrace_1b_after_v1.txt).  These loads are OLDER than the weight loads, so conditions around them
+    //     cost the later waits nothing (a wait for an old load only counts the loads guaranteed to be younger).
+    const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+    const f32x4_t zerof = {0.f, 0.f, 0.f, 0.f};
+    u32x4_t e_w = zero4, e_res = zero4, e_h = zero4;
     f32x4_t e_lo[8], e_hi[8];
-    const float* hp = p.h_parts ? p.h_parts + (size_t)mm * K + k8 * 8 : reinterpret_cast<const float*>(p.norm_w) + min(k8 * 4, (K >> 1) - 8);
-    const size_t slab_stride = p.h_parts ? (size_t)M * K : 0;
-    const int nslab = p.h_parts ? p.S : 0;
 #pragma unroll
-    for (int sidx = 0; sidx < 8; ++sidx) {
-      const float* src = hp + (size_t)max(0, min(sidx, nslab - 1)) * slab_stride;
-      e_lo[sidx] = *reinterpret_cast<const f32x4_t*>(src);
-      e_hi[sidx] = *reinterpret_cast<const f32x4_t*>(src + 4);
+    for (int sidx = 0; sidx < 8; ++sidx) { e_lo[sidx] = zerof; e_hi[sidx] = zerof; }
+    const int nslab = p.h_parts ? p.S : 0;
+    const float* hp = p.h_parts + (size_t)mm * K + k8 * 8;
+    const size_t slab_stride = (size_t)M * K;
+    if (act) {
+      e_w = *reinterpret_cast<const u32x4_t*>(p.norm_w + k8 * 8);
+      if (p.res_in) e_res = *reinterpret_cast<const u32x4_t*>(p.res_in + (size_t)mm * K + k8 * 8);
+      if (p.h_parts) {
+#pragma unroll
+        for (int sidx = 0; sidx < 8; ++sidx)
+          if (sidx < nslab) {
+            e_lo[sidx] = *reinterpret_cast<const f32x4_t*>(hp + sidx * slab_stride);
+            e_hi[sidx] = *reinterpret_cast<const f32x4_t*>(hp + sidx * slab_stride + 4);
+          }
+      } else {
+        e_h = *reinterpret_cast<const u32x4_t*>(p.h + (size_t)mm * K + k8 * 8);
+      }
     }
-    const u32x4_t e_h = *reinterpret_cast<const u32x4_t*>(p.h ? p.h + (size_t)mm * K + k8 * 8 : p.norm_w + (k8 ^ 2) * 8);
     __builtin_amdgcn_sched_barrier(0);
     // (b) weight group 0: a wave without a group (fewer groups than waves) reads an L2-resident dummy (the norm weight) instead --
     //     an unconditional load either way
@@ -173,6 +181,12 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
         for (int nt = 0; nt < NT; ++nt) wa[0][u][nt] = __builtin_nontemporal_load(base + nt * s_nt + u * s_u);
     }
     __builtin_amdgcn_sched_barrier(0);
+    // the x registers become "known" only here: the compiler can neither sink their first use into the load blocks above (it did:
+    // a wait for slab 0 in front of the weight loads) nor move a weight load below this point; the wait it inserts for them here
+    // is an exact vmcnt(weight loads)
+#pragma unroll
+    for (int sidx = 0; sidx < 8; ++sidx) asm volatile("" : "+v"(e_lo[sidx]), "+v"(e_hi[sidx]) : : "memory");
+    asm volatile("" : "+v"(e_w), "+v"(e_res), "+v"(e_h) : : "memory");
     KTRACE(KTS, 1);
     // (c) x32, chunk sums, residual slice
     float x32[8];

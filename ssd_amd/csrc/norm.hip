@@ -58,8 +58,7 @@ rmsnorm_kernel(const u32x4_t* __restrict__ x, const u32x4_t* __restrict__ res_in
       if (res_in) rv = res_in[(size_t)row_in * H8 + c];
       if (parts) {      // x = bf16(sum of the producer GEMM's S fp32 partial slabs, in slab order) -- csrc/gemm_sk.hip ssd_gemm_parts
         // every slab's loads are issued before the first add (a rolled `for s < S` is load -> wait -> add per slab: S dependent
-        // L2 round trips in a kernel that is nothing but a latency chain, 3.8 us at S = 4); slots past S re-read slab S - 1 and
-        // are not added -- the same additions in the same order
+        // L2 round trips in a kernel that is nothing but a latency chain, 3.8 us at S = 4) -- the same additions in the same order
         f32x4_t a = {0.f, 0.f, 0.f, 0.f}, b = a;
         const float* src0 = parts + (size_t)row_in * H + c * 8;
         const size_t sstride = (size_t)slab_rows * H;
@@ -69,10 +68,16 @@ rmsnorm_kernel(const u32x4_t* __restrict__ x, const u32x4_t* __restrict__ res_in
             f32x4_t ta[8], tb[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              const float* src = src0 + (size_t)min(s0 + j, S - 1) * sstride;
-              ta[j] = *reinterpret_cast<const f32x4_t*>(src);
-              tb[j] = *reinterpret_cast<const f32x4_t*>(src + 4);
+              ta[j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; tb[j] = ta[j];
+              if (s0 + j < S) {         // (block-uniform; no clamped re-reads: a first version that read 8 slabs whatever S was slower)
+                const float* src = src0 + (size_t)(s0 + j) * sstride;
+                ta[j] = *reinterpret_cast<const f32x4_t*>(src);
+                tb[j] = *reinterpret_cast<const f32x4_t*>(src + 4);
+              }
             }
+            // the values become "known" only here: the first add (and its wait) cannot be sunk into the load blocks above
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(ta[j]), "+v"(tb[j]));
 #pragma unroll
             for (int j = 0; j < 8; ++j)
               if (s0 + j < S) { a += ta[j]; b += tb[j]; }
