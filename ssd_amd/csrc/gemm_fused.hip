@@ -124,7 +124,11 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
   int pre_slot = -1;
   bool pre_ok = false;
   constexpr bool EARLY = XNORM && FUSED_MAXC == 1;      // single-token draft decode: M * K / 8 chunks fit the workgroup's threads
+  __shared__ int pro_cnt[2];          // EARLY: producer-wave meeting point / "x^ published" (see (c) below)
   if constexpr (EARLY) {
+    if (threadIdx.x == 0) { pro_cnt[0] = 0; pro_cnt[1] = 0; }
+    __syncthreads();                  // before any load is issued: every wave is here within a few hundred cycles of the launch
+
     // ---- the latency-ordered front (round 4, from the in-kernel timeline profiles/r04_ktrace_1b_before.txt) ----
     // The kernel is ONE dependency chain: x / slabs -> sum of squares -> x^ -> MFMA -> combine -> epilogue.  Vector-memory
     // returns are counted in order (vmcnt), so the head of that chain must be the OLDEST loads in flight: issued behind the
@@ -188,47 +192,82 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
     for (int sidx = 0; sidx < 8; ++sidx) asm volatile("" : "+v"(e_lo[sidx]), "+v"(e_hi[sidx]) : : "memory");
     asm volatile("" : "+v"(e_w), "+v"(e_res), "+v"(e_h) : : "memory");
     KTRACE(KTS, 1);
-    // (c) x32, chunk sums, residual slice
-    float x32[8];
-    {
-      float hf[8];
-      f32x4_t lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+    // (c) the prologue proper, by the PRODUCER waves only (the nwa waves whose lanes own a chunk; M = 1: 4 of 16) and without a
+    //     workgroup barrier: a barrier is reached by a wave only after it has ISSUED its weight loads, and with 512 workgroups
+    //     queueing 67 MB that is +8 us -- x^ was ready at +13.9 us although its inputs had long arrived, and the MFMAs of every
+    //     wave waited for it (profiles/r04_ktrace_1b_before.txt / _after2.txt).  The producers meet on an LDS counter, publish x^
+    //     with a second one, and every wave polls that one right before its first MFMA.  No fences: LDS operations of one wave
+    //     execute in order (data before counter on the writer side, counter before data on the reader side) and a workgroup-scope
+    //     release would drain the wave's weight loads (s_waitcnt vmcnt(0)); the asm statements only stop the COMPILER reordering.
+    const int nwa = (total + 63) >> 6;
+    if (wave < nwa) {
+      float x32[8];
+      {
+        float hf[8];
+        f32x4_t lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
 #pragma unroll
-      for (int sidx = 0; sidx < 8; ++sidx)
-        if (sidx < nslab) { lo += e_lo[sidx]; hi += e_hi[sidx]; }
-      for (int sidx = 8; sidx < nslab; ++sidx) {          // (more than 8 slabs: not a shape the engine produces)
-        const float* src = hp + (size_t)sidx * slab_stride;
-        lo += *reinterpret_cast<const f32x4_t*>(src);
-        hi += *reinterpret_cast<const f32x4_t*>(src + 4);
+        for (int sidx = 0; sidx < 8; ++sidx)
+          if (sidx < nslab) { lo += e_lo[sidx]; hi += e_hi[sidx]; }
+        for (int sidx = 8; sidx < nslab; ++sidx) {          // (more than 8 slabs: not a shape the engine produces)
+          const float* src = hp + (size_t)sidx * slab_stride;
+          lo += *reinterpret_cast<const f32x4_t*>(src);
+          hi += *reinterpret_cast<const f32x4_t*>(src + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          hf[j] = p.h_parts ? round_bf(lo[j]) : bf2f(e_h[j >> 1] >> ((j & 1) * 16) & 0xffffu);
+          hf[4 + j] = p.h_parts ? round_bf(hi[j]) : bf2f(e_h[2 + (j >> 1)] >> ((j & 1) * 16) & 0xffffu);
+        }
+        const u32x4_t rv = p.res_in ? e_res : u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          x32[2 * j] = hf[2 * j] + bf2f(rv[j] & 0xffffu);
+          x32[2 * j + 1] = hf[2 * j + 1] + bf2f(rv[j] >> 16);
+        }
       }
+      const int cpb = (K8 + gridDim.x - 1) / gridDim.x;              // residual: workgroup b owns chunk columns [b*cpb, (b+1)*cpb)
+      if (act) {
+        float ss = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        hf[j] = p.h_parts ? round_bf(lo[j]) : bf2f(e_h[j >> 1] >> ((j & 1) * 16) & 0xffffu);
-        hf[4 + j] = p.h_parts ? round_bf(hi[j]) : bf2f(e_h[2 + (j >> 1)] >> ((j & 1) * 16) & 0xffffu);
+        for (int j = 0; j < 4; ++j) { ss += x32[2 * j] * x32[2 * j]; ss += x32[2 * j + 1] * x32[2 * j + 1]; }
+        ssbuf[c] = ss;
+        if (p.res_out && k8 / cpb == (int)blockIdx.x) {
+          u32x4_t o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = pack_bf2(x32[2 * j], x32[2 * j + 1]);
+          *reinterpret_cast<u32x4_t*>(p.res_out + (size_t)mm * K + k8 * 8) = o;
+        }
       }
-      const u32x4_t rv = p.res_in ? e_res : u32x4_t{0u, 0u, 0u, 0u};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        x32[2 * j] = hf[2 * j] + bf2f(rv[j] & 0xffffu);
-        x32[2 * j + 1] = hf[2 * j + 1] + bf2f(rv[j] >> 16);
+      asm volatile("" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(&pro_cnt[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      while (__hip_atomic_load(&pro_cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < nwa) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
+      KTRACE(KTS, 2);
+      // every producer wave reduces the chunk sums of all M rows itself (same order as ssd_rmsnorm: lane-strided partials, then
+      // the xor tree) and keeps rs in its own LDS row
+      float* rsbuf = ssbuf + total + wave * 16;           // behind the chunk sums
+      for (int m2 = 0; m2 < M; ++m2) {
+        float t = 0.f;
+        for (int cc = lane; cc < K8; cc += 64) t += ssbuf[m2 * K8 + cc];
+        t = wave_sum(t);
+        if (lane == 0) rsbuf[m2] = 1.0f / sqrtf(t / (float)K + p.eps);
       }
-    }
-    const int cpb = (K8 + gridDim.x - 1) / gridDim.x;              // residual: workgroup b owns chunk columns [b*cpb, (b+1)*cpb)
-    if (act) {
-      float ss = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { ss += x32[2 * j] * x32[2 * j]; ss += x32[2 * j + 1] * x32[2 * j + 1]; }
-      ssbuf[c] = ss;
-      if (p.res_out && k8 / cpb == (int)blockIdx.x) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (act) {
+        const float rs = rsbuf[mm];
         u32x4_t o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = pack_bf2(x32[2 * j], x32[2 * j + 1]);
-        *reinterpret_cast<u32x4_t*>(p.res_out + (size_t)mm * K + k8 * 8) = o;
+        for (int j = 0; j < 4; ++j)
+          o[j] = pack_bf2((x32[2 * j] * rs) * bf2f(e_w[j] & 0xffffu), (x32[2 * j + 1] * rs) * bf2f(e_w[j] >> 16));
+        xlds[k8 * M + mm] = o;
       }
+      asm volatile("" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(&pro_cnt[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    // (d) cos / sin of this wave's epilogue row group: `pos` (older than x) has arrived with x, so the pair is issued now and lands
-    //     with the weights (unconditional: a clamped group, read for nothing by the waves that own no row group); then the second
-    //     weight group of waves that have one
+    // (d) cos / sin of this wave's epilogue row group (`pos` is older than the weights: an exact wait), then the second weight group
+    //     of waves that have one
     if (EPI == FEPI_QKV_ROPE) {
       const int gph = p.hd >> 4;
       const int grp = min(tile0 + min(wave, NT - 1), (p.nh + p.nkv) * gph - 1);
@@ -240,29 +279,9 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
       pre_ok = wave < NT && mcol < M;
     }
     if (nmain > 1) loadw(1, kt0 + kstep);
-    __syncthreads();
-    KTRACE(KTS, 2);
-    // every wave reduces the chunk sums of all M rows itself (same order as ssd_rmsnorm: lane-strided partials, then the
-    // xor tree) and keeps rs in its own LDS row: no second workgroup barrier
-    float* rsbuf = ssbuf + total + wave * 16;           // behind the chunk sums
-    for (int m2 = 0; m2 < M; ++m2) {
-      float t = 0.f;
-      for (int cc = lane; cc < K8; cc += 64) t += ssbuf[m2 * K8 + cc];
-      t = wave_sum(t);
-      if (lane == 0) rsbuf[m2] = 1.0f / sqrtf(t / (float)K + p.eps);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (act) {
-      const float rs = rsbuf[mm];
-      u32x4_t o;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        o[j] = pack_bf2((x32[2 * j] * rs) * bf2f(e_w[j] & 0xffffu), (x32[2 * j + 1] * rs) * bf2f(e_w[j] >> 16));
-      xlds[k8 * M + mm] = o;
-    }
-    __syncthreads();
+    // (e) every wave: x^ published?  (an LDS poll; the producers are long done by the time a consumer's weights arrive)
+    while (__hip_atomic_load(&pro_cnt[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < nwa) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
     KTRACE(KTS, 3);
   } else {
   // the first TWO groups of weight tiles fly while the norm prologue runs (for the 1B draft that is the whole K range:

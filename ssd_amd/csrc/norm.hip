@@ -6,6 +6,7 @@
 // The normalised output can be written row-major and/or directly in the fragment-major layout that
 // the next skinny GEMM consumes (common.h), so no separate re-layout pass exists on the hot path.
 #include "common.h"
+#include <type_traits>
 
 __global__ void embedding_kernel(const int64_t* __restrict__ ids, const u32x4_t* __restrict__ table,
                                  u32x4_t* __restrict__ out, int H8, long vocab_start, long vocab_count) {
@@ -62,26 +63,27 @@ rmsnorm_kernel(const u32x4_t* __restrict__ x, const u32x4_t* __restrict__ res_in
         f32x4_t a = {0.f, 0.f, 0.f, 0.f}, b = a;
         const float* src0 = parts + (size_t)row_in * H + c * 8;
         const size_t sstride = (size_t)slab_rows * H;
+        // one straight-line path per slab count class (block-uniform switch): SN loads issued back to back, then SN adds.  (Round 4
+        // tried "always 8 clamped loads" -- better at S = 4, worse at S = 2 -- and "conditional loads + opaque uses" -- worse
+        // everywhere, the code tripled: profiles/r04_ktrace_1b_after_v1.txt / _after2.txt.)
+        auto sum_slabs = [&](auto sn, int s0) {
+          constexpr int SN = decltype(sn)::value;
+          f32x4_t ta[SN], tb[SN];
 #pragma unroll
-        for (int s0 = 0; s0 < 16; s0 += 8) {
-          if (s0 < S) {
-            f32x4_t ta[8], tb[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              ta[j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; tb[j] = ta[j];
-              if (s0 + j < S) {         // (block-uniform; no clamped re-reads: a first version that read 8 slabs whatever S was slower)
-                const float* src = src0 + (size_t)(s0 + j) * sstride;
-                ta[j] = *reinterpret_cast<const f32x4_t*>(src);
-                tb[j] = *reinterpret_cast<const f32x4_t*>(src + 4);
-              }
-            }
-            // the values become "known" only here: the first add (and its wait) cannot be sunk into the load blocks above
-#pragma unroll
-            for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(ta[j]), "+v"(tb[j]));
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (s0 + j < S) { a += ta[j]; b += tb[j]; }
+          for (int j = 0; j < SN; ++j) {
+            const float* src = src0 + (size_t)min(s0 + j, S - 1) * sstride;
+            ta[j] = *reinterpret_cast<const f32x4_t*>(src);
+            tb[j] = *reinterpret_cast<const f32x4_t*>(src + 4);
           }
+#pragma unroll
+          for (int j = 0; j < SN; ++j)
+            if (s0 + j < S) { a += ta[j]; b += tb[j]; }
+        };
+        if (S <= 2) sum_slabs(std::integral_constant<int, 2>{}, 0);
+        else if (S <= 4) sum_slabs(std::integral_constant<int, 4>{}, 0);
+        else {
+          sum_slabs(std::integral_constant<int, 8>{}, 0);
+          if (S > 8) sum_slabs(std::integral_constant<int, 8>{}, 8);
         }
         xv = u32x4_t{pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(b[0], b[1]), pack_bf2(b[2], b[3])};
       } else {
