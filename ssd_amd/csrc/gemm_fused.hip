@@ -127,7 +127,6 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
   __shared__ int pro_cnt[2];          // EARLY: producer-wave meeting point / "x^ published" (see (c) below)
   if constexpr (EARLY) {
     if (threadIdx.x == 0) { pro_cnt[0] = 0; pro_cnt[1] = 0; }
-    __syncthreads();                  // before any load is issued: every wave is here within a few hundred cycles of the launch
 
     // ---- the latency-ordered front (round 4, from the in-kernel timeline profiles/r04_ktrace_1b_before.txt) ----
     // The kernel is ONE dependency chain: x / slabs -> sum of squares -> x^ -> MFMA -> combine -> epilogue.  Vector-memory
@@ -141,7 +140,7 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
     const int total = M * K8;
     const int c = min((int)threadIdx.x, total - 1);
     const bool act = (int)threadIdx.x < total;
-    const int mm = c / K8, k8 = c % K8;
+    const int mm = M == 1 ? 0 : c / K8, k8 = M == 1 ? c : c % K8;      // (M = 1: no integer division in front of the first load)
     const int mrow = min(mcol, M - 1);
     int64_t pos = 0;
     if (EPI == FEPI_QKV_ROPE) { pos = p.positions[mrow]; pre_slot = p.slots[mrow]; }
@@ -172,6 +171,13 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
         e_h = *reinterpret_cast<const u32x4_t*>(p.h + (size_t)mm * K + k8 * 8);
       }
     }
+    // ONE workgroup barrier, here: (i) the LDS counters are zeroed; (ii) no wave of this workgroup has issued a weight load yet.
+    // A CU's vector-memory path returns in order across its waves: x loads issued behind the other waves' weight loads (the
+    // producers reach their first load ~1 us later than the waves that skip the address arithmetic above) came back only as the
+    // weight stream drained -- x "arrived" at +10.5 us of an 18 us kernel whatever the program order inside the producer wave
+    // (profiles/r04_ktrace_1b_after3.txt).  Holding the weights back until the x loads are in the queue costs the stream ~1 us
+    // and takes the whole prologue off the critical path.
+    __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     // (b) weight group 0: a wave without a group (fewer groups than waves) reads an L2-resident dummy (the norm weight) instead --
     //     an unconditional load either way
