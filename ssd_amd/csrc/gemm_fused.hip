@@ -179,17 +179,19 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
     // and takes the whole prologue off the critical path.
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    // (b) weight group 0: a wave without a group (fewer groups than waves) reads an L2-resident dummy (the norm weight) instead --
-    //     an unconditional load either way
-    {
-      const bool have = nmain > 0;
-      const u32x4_t* base = have ? wp + ((size_t)kt0 << 6) : reinterpret_cast<const u32x4_t*>(p.norm_w) + (lane & 3);
-      const size_t s_nt = have ? wstride : 0, s_u = have ? 64 : 0;
+    // (b) weight group 0 -- the CONSUMER waves now, the producers after they have published x^: a wave's loads issue in order and
+    //     the issue itself blocks while the CU's memory pipeline is backed up with the stream (a producer that queued its own 8
+    //     weight tiles first got to its prologue at +6.5 us, profiles/r04_ktrace_1b_after4.txt)
+    const int nwa = (total + 63) >> 6;
+    auto load_g0 = [&]() {
+      if (nmain > 0) {
 #pragma unroll
-      for (int u = 0; u < U; ++u)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wa[0][u][nt] = __builtin_nontemporal_load(base + nt * s_nt + u * s_u);
-    }
+          for (int nt = 0; nt < NT; ++nt) wa[0][u][nt] = __builtin_nontemporal_load(wp + nt * wstride + ((size_t)(kt0 + u) << 6));
+      }
+    };
+    if (wave >= nwa) load_g0();
     __builtin_amdgcn_sched_barrier(0);
     // the x registers become "known" only here: the compiler can neither sink their first use into the load blocks above (it did:
     // a wait for slab 0 in front of the weight loads) nor move a weight load below this point; the wait it inserts for them here
@@ -205,7 +207,6 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
     //     with a second one, and every wave polls that one right before its first MFMA.  No fences: LDS operations of one wave
     //     execute in order (data before counter on the writer side, counter before data on the reader side) and a workgroup-scope
     //     release would drain the wave's weight loads (s_waitcnt vmcnt(0)); the asm statements only stop the COMPILER reordering.
-    const int nwa = (total + 63) >> 6;
     if (wave < nwa) {
       float x32[8];
       {
@@ -271,6 +272,7 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
       }
       asm volatile("" ::: "memory");
       if (lane == 0) __hip_atomic_fetch_add(&pro_cnt[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      load_g0();
     }
     // (d) cos / sin of this wave's epilogue row group (`pos` is older than the weights: an exact wait), then the second weight group
     //     of waves that have one
