@@ -122,26 +122,6 @@ static inline void ssd_pick_skinny_cfg(int groups, int KT, bool silu_pairs, int*
   *nt = n; *waves = w; *tpw = t;
 }
 
-// Sum of the per-wave partial tiles p[w * stride] (w < nw <= 16) in wave order -- the fixed-order split-K combine of every
-// skinny kernel.  Written as "all LDS reads first, then the adds" (a rolled `for w < nw: s += p[w]` compiles to ds_read ->
-// s_waitcnt -> v_add per wave: sixteen exposed LDS latencies, ~0.5 us of a 4-8 us kernel, profiles/r04_ktrace_1b_before.txt).
-// Slots past nw re-read the last valid tile and are not added: same additions in the same order as the loop, bit-identical.
-__device__ __forceinline__ f32x4_t lds_sum_waves(const f32x4_t* p, int stride, int nw) {
-  f32x4_t s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int w0 = 0; w0 < 16; w0 += 8) {          // two batches of eight reads (32 VGPRs of temporaries, not 64)
-    if (w0 < nw) {
-      f32x4_t t[8];
-#pragma unroll
-      for (int w = 0; w < 8; ++w) t[w] = p[min(w0 + w, nw - 1) * stride];
-#pragma unroll
-      for (int w = 0; w < 8; ++w)
-        if (w0 + w < nw) s += t[w];
-    }
-  }
-  return s;
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // In-kernel timeline (profiling builds only: `make trace` -> _lib/libssdhip_trace.so with -DSSD_KTRACE; the product library
 // contains none of it).  KTRACE(slot, i): thread 0 of every workgroup stores the chip-wide 100 MHz clock (s_memrealtime) into

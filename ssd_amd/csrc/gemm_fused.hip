@@ -120,184 +120,15 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
   const int kt0 = wave * U;
   const int ngroups = KT / U;
   const int nmain = ngroups > wave ? (ngroups - wave + nw - 1) / nw : 0;   // groups of this wave
-  float pre_cs[8];
-  int pre_slot = -1;
-  bool pre_ok = false;
-  constexpr bool EARLY = XNORM && FUSED_MAXC == 1;      // single-token draft decode: M * K / 8 chunks fit the workgroup's threads
-  __shared__ int pro_cnt[2];          // EARLY: producer-wave meeting point / "x^ published" (see (c) below)
-  if constexpr (EARLY) {
-    if (threadIdx.x == 0) { pro_cnt[0] = 0; pro_cnt[1] = 0; }
-
-    // ---- the latency-ordered front (round 4, from the in-kernel timeline profiles/r04_ktrace_1b_before.txt) ----
-    // The kernel is ONE dependency chain: x / slabs -> sum of squares -> x^ -> MFMA -> combine -> epilogue.  Vector-memory
-    // returns are counted in order (vmcnt), so the head of that chain must be the OLDEST loads in flight: issued behind the
-    // weight tiles (as until round 3) the prologue's first wait was a wait for the weights' HBM round trip as well, and the
-    // RoPE operands' positions -> cos / sin chain in front of it cost another round trip (x^ ready at +5.5 us; with 512
-    // workgroups queueing 67 MB of gate_up weights first, at +13.9 us).  Order now: [positions, slots] [residual, norm weight,
-    // S slabs] [weight group 0], all of them unconditional (clamped indices, pointer select) so that every wait is an exact
-    // vmcnt(n > 0); cos / sin are fetched after the prologue, behind the weights, and land during the MFMAs.
-    float* ssbuf = reinterpret_cast<float*>(smem);
-    const int total = M * K8;
-    const int c = min((int)threadIdx.x, total - 1);
-    const bool act = (int)threadIdx.x < total;
-    const int mm = M == 1 ? 0 : c / K8, k8 = M == 1 ? c : c % K8;      // (M = 1: no integer division in front of the first load)
-    const int mrow = min(mcol, M - 1);
-    int64_t pos = 0;
-    if (EPI == FEPI_QKV_ROPE) { pos = p.positions[mrow]; pre_slot = p.slots[mrow]; }
-    // (a) x = h + res, norm weight: only the lanes that own a chunk load (M = 1: 4 of the 16 waves; the first version of this
-    //     front had every lane issue clamped copies -- 16 slab loads x 1024 threads in front of the weights made the kernel
-    //     SLOWER, profiles/r04_ktrace_1b_after_v1.txt).  These loads are OLDER than the weight loads, so conditions around them
-    //     cost the later waits nothing (a wait for an old load only counts the loads guaranteed to be younger).
-    const u32x4_t zero4 = {0u, 0u, 0u, 0u};
-    const f32x4_t zerof = {0.f, 0.f, 0.f, 0.f};
-    u32x4_t e_w = zero4, e_res = zero4, e_h = zero4;
-    f32x4_t e_lo[8], e_hi[8];
-#pragma unroll
-    for (int sidx = 0; sidx < 8; ++sidx) { e_lo[sidx] = zerof; e_hi[sidx] = zerof; }
-    const int nslab = p.h_parts ? p.S : 0;
-    const float* hp = p.h_parts + (size_t)mm * K + k8 * 8;
-    const size_t slab_stride = (size_t)M * K;
-    if (act) {
-      e_w = *reinterpret_cast<const u32x4_t*>(p.norm_w + k8 * 8);
-      if (p.res_in) e_res = *reinterpret_cast<const u32x4_t*>(p.res_in + (size_t)mm * K + k8 * 8);
-      if (p.h_parts) {
-#pragma unroll
-        for (int sidx = 0; sidx < 8; ++sidx)
-          if (sidx < nslab) {
-            e_lo[sidx] = *reinterpret_cast<const f32x4_t*>(hp + sidx * slab_stride);
-            e_hi[sidx] = *reinterpret_cast<const f32x4_t*>(hp + sidx * slab_stride + 4);
-          }
-      } else {
-        e_h = *reinterpret_cast<const u32x4_t*>(p.h + (size_t)mm * K + k8 * 8);
-      }
-    }
-    // ONE workgroup barrier, here: (i) the LDS counters are zeroed; (ii) no wave of this workgroup has issued a weight load yet.
-    // A CU's vector-memory path returns in order across its waves: x loads issued behind the other waves' weight loads (the
-    // producers reach their first load ~1 us later than the waves that skip the address arithmetic above) came back only as the
-    // weight stream drained -- x "arrived" at +10.5 us of an 18 us kernel whatever the program order inside the producer wave
-    // (profiles/r04_ktrace_1b_after3.txt).  Holding the weights back until the x loads are in the queue costs the stream ~1 us
-    // and takes the whole prologue off the critical path.
-    __syncthreads();
-    __builtin_amdgcn_sched_barrier(0);
-    // (b) weight group 0 -- the CONSUMER waves now, the producers after they have published x^: a wave's loads issue in order and
-    //     the issue itself blocks while the CU's memory pipeline is backed up with the stream (a producer that queued its own 8
-    //     weight tiles first got to its prologue at +6.5 us, profiles/r04_ktrace_1b_after4.txt)
-    const int nwa = (total + 63) >> 6;
-    auto load_g0 = [&]() {
-      if (nmain > 0) {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) wa[0][u][nt] = __builtin_nontemporal_load(wp + nt * wstride + ((size_t)(kt0 + u) << 6));
-      }
-    };
-    if (wave >= nwa) load_g0();
-    __builtin_amdgcn_sched_barrier(0);
-    // the x registers become "known" only here: the compiler can neither sink their first use into the load blocks above (it did:
-    // a wait for slab 0 in front of the weight loads) nor move a weight load below this point; the wait it inserts for them here
-    // is an exact vmcnt(weight loads)
-#pragma unroll
-    for (int sidx = 0; sidx < 8; ++sidx) asm volatile("" : "+v"(e_lo[sidx]), "+v"(e_hi[sidx]) : : "memory");
-    asm volatile("" : "+v"(e_w), "+v"(e_res), "+v"(e_h) : : "memory");
-    KTRACE(KTS, 1);
-    // (c) the prologue proper, by the PRODUCER waves only (the nwa waves whose lanes own a chunk; M = 1: 4 of 16) and without a
-    //     workgroup barrier: a barrier is reached by a wave only after it has ISSUED its weight loads, and with 512 workgroups
-    //     queueing 67 MB that is +8 us -- x^ was ready at +13.9 us although its inputs had long arrived, and the MFMAs of every
-    //     wave waited for it (profiles/r04_ktrace_1b_before.txt / _after2.txt).  The producers meet on an LDS counter, publish x^
-    //     with a second one, and every wave polls that one right before its first MFMA.  No fences: LDS operations of one wave
-    //     execute in order (data before counter on the writer side, counter before data on the reader side) and a workgroup-scope
-    //     release would drain the wave's weight loads (s_waitcnt vmcnt(0)); the asm statements only stop the COMPILER reordering.
-    if (wave < nwa) {
-      float x32[8];
-      {
-        float hf[8];
-        f32x4_t lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
-#pragma unroll
-        for (int sidx = 0; sidx < 8; ++sidx)
-          if (sidx < nslab) { lo += e_lo[sidx]; hi += e_hi[sidx]; }
-        for (int sidx = 8; sidx < nslab; ++sidx) {          // (more than 8 slabs: not a shape the engine produces)
-          const float* src = hp + (size_t)sidx * slab_stride;
-          lo += *reinterpret_cast<const f32x4_t*>(src);
-          hi += *reinterpret_cast<const f32x4_t*>(src + 4);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          hf[j] = p.h_parts ? round_bf(lo[j]) : bf2f(e_h[j >> 1] >> ((j & 1) * 16) & 0xffffu);
-          hf[4 + j] = p.h_parts ? round_bf(hi[j]) : bf2f(e_h[2 + (j >> 1)] >> ((j & 1) * 16) & 0xffffu);
-        }
-        const u32x4_t rv = p.res_in ? e_res : u32x4_t{0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          x32[2 * j] = hf[2 * j] + bf2f(rv[j] & 0xffffu);
-          x32[2 * j + 1] = hf[2 * j + 1] + bf2f(rv[j] >> 16);
-        }
-      }
-      const int cpb = (K8 + gridDim.x - 1) / gridDim.x;              // residual: workgroup b owns chunk columns [b*cpb, (b+1)*cpb)
-      if (act) {
-        float ss = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { ss += x32[2 * j] * x32[2 * j]; ss += x32[2 * j + 1] * x32[2 * j + 1]; }
-        ssbuf[c] = ss;
-        if (p.res_out && k8 / cpb == (int)blockIdx.x) {
-          u32x4_t o;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = pack_bf2(x32[2 * j], x32[2 * j + 1]);
-          *reinterpret_cast<u32x4_t*>(p.res_out + (size_t)mm * K + k8 * 8) = o;
-        }
-      }
-      asm volatile("" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(&pro_cnt[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      while (__hip_atomic_load(&pro_cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < nwa) __builtin_amdgcn_s_sleep(1);
-      asm volatile("" ::: "memory");
-      KTRACE(KTS, 2);
-      // every producer wave reduces the chunk sums of all M rows itself (same order as ssd_rmsnorm: lane-strided partials, then
-      // the xor tree) and keeps rs in its own LDS row
-      float* rsbuf = ssbuf + total + wave * 16;           // behind the chunk sums
-      for (int m2 = 0; m2 < M; ++m2) {
-        float t = 0.f;
-        for (int cc = lane; cc < K8; cc += 64) t += ssbuf[m2 * K8 + cc];
-        t = wave_sum(t);
-        if (lane == 0) rsbuf[m2] = 1.0f / sqrtf(t / (float)K + p.eps);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (act) {
-        const float rs = rsbuf[mm];
-        u32x4_t o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          o[j] = pack_bf2((x32[2 * j] * rs) * bf2f(e_w[j] & 0xffffu), (x32[2 * j + 1] * rs) * bf2f(e_w[j] >> 16));
-        xlds[k8 * M + mm] = o;
-      }
-      asm volatile("" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(&pro_cnt[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      load_g0();
-    }
-    // (d) cos / sin of this wave's epilogue row group (`pos` is older than the weights: an exact wait), then the second weight group
-    //     of waves that have one
-    if (EPI == FEPI_QKV_ROPE) {
-      const int gph = p.hd >> 4;
-      const int grp = min(tile0 + min(wave, NT - 1), (p.nh + p.nkv) * gph - 1);
-      const int d = (grp % gph) * 8 + (q4 & 1) * 4;
-      const float* cs = p.cos_sin + (size_t)pos * p.hd;
-      const f32x4_t c4 = *reinterpret_cast<const f32x4_t*>(cs + d), s4 = *reinterpret_cast<const f32x4_t*>(cs + (p.hd >> 1) + d);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { pre_cs[r] = c4[r]; pre_cs[4 + r] = s4[r]; }
-      pre_ok = wave < NT && mcol < M;
-    }
-    if (nmain > 1) loadw(1, kt0 + kstep);
-    // (e) every wave: x^ published?  (an LDS poll; the producers are long done by the time a consumer's weights arrive)
-    while (__hip_atomic_load(&pro_cnt[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < nwa) __builtin_amdgcn_s_sleep(1);
-    asm volatile("" ::: "memory");
-    KTRACE(KTS, 3);
-  } else {
   // the first TWO groups of weight tiles fly while the norm prologue runs (for the 1B draft that is the whole K range:
   // one HBM round trip per wave; a kernel this short is a latency chain)
   if (nmain > 0) loadw(0, kt0);
   if (nmain > 1) loadw(1, kt0 + kstep);
   // RoPE epilogue operands of the wave that will own row group `wave` (positions -> cos/sin rows -> slot: a chain of
   // dependent L2 round trips if left to the epilogue), fetched now, behind the weight stream
+  float pre_cs[8];
+  int pre_slot = -1;
+  bool pre_ok = false;
   if (EPI == FEPI_QKV_ROPE && wave < NT && mcol < M) {
     const int grp = tile0 + wave;
     const int gph = p.hd >> 4;
@@ -402,8 +233,6 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
     KTRACE(KTS, 3);
   }
 
-  }
-
   auto xfrag = [&](int buf, int u, int kt) -> u32x4_t {
     if (!XNORM) return xg[buf][u];
     u32x4_t o = {0u, 0u, 0u, 0u};
@@ -454,8 +283,11 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
     const int KT2 = (p.N >> 1) >> 5;
     u32x2_t* out = reinterpret_cast<u32x2_t*>(p.y);
     for (int pr = wave; pr < PAIRS; pr += nw) {
-      const f32x4_t g = lds_sum_waves(cred + (2 * pr) * 64 + lane, NT * 64, nw);
-      const f32x4_t u = lds_sum_waves(cred + (2 * pr + 1) * 64 + lane, NT * 64, nw);
+      f32x4_t g = f32x4_t{0.f, 0.f, 0.f, 0.f}, u = g;
+      for (int w = 0; w < nw; ++w) {
+        g += cred[(w * NT + 2 * pr) * 64 + lane];
+        u += cred[(w * NT + 2 * pr + 1) * 64 + lane];
+      }
       const int n = ((tile0 >> 1) + pr) * 16 + nrow;
       float o[4];
 #pragma unroll
@@ -470,7 +302,8 @@ __global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
     }
   } else {
     for (int nt = wave; nt < NT; nt += nw) {
-      f32x4_t s = lds_sum_waves(cred + nt * 64 + lane, NT * 64, nw);
+      f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int w = 0; w < nw; ++w) s += cred[(w * NT + nt) * 64 + lane];
       const int grp = tile0 + nt;
       if (p.bias) {
 #pragma unroll
@@ -621,7 +454,8 @@ __global__ void __launch_bounds__(1024) gemm_qkv_rope_m32_kernel(const FusedPara
   const int gph = p.hd >> 4, qk_groups = (p.nh + p.nkv) * gph, half = p.hd >> 1;
   for (int item = wave; item < NT * MT; item += nw) {
     const int nt = item / MT, mt = item % MT;
-    f32x4_t s = lds_sum_waves(cred + item * 64 + lane, NT * MT * 64, nw);
+    f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int w = 0; w < nw; ++w) s += cred[(w * NT * MT + item) * 64 + lane];
     const int grp = tile0 + nt;
     const int m = mt * 16 + mcol;
     if (p.bias) {

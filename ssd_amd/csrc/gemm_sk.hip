@@ -165,7 +165,8 @@ gemm_sp_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, c
   KTRACE(KTS, 3);
   if (wave >= MT) return;                                  // wave mt finishes m-tile mt
   const int mt = wave;
-  f32x4_t s = lds_sum_waves(red + mt * 64 + lane, MT * 64, nw);
+  f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+  for (int w = 0; w < nw; ++w) s += red[(w * MT + mt) * 64 + lane];
   const int m = mt * 16 + (lane & 15), n = g * 16 + (lane >> 4) * 4;
   if (m >= M) return;
   if (P) {
