@@ -474,6 +474,16 @@ def run(args, guard, rank, world):
     # -- what a serving process sees for its recurring prompt shapes -- starts with the third sample
     kept = ttfts[2:] if len(ttfts) > 2 else ttfts[-1:]
     ttft_p50 = statistics.median(kept)
+    # what a server with free-form prompt lengths sees: a shape on first sight runs eagerly (no graph yet).  Sample 0 above also
+    # carries one-time costs of the process (first use of every kernel, allocator growth), so a FRESH shape is timed now that the
+    # process is warm: a prompt one token shorter than any seen so far.
+    guard.stage("ttft_first_sighting")
+    first = []
+    sync_all()
+    t0 = time.perf_counter()
+    engine.generate([prompt[:-1]], SamplingParams(temperature=0, ignore_eos=True, max_new_tokens=1), use_tqdm=False,
+                    stream_callback=lambda sid, toks: first.append(time.perf_counter()) if not first else None)
+    ttft_first_sighting = (first[0] - t0) * 1e3
     ttft_round_p50 = statistics.median(ttfts_round[2:] if len(ttfts_round) > 2 else ttfts_round[-1:])
 
     # ---- timed decode steps through the real engine ----
@@ -589,11 +599,15 @@ def run(args, guard, rank, world):
         # prefill's token when the prefill returns; the reference's loop (and this repo until round 2) streams it one speculation
         # round later -- that figure is kept beside it
         "ttft_after_first_round_p50_ms": round(ttft_round_p50, 3),
+        # eager prefill of a prompt length met for the first time (warm process); `ttft_cold_process_ms` = the very first request
+        "ttft_first_sighting_ms": round(ttft_first_sighting, 3), "ttft_cold_process_ms": round(ttfts[0], 3),
         # the reference's own protocol (2 x 128 -> 512 tokens, prefill included, context -> 640): THE tokens/s to quote
         "value_reference_protocol": None if ref is None else ref["tokens_per_s_total"],
         "draft_forwards_per_step": round(draft_fwd, 3),
         "step_hbm_bytes_per_gpu": int(step_bytes),
         "step_roofline_frac": round(step_bytes / (dt / args.steps) / HBM_PEAK, 4),
+        # the same without the bytes of the co-located draft: target weights + target KV only (what a dedicated-draft layout streams)
+        "step_roofline_frac_target_only": round((tb + ctx * kv_tok(tm)) / (dt / args.steps) / HBM_PEAK, 4),
         "tokens_per_s_at_accepted_len": {str(a): round(a / (dt / args.steps), 1) for a in (1, 2, 4, K + 1)},
         "reference_protocol": ref,
     }

@@ -286,6 +286,18 @@ int ssd_allreduce_add_rmsnorm_bf16(const void* in, const void* res_in, void* res
                                    void* const* flags, long slot_elems, void* counters, void* err, long spin_budget,
                                    void* stream);
 
+/* The same two collectives over DATA-TAGGED GRANULES (round 4; csrc/comm.hip): every rank pushes its values into each peer's
+ * inbox as 8-byte {2 x bf16, epoch} words -- one write-through store each, single-copy atomic -- and polls its OWN inbox: one
+ * hop, no drain / flag / remote read, no ordering between separate payload and flag stores to rely on.  2x the wire bytes, so
+ * for messages up to 64 Ki elements (every decode / verify sum of the tensor-parallel target); larger ones use the calls above.
+ * inboxes[r] = rank r's inbox (2 * 8 * gr_cap granules, zeroed); counters / err are the SAME as in the calls above -- the two
+ * protocols share one epoch and may be interleaved.  Replace ssd/layers/linear.py:195-199 (+ layernorm.py:76-88) like them. */
+int ssd_allreduce_gr_bf16(const void* in, void* out, long n, int rank, int world, void* const* inboxes, long gr_cap,
+                          void* counters, void* err, long spin_budget, void* stream);
+int ssd_allreduce_add_rmsnorm_gr_bf16(const void* in, const void* res_in, void* res_out, const void* weight, float eps,
+                                      void* out_rows, void* out_frag, int T, int H, int rank, int world, void* const* inboxes,
+                                      long gr_cap, void* counters, void* err, long spin_budget, void* stream);
+
 /* A stream restricted to the compute units whose bit is set in cu_mask (bit i of word i/32 = CU i): partitions the chip
  * between the co-located draft server and the target's verify of asynchronous speculation (the reference gives the draft
  * a GPU of its own, ssd/engine/llm_engine.py:82-89; on one GPU the two rounds otherwise serialise).  Start-up only. */

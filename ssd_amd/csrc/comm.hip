@@ -23,6 +23,7 @@
 // A spin that exceeds its budget sets an error word instead of hanging; the caller then falls back to RCCL.
 #include "common.h"
 #include <cstring>
+#include <cstdlib>
 
 constexpr int AR_MAX_RANKS = 8;
 constexpr int AR_BLOCKS = 8;
@@ -48,15 +49,22 @@ __device__ __forceinline__ unsigned long long ld_sys64(const unsigned long long*
 // No release fence (an L2 write-back of everything the preceding GEMM left dirty) and no acquire fence (an L2 invalidate
 // that the NEXT GEMM would pay for): measured on MI355X with the TP = 4 shard shapes, the fused all-reduce + norm launch
 // went from 7.6 us to the figure in profiles/r03_tp_shard_per_kind.txt.
-__device__ __forceinline__ void ar_publish_barrier() {
+__device__ __forceinline__ void ar_publish_barrier(int fences) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // SSD_AR_FENCES=1: the belt-and-braces form -- a system-scope release before the flag stores and an acquire after
+  // the poll, as until round 2 -- for a platform where the drained write-through stores above should prove insufficient
+  if (fences) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   __syncthreads();
+}
+static int ar_fences() {
+  static const int v = [] { const char* e = getenv("SSD_AR_FENCES"); return (e && e[0] == '1') ? 1 : 0; }();
+  return v;
 }
 
 __global__ void __launch_bounds__(AR_THREADS)
 allreduce_bf16_kernel(const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out, long n8,
                       long slot_words, ArPeers peers, int rank, int world, unsigned int* __restrict__ counters,
-                      unsigned int* __restrict__ err, long spin_budget, int gather) {
+                      unsigned int* __restrict__ err, long spin_budget, int gather, int fences) {
   __shared__ unsigned int s_epoch;
   __shared__ int s_fail;
   const int blk = blockIdx.x;
@@ -67,7 +75,7 @@ allreduce_bf16_kernel(const unsigned long long* __restrict__ in, unsigned long l
   const long i0 = blk * per, i1 = min(n8, i0 + per);
   unsigned long long* my = peers.slot[rank] + (long)(epoch & 1u) * slot_words;
   for (long i = i0 + threadIdx.x; i < i1; i += AR_THREADS) st_sys64(my + i, in[i]);
-  ar_publish_barrier();
+  ar_publish_barrier(fences);
   if (threadIdx.x < world) {
     const int peer = threadIdx.x;
     __hip_atomic_store(peers.flags[peer] + blk * AR_MAX_RANKS + rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -81,9 +89,10 @@ allreduce_bf16_kernel(const unsigned long long* __restrict__ in, unsigned long l
       if (++spins > spin_budget) { s_fail = 1; break; }
     }
   }
+  if (fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   __syncthreads();
   if (threadIdx.x == 0) {
-    counters[blk] = epoch;           // (no acquire fence: every staged word is read with a system-scope load, see ar_publish_barrier)
+    counters[blk] = epoch;           // (default: no acquire fence -- every staged word is read with a system-scope load, see ar_publish_barrier)
     if (s_fail) atomicExch(err, 1u);
   }
   __syncthreads();
@@ -94,12 +103,18 @@ allreduce_bf16_kernel(const unsigned long long* __restrict__ in, unsigned long l
     return;
   }
   for (long i = i0 + threadIdx.x; i < i1; i += AR_THREADS) {
+    // every rank's word is requested before the first add (a rolled loop is load -> wait -> add per rank: `world` dependent
+    // remote round trips); ranks past `world` re-read the last one and are not added -- same sum, same (rank) order
+    unsigned long long v[AR_MAX_RANKS];
+#pragma unroll
+    for (int r = 0; r < AR_MAX_RANKS; ++r) v[r] = ld_sys64(peers.slot[min(r, world - 1)] + (long)(epoch & 1u) * slot_words + i);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (int r = 0; r < world; ++r) {
-      const unsigned long long v = ld_sys64(peers.slot[r] + (long)(epoch & 1u) * slot_words + i);
-      a0 += bf2f((unsigned)(v & 0xffffu)); a1 += bf2f((unsigned)((v >> 16) & 0xffffu));
-      a2 += bf2f((unsigned)((v >> 32) & 0xffffu)); a3 += bf2f((unsigned)(v >> 48));
-    }
+#pragma unroll
+    for (int r = 0; r < AR_MAX_RANKS; ++r)
+      if (r < world) {
+        a0 += bf2f((unsigned)(v[r] & 0xffffu)); a1 += bf2f((unsigned)((v[r] >> 16) & 0xffffu));
+        a2 += bf2f((unsigned)((v[r] >> 32) & 0xffffu)); a3 += bf2f((unsigned)(v[r] >> 48));
+      }
     out[i] = (unsigned long long)pack_bf2(a0, a1) | ((unsigned long long)pack_bf2(a2, a3) << 32);
   }
 }
@@ -117,7 +132,7 @@ allreduce_add_rmsnorm_kernel(const unsigned long long* __restrict__ in, const u3
                              u32x4_t* __restrict__ res_out, const u32x4_t* __restrict__ w, float eps,
                              u32x4_t* __restrict__ out_rows, u32x4_t* __restrict__ out_frag, int T, int H,
                              long slot_words, ArPeers peers, int rank, int world, unsigned int* __restrict__ counters,
-                             unsigned int* __restrict__ err, long spin_budget) {
+                             unsigned int* __restrict__ err, long spin_budget, int fences) {
   __shared__ unsigned int s_epoch;
   __shared__ int s_fail;
   __shared__ float red[ARN_THREADS / 64];
@@ -131,7 +146,7 @@ allreduce_add_rmsnorm_kernel(const unsigned long long* __restrict__ in, const u3
   const long hw = H >> 2;                       // 8-byte words per row
   unsigned long long* my = peers.slot[rank] + (long)(epoch & 1u) * slot_words;
   for (long i = (long)r0 * hw + threadIdx.x; i < (long)r1 * hw; i += ARN_THREADS) st_sys64(my + i, in[i]);
-  ar_publish_barrier();
+  ar_publish_barrier(fences);
   if (threadIdx.x < world) {
     const int peer = threadIdx.x;
     __hip_atomic_store(peers.flags[peer] + blk * AR_MAX_RANKS + rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -142,6 +157,7 @@ allreduce_add_rmsnorm_kernel(const unsigned long long* __restrict__ in, const u3
       if (++spins > spin_budget) { s_fail = 1; break; }
     }
   }
+  if (fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   __syncthreads();
   if (threadIdx.x == 0) {
     counters[blk] = epoch;
@@ -158,15 +174,21 @@ allreduce_add_rmsnorm_kernel(const unsigned long long* __restrict__ in, const u3
       const int c = threadIdx.x + i * ARN_THREADS;
       if (c < H8) {
         float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int r = 0; r < world; ++r) {
-          const unsigned long long* sp = peers.slot[r] + (long)(epoch & 1u) * slot_words + (long)row * hw + 2 * c;
-          const unsigned long long v0 = ld_sys64(sp), v1 = ld_sys64(sp + 1);
-          a[0] += bf2f((unsigned)(v0 & 0xffffu)); a[1] += bf2f((unsigned)((v0 >> 16) & 0xffffu));
-          a[2] += bf2f((unsigned)((v0 >> 32) & 0xffffu)); a[3] += bf2f((unsigned)(v0 >> 48));
-          a[4] += bf2f((unsigned)(v1 & 0xffffu)); a[5] += bf2f((unsigned)((v1 >> 16) & 0xffffu));
-          a[6] += bf2f((unsigned)((v1 >> 32) & 0xffffu)); a[7] += bf2f((unsigned)(v1 >> 48));
+        unsigned long long v0[AR_MAX_RANKS], v1[AR_MAX_RANKS];      // all ranks' words in flight at once (see allreduce_bf16_kernel)
+#pragma unroll
+        for (int r = 0; r < AR_MAX_RANKS; ++r) {
+          const unsigned long long* sp = peers.slot[min(r, world - 1)] + (long)(epoch & 1u) * slot_words + (long)row * hw + 2 * c;
+          v0[r] = ld_sys64(sp); v1[r] = ld_sys64(sp + 1);
         }
         const u32x4_t rv = res_in[(size_t)row * H8 + c];
+#pragma unroll
+        for (int r = 0; r < AR_MAX_RANKS; ++r)
+          if (r < world) {
+            a[0] += bf2f((unsigned)(v0[r] & 0xffffu)); a[1] += bf2f((unsigned)((v0[r] >> 16) & 0xffffu));
+            a[2] += bf2f((unsigned)((v0[r] >> 32) & 0xffffu)); a[3] += bf2f((unsigned)(v0[r] >> 48));
+            a[4] += bf2f((unsigned)(v1[r] & 0xffffu)); a[5] += bf2f((unsigned)((v1[r] >> 16) & 0xffffu));
+            a[6] += bf2f((unsigned)((v1[r] >> 32) & 0xffffu)); a[7] += bf2f((unsigned)(v1[r] >> 48));
+          }
         u32x4_t ro;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -204,6 +226,230 @@ allreduce_add_rmsnorm_kernel(const unsigned long long* __restrict__ in, const u3
         if (out_frag) out_frag[frag_chunk(row, c, KT)] = o;
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Data-tagged granules (round 4): the same collectives with ONE hop instead of three dependent ones.
+//
+// The protocol above is stage -> drain -> flag -> (peer) poll -> remote READ: three dependent uncached trips before a byte of
+// the sum exists, and its correctness rests on "all my payload stores completed before my flag store is issued".  Here every
+// rank PUSHES its values into each peer's inbox as naturally aligned 8-byte granules {2 bf16 payload, 32-bit epoch tag} with
+// one write-through store each, and then polls ITS OWN inbox (local reads) until every granule it needs carries this call's
+// epoch.  An 8-byte store is single-copy atomic, so a reader sees a granule whole or not at all: there is no ordering
+// between separate payload and flag stores to get right, no drain, no fence, no remote read round trip -- the guide's
+// handoff-1to1 primitive (MI355X_MICROARCH.md: 0.8-1.0 us idle per hop against 1.7-2.5x for payload + flag).  Cost: 2x the
+// bytes on the wire (a [8, 8192] bf16 message is 256 KiB per peer instead of 128), which is why messages above GR_MAX_ELEMS
+// keep the flag protocol.  Epochs, counters, launch width and the double-buffering argument are those of the flag protocol
+// (a rank overwrites the parity-e inbox regions at call e + 2, by which time every peer has retired call e): the two
+// protocols may be interleaved freely.  inbox[r] = rank r's inbox: [2 parities][AR_MAX_RANKS sources][gr_cap granules].
+// ---------------------------------------------------------------------------------------------------------------------
+struct GrPeers {
+  unsigned long long* inbox[AR_MAX_RANKS];
+};
+
+__device__ __forceinline__ unsigned long long gr_make(unsigned int payload, unsigned int epoch) {
+  return (unsigned long long)payload | ((unsigned long long)epoch << 32);
+}
+
+// poll NG granules of every peer source (own rank skipped) until all carry `epoch`; returns false on a timeout
+template <int NG>
+__device__ __forceinline__ bool gr_collect(const unsigned long long* mybox, long src_stride, long g0, int rank, int world,
+                                           unsigned int epoch, long spin_budget, unsigned long long (&v)[AR_MAX_RANKS][NG]) {
+  long spins = 0;
+  while (true) {
+    bool ok = true;
+#pragma unroll
+    for (int r = 0; r < AR_MAX_RANKS; ++r) {
+      const int rr = min(r, world - 1);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) v[r][g] = ld_sys64(mybox + (long)rr * src_stride + g0 + g);
+    }
+#pragma unroll
+    for (int r = 0; r < AR_MAX_RANKS; ++r)
+      if (r < world && r != rank) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) ok = ok && ((unsigned int)(v[r][g] >> 32) == epoch);
+      }
+    if (ok) return true;
+    if (spins < 4096) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(32);
+    if (++spins > spin_budget) return false;
+  }
+}
+
+__global__ void __launch_bounds__(AR_THREADS)
+allreduce_gr_kernel(const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out, long n8, long gr_cap,
+                    GrPeers peers, int rank, int world, unsigned int* __restrict__ counters, unsigned int* __restrict__ err,
+                    long spin_budget) {
+  __shared__ unsigned int s_epoch;
+  __shared__ int s_fail;
+  const int blk = blockIdx.x;
+  const long per = (n8 + gridDim.x - 1) / gridDim.x;
+  const long i0 = blk * per, i1 = min(n8, i0 + per);
+  // this call's input words are requested before the epoch is known (the counter read is a dependent round trip of its own)
+  constexpr int MAXI = 4;        // words per thread: n8 <= GR_MAX_ELEMS / 4 = 16384 over 8 x 512 threads
+  unsigned long long w[MAXI];
+#pragma unroll
+  for (int k = 0; k < MAXI; ++k) {
+    const long i = i0 + threadIdx.x + (long)k * AR_THREADS;
+    w[k] = i < i1 ? in[i] : 0ull;
+  }
+  if (threadIdx.x == 0) { s_epoch = counters[blk] + 1; s_fail = 0; }
+  __syncthreads();
+  const unsigned int epoch = s_epoch;
+  const long par = (long)(epoch & 1u) * AR_MAX_RANKS * gr_cap;
+#pragma unroll
+  for (int k = 0; k < MAXI; ++k) {
+    const long i = i0 + threadIdx.x + (long)k * AR_THREADS;
+    if (i < i1) {
+      const unsigned long long g_lo = gr_make((unsigned int)w[k], epoch), g_hi = gr_make((unsigned int)(w[k] >> 32), epoch);
+      for (int pr = 0; pr < world; ++pr)
+        if (pr != rank) {
+          unsigned long long* dst = peers.inbox[pr] + par + (long)rank * gr_cap + 2 * i;
+          st_sys64(dst, g_lo);
+          st_sys64(dst + 1, g_hi);
+        }
+    }
+  }
+  const unsigned long long* mybox = peers.inbox[rank] + par;
+  bool fail = false;
+#pragma unroll
+  for (int k = 0; k < MAXI; ++k) {
+    const long i = i0 + threadIdx.x + (long)k * AR_THREADS;
+    if (i < i1 && !fail) {
+      unsigned long long v[AR_MAX_RANKS][2];
+      if (!gr_collect<2>(mybox, gr_cap, 2 * i, rank, world, epoch, spin_budget, v)) { fail = true; break; }
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+      for (int r = 0; r < AR_MAX_RANKS; ++r)
+        if (r < world) {
+          const unsigned int lo = r == rank ? (unsigned int)w[k] : (unsigned int)v[r][0];
+          const unsigned int hi = r == rank ? (unsigned int)(w[k] >> 32) : (unsigned int)v[r][1];
+          a0 += bf2f(lo & 0xffffu); a1 += bf2f(lo >> 16);
+          a2 += bf2f(hi & 0xffffu); a3 += bf2f(hi >> 16);
+        }
+      out[i] = (unsigned long long)pack_bf2(a0, a1) | ((unsigned long long)pack_bf2(a2, a3) << 32);
+    }
+  }
+  if (fail) s_fail = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    counters[blk] = epoch;
+    if (s_fail) atomicExch(err, 1u);
+  }
+}
+
+template <int ARN_THREADS>
+__global__ void __launch_bounds__(ARN_THREADS)
+allreduce_add_rmsnorm_gr_kernel(const unsigned long long* __restrict__ in, const u32x4_t* __restrict__ res_in,
+                                u32x4_t* __restrict__ res_out, const u32x4_t* __restrict__ w, float eps,
+                                u32x4_t* __restrict__ out_rows, u32x4_t* __restrict__ out_frag, int T, int H, long gr_cap,
+                                GrPeers peers, int rank, int world, unsigned int* __restrict__ counters,
+                                unsigned int* __restrict__ err, long spin_budget) {
+  __shared__ unsigned int s_epoch;
+  __shared__ int s_fail;
+  __shared__ float red[ARN_THREADS / 64];
+  const int blk = blockIdx.x;
+  const int rpb = (T + gridDim.x - 1) / gridDim.x;
+  const int r0 = blk * rpb, r1 = min(T, r0 + rpb);
+  const int H8 = H >> 3, KT = H >> 5;
+  const long hw = H >> 2;                       // 8-byte words per row
+  constexpr int ARN_MAXC = ARN_MAXH / 8 / ARN_THREADS;
+  if (threadIdx.x == 0) { s_epoch = counters[blk] + 1; s_fail = 0; }
+  __syncthreads();
+  const unsigned int epoch = s_epoch;
+  const long par = (long)(epoch & 1u) * AR_MAX_RANKS * gr_cap;
+  const unsigned long long* mybox = peers.inbox[rank] + par;
+  // ---- push: every chunk of every row this workgroup owns, to every peer ----
+  for (int row = r0; row < r1; ++row) {
+#pragma unroll
+    for (int i = 0; i < ARN_MAXC; ++i) {
+      const int c = threadIdx.x + i * ARN_THREADS;
+      if (c < H8) {
+        const unsigned long long* src = in + (long)row * hw + 2 * c;
+        const unsigned long long x0 = src[0], x1 = src[1];
+        const unsigned long long g[4] = {gr_make((unsigned int)x0, epoch), gr_make((unsigned int)(x0 >> 32), epoch),
+                                         gr_make((unsigned int)x1, epoch), gr_make((unsigned int)(x1 >> 32), epoch)};
+        for (int pr = 0; pr < world; ++pr)
+          if (pr != rank) {
+            unsigned long long* dst = peers.inbox[pr] + par + (long)rank * gr_cap + ((long)row * H8 + c) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) st_sys64(dst + q, g[q]);
+          }
+      }
+    }
+  }
+  // ---- collect + add + norm, row by row (arithmetic and order of allreduce_add_rmsnorm_kernel) ----
+  bool fail = false;
+  for (int row = r0; row < r1; ++row) {
+    float v[ARN_MAXC][8];
+    u32x4_t wreg[ARN_MAXC];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < ARN_MAXC; ++i) {
+      const int c = threadIdx.x + i * ARN_THREADS;
+      if (c < H8 && !fail) {
+        wreg[i] = w[c];
+        const u32x4_t rv = res_in[(size_t)row * H8 + c];
+        const unsigned long long* src = in + (long)row * hw + 2 * c;
+        const unsigned long long x0 = src[0], x1 = src[1];
+        unsigned long long gv[AR_MAX_RANKS][4];
+        if (!gr_collect<4>(mybox, gr_cap, ((long)row * H8 + c) * 4, rank, world, epoch, spin_budget, gv)) { fail = true; }
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < AR_MAX_RANKS; ++r)
+          if (r < world) {
+            unsigned int u[4];
+            if (r == rank) { u[0] = (unsigned int)x0; u[1] = (unsigned int)(x0 >> 32); u[2] = (unsigned int)x1; u[3] = (unsigned int)(x1 >> 32); }
+            else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) u[q] = (unsigned int)gv[r][q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { a[2 * q] += bf2f(u[q] & 0xffffu); a[2 * q + 1] += bf2f(u[q] >> 16); }
+          }
+        u32x4_t ro;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = round_bf(a[2 * j]) + bf2f(rv[j] & 0xffffu);
+          const float hi = round_bf(a[2 * j + 1]) + bf2f(rv[j] >> 16);
+          v[i][2 * j] = lo; v[i][2 * j + 1] = hi;
+          ro[j] = pack_bf2(lo, hi);
+          ss += lo * lo; ss += hi * hi;
+        }
+        res_out[(size_t)row * H8 + c] = ro;
+      }
+    }
+    ss = wave_sum(ss);
+    __syncthreads();                       // red[] of the previous row has been consumed
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < ARN_THREADS / 64; ++i) tot += red[i];
+    const float rs = 1.0f / sqrtf(tot / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < ARN_MAXC; ++i) {
+      const int c = threadIdx.x + i * ARN_THREADS;
+      if (c < H8) {
+        const u32x4_t wv = wreg[i];
+        u32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = (v[i][2 * j] * rs) * bf2f(wv[j] & 0xffffu);
+          const float hi = (v[i][2 * j + 1] * rs) * bf2f(wv[j] >> 16);
+          o[j] = pack_bf2(lo, hi);
+        }
+        if (out_rows) out_rows[(size_t)row * H8 + c] = o;
+        if (out_frag) out_frag[frag_chunk(row, c, KT)] = o;
+      }
+    }
+  }
+  if (fail) s_fail = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    counters[blk] = epoch;
+    if (s_fail) atomicExch(err, 1u);
   }
 }
 
@@ -249,7 +495,7 @@ extern "C" int ssd_allreduce_bf16(const void* in, void* out, long n, int rank, i
   const long n8 = n / 4;
   hipLaunchKernelGGL(allreduce_bf16_kernel, dim3(AR_BLOCKS), dim3(AR_THREADS), 0, (hipStream_t)stream,
                      (const unsigned long long*)in, (unsigned long long*)out, n8, slot_elems / 4, peers, rank, world,
-                     (unsigned int*)counters, (unsigned int*)err, spin_budget, 0);
+                     (unsigned int*)counters, (unsigned int*)err, spin_budget, 0, ar_fences());
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
@@ -266,7 +512,7 @@ extern "C" int ssd_allgather_u64(const void* in, void* out, long n8, int rank, i
   }
   hipLaunchKernelGGL(allreduce_bf16_kernel, dim3(AR_BLOCKS), dim3(AR_THREADS), 0, (hipStream_t)stream,
                      (const unsigned long long*)in, (unsigned long long*)out, n8, slot_elems / 4, peers, rank, world,
-                     (unsigned int*)counters, (unsigned int*)err, spin_budget, 1);
+                     (unsigned int*)counters, (unsigned int*)err, spin_budget, 1, ar_fences());
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
@@ -291,12 +537,52 @@ extern "C" int ssd_allreduce_add_rmsnorm_bf16(const void* in, const void* res_in
     hipLaunchKernelGGL(allreduce_add_rmsnorm_kernel<1024>, dim3(AR_BLOCKS), dim3(1024), 0, (hipStream_t)stream,
                        (const unsigned long long*)in, (const u32x4_t*)res_in, (u32x4_t*)res_out, (const u32x4_t*)weight, eps,
                        (u32x4_t*)out_rows, (u32x4_t*)out_frag, T, H, slot_elems / 4, peers, rank, world,
-                       (unsigned int*)counters, (unsigned int*)err, spin_budget);
+                       (unsigned int*)counters, (unsigned int*)err, spin_budget, ar_fences());
   } else {
     hipLaunchKernelGGL(allreduce_add_rmsnorm_kernel<256>, dim3(AR_BLOCKS), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned long long*)in, (const u32x4_t*)res_in, (u32x4_t*)res_out, (const u32x4_t*)weight, eps,
                        (u32x4_t*)out_rows, (u32x4_t*)out_frag, T, H, slot_elems / 4, peers, rank, world,
-                       (unsigned int*)counters, (unsigned int*)err, spin_budget);
+                       (unsigned int*)counters, (unsigned int*)err, spin_budget, ar_fences());
+  }
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
+// ---- data-tagged granule variants (see the comment above allreduce_gr_kernel).  inboxes[r] = rank r's inbox (own allocation for
+// `rank`, IPC-opened mappings for the peers): 2 * AR_MAX_RANKS * gr_cap granules of 8 bytes, zero-initialised; gr_cap = granules
+// per (parity, source) region >= n / 2.  counters / err as above (the SAME counters as the flag protocol's calls).
+extern "C" int ssd_allreduce_gr_bf16(const void* in, void* out, long n, int rank, int world, void* const* inboxes, long gr_cap,
+                                     void* counters, void* err, long spin_budget, void* stream) {
+  if (world < 1 || world > AR_MAX_RANKS || rank < 0 || rank >= world || n <= 0 || (n & 3) || n / 2 > gr_cap ||
+      n / 4 > 4L * AR_BLOCKS * AR_THREADS)
+    return SSD_ERR_SHAPE;
+  GrPeers peers;
+  for (int r = 0; r < AR_MAX_RANKS; ++r) peers.inbox[r] = (unsigned long long*)(r < world ? inboxes[r] : nullptr);
+  hipLaunchKernelGGL(allreduce_gr_kernel, dim3(AR_BLOCKS), dim3(AR_THREADS), 0, (hipStream_t)stream,
+                     (const unsigned long long*)in, (unsigned long long*)out, n / 4, gr_cap, peers, rank, world,
+                     (unsigned int*)counters, (unsigned int*)err, spin_budget);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
+extern "C" int ssd_allreduce_add_rmsnorm_gr_bf16(const void* in, const void* res_in, void* res_out, const void* weight, float eps,
+                                                 void* out_rows, void* out_frag, int T, int H, int rank, int world,
+                                                 void* const* inboxes, long gr_cap, void* counters, void* err, long spin_budget,
+                                                 void* stream) {
+  if (world < 1 || world > AR_MAX_RANKS || rank < 0 || rank >= world || T <= 0 || H <= 0 || (H & 31) || H > ARN_MAXH ||
+      (long)T * H / 2 > gr_cap)
+    return SSD_ERR_SHAPE;
+  if (!in || !res_in || !res_out || !weight) return SSD_ERR_ARG;
+  GrPeers peers;
+  for (int r = 0; r < AR_MAX_RANKS; ++r) peers.inbox[r] = (unsigned long long*)(r < world ? inboxes[r] : nullptr);
+  if (ssd_norm_threads(H) == 1024) {
+    hipLaunchKernelGGL(allreduce_add_rmsnorm_gr_kernel<1024>, dim3(AR_BLOCKS), dim3(1024), 0, (hipStream_t)stream,
+                       (const unsigned long long*)in, (const u32x4_t*)res_in, (u32x4_t*)res_out, (const u32x4_t*)weight, eps,
+                       (u32x4_t*)out_rows, (u32x4_t*)out_frag, T, H, gr_cap, peers, rank, world, (unsigned int*)counters,
+                       (unsigned int*)err, spin_budget);
+  } else {
+    hipLaunchKernelGGL(allreduce_add_rmsnorm_gr_kernel<256>, dim3(AR_BLOCKS), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned long long*)in, (const u32x4_t*)res_in, (u32x4_t*)res_out, (const u32x4_t*)weight, eps,
+                       (u32x4_t*)out_rows, (u32x4_t*)out_frag, T, H, gr_cap, peers, rank, world, (unsigned int*)counters,
+                       (unsigned int*)err, spin_budget);
   }
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }

@@ -70,6 +70,9 @@ SIGNATURES = {
                           c_void_p, c_void_p, c_long, c_void_p],
     "ssd_allreduce_add_rmsnorm_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                        C.POINTER(c_void_p), C.POINTER(c_void_p), c_long, c_void_p, c_void_p, c_long, c_void_p],
+    "ssd_allreduce_gr_bf16": [c_void_p, c_void_p, c_long, c_int, c_int, C.POINTER(c_void_p), c_long, c_void_p, c_void_p, c_long, c_void_p],
+    "ssd_allreduce_add_rmsnorm_gr_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                          C.POINTER(c_void_p), c_long, c_void_p, c_void_p, c_long, c_void_p],
     "ssd_topk_rows": [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p],
     "ssd_sample_rows": [c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p, C.c_uint, c_void_p, c_void_p, c_void_p, c_int,
                         c_float, c_void_p],

@@ -20,6 +20,9 @@ from ssd_amd.hip.lib import load_library
 from ssd_amd.utils.graphs import capture
 
 SLOT_ELEMS = 1 << 19          # bf16 elements per staging slot (1 MiB); messages above this go to RCCL
+GR_MAX_ELEMS = 1 << 16        # messages up to this many bf16 elements travel as data-tagged granules (csrc/comm.hip): [8, 8192] fits
+GR_CAP = GR_MAX_ELEMS // 2    # granules (8 bytes: 2 bf16 + epoch tag) per (parity, source rank) inbox region
+AR_MAX_RANKS = 8
 FLAG_BYTES = 4096
 SPIN_BUDGET = 100_000_000     # polls (~1 us each after the first 4096: ~100 s) before a wait gives up and sets the error word
 
@@ -30,6 +33,8 @@ class OneShotAllReduce:
         self.group, self.device = group, device
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        # SSD_AR_PROTO=flag keeps every message on the stage -> flag -> peer-read protocol; default: granules for the small ones
+        self.granules = os.environ.get("SSD_AR_PROTO", "granule") != "flag"
         torch.cuda.set_device(device)
         self._own, self._opened = [], []
         # Every rank takes part in every collective of this constructor even if a local step failed, and the outcome is
@@ -39,7 +44,8 @@ class OneShotAllReduce:
         try:
             slot = self._alloc(2 * SLOT_ELEMS * 2)
             flags = self._alloc(FLAG_BYTES)
-            mine = (self._export(slot), self._export(flags))
+            inbox = self._alloc(2 * AR_MAX_RANKS * GR_CAP * 8)
+            mine = (self._export(slot), self._export(flags), self._export(inbox))
         except Exception:
             mine = None
         handles = [None] * self.world
@@ -47,16 +53,19 @@ class OneShotAllReduce:
         ok = all(h is not None for h in handles)
         if ok:
             try:
-                slots, flgs = [], []
-                for r, (hs, hf) in enumerate(handles):
+                slots, flgs, boxes = [], [], []
+                for r, (hs, hf, hb) in enumerate(handles):
                     if r == self.rank:
                         slots.append(slot)
                         flgs.append(flags)
+                        boxes.append(inbox)
                     else:
                         slots.append(self._open(hs))
                         flgs.append(self._open(hf))
+                        boxes.append(self._open(hb))
                 self.slots = (C.c_void_p * self.world)(*slots)
                 self.flags = (C.c_void_p * self.world)(*flgs)
+                self.inboxes = (C.c_void_p * self.world)(*boxes)
                 self.counters = torch.zeros(8, dtype=torch.int32, device=device)
                 self.err = torch.zeros(1, dtype=torch.int32, device=device)
             except Exception:
@@ -93,6 +102,13 @@ class OneShotAllReduce:
 
     def all_reduce(self, t: torch.Tensor) -> None:
         """In-place sum over the group (bf16, fp32 accumulation in rank order); enqueued on the current stream."""
+        if self.granules and t.numel() <= GR_MAX_ELEMS:
+            rc = self.lib.ssd_allreduce_gr_bf16(t.data_ptr(), t.data_ptr(), t.numel(), self.rank, self.world, self.inboxes, GR_CAP,
+                                                self.counters.data_ptr(), self.err.data_ptr(), SPIN_BUDGET,
+                                                torch.cuda.current_stream().cuda_stream)
+            if rc != 0:
+                raise RuntimeError(f"ssd_allreduce_gr_bf16 failed with code {rc}")
+            return
         rc = self.lib.ssd_allreduce_bf16(t.data_ptr(), t.data_ptr(), t.numel(), self.rank, self.world, self.slots, self.flags,
                                          SLOT_ELEMS, self.counters.data_ptr(), self.err.data_ptr(), SPIN_BUDGET,
                                          torch.cuda.current_stream().cuda_stream)
@@ -106,6 +122,15 @@ class OneShotAllReduce:
                                eps: float, T: int, H: int, out_rows=None, out_frag=None) -> None:
         """res_out = bf16(sum_over_ranks(x[:T]) + res_in); out = RMSNorm(that) * weight (csrc/comm.hip): the all-reduce
         after o_proj / down_proj and the add + RMSNorm that follows it, in one launch."""
+        if self.granules and T * H <= GR_MAX_ELEMS:
+            rc = self.lib.ssd_allreduce_add_rmsnorm_gr_bf16(x.data_ptr(), res_in.data_ptr(), res_out.data_ptr(), weight.data_ptr(), eps,
+                                                            0 if out_rows is None else out_rows.data_ptr(),
+                                                            0 if out_frag is None else out_frag.data_ptr(), T, H, self.rank, self.world,
+                                                            self.inboxes, GR_CAP, self.counters.data_ptr(), self.err.data_ptr(),
+                                                            SPIN_BUDGET, torch.cuda.current_stream().cuda_stream)
+            if rc != 0:
+                raise RuntimeError(f"ssd_allreduce_add_rmsnorm_gr_bf16 failed with code {rc}")
+            return
         rc = self.lib.ssd_allreduce_add_rmsnorm_bf16(x.data_ptr(), res_in.data_ptr(), res_out.data_ptr(), weight.data_ptr(), eps,
                                                      0 if out_rows is None else out_rows.data_ptr(),
                                                      0 if out_frag is None else out_frag.data_ptr(), T, H, self.rank, self.world,
