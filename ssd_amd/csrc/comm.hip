@@ -61,6 +61,10 @@ static int ar_fences() {
   return v;
 }
 
+// W: ranks the peer loops are unrolled over (1 / 2 / 4 / 8, the smallest >= world): every rank's word is requested before the
+// first add, and no rank is read twice (a first version unrolled over all 8 whatever the world size: at world = 1 the fused
+// all-reduce + norm launch went from 7.6 to 11.1 us, profiles/r04_tp_shard_per_kind_v1.txt)
+template <int W>
 __global__ void __launch_bounds__(AR_THREADS)
 allreduce_bf16_kernel(const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out, long n8,
                       long slot_words, ArPeers peers, int rank, int world, unsigned int* __restrict__ counters,
@@ -105,12 +109,12 @@ allreduce_bf16_kernel(const unsigned long long* __restrict__ in, unsigned long l
   for (long i = i0 + threadIdx.x; i < i1; i += AR_THREADS) {
     // every rank's word is requested before the first add (a rolled loop is load -> wait -> add per rank: `world` dependent
     // remote round trips); ranks past `world` re-read the last one and are not added -- same sum, same (rank) order
-    unsigned long long v[AR_MAX_RANKS];
+    unsigned long long v[W];
 #pragma unroll
-    for (int r = 0; r < AR_MAX_RANKS; ++r) v[r] = ld_sys64(peers.slot[min(r, world - 1)] + (long)(epoch & 1u) * slot_words + i);
+    for (int r = 0; r < W; ++r) v[r] = ld_sys64(peers.slot[min(r, world - 1)] + (long)(epoch & 1u) * slot_words + i);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-    for (int r = 0; r < AR_MAX_RANKS; ++r)
+    for (int r = 0; r < W; ++r)
       if (r < world) {
         a0 += bf2f((unsigned)(v[r] & 0xffffu)); a1 += bf2f((unsigned)((v[r] >> 16) & 0xffffu));
         a2 += bf2f((unsigned)((v[r] >> 32) & 0xffffu)); a3 += bf2f((unsigned)(v[r] >> 48));
@@ -126,7 +130,7 @@ allreduce_bf16_kernel(const unsigned long long* __restrict__ in, unsigned long l
 // those of allreduce_bf16_kernel followed by rmsnorm_kernel (norm.hip) -- results are bit-identical to the unfused pair.
 constexpr int ARN_MAXH = 16384;    // = NORM_MAXH; ARN_THREADS = ssd_norm_threads(H): same chunk -> thread mapping, same
                                    // sum-of-squares order as rmsnorm_kernel<THREADS> (norm.hip)
-template <int ARN_THREADS>
+template <int ARN_THREADS, int W>
 __global__ void __launch_bounds__(ARN_THREADS)
 allreduce_add_rmsnorm_kernel(const unsigned long long* __restrict__ in, const u32x4_t* __restrict__ res_in,
                              u32x4_t* __restrict__ res_out, const u32x4_t* __restrict__ w, float eps,
@@ -174,15 +178,15 @@ allreduce_add_rmsnorm_kernel(const unsigned long long* __restrict__ in, const u3
       const int c = threadIdx.x + i * ARN_THREADS;
       if (c < H8) {
         float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        unsigned long long v0[AR_MAX_RANKS], v1[AR_MAX_RANKS];      // all ranks' words in flight at once (see allreduce_bf16_kernel)
+        unsigned long long v0[W], v1[W];      // all ranks' words in flight at once (see allreduce_bf16_kernel)
 #pragma unroll
-        for (int r = 0; r < AR_MAX_RANKS; ++r) {
+        for (int r = 0; r < W; ++r) {
           const unsigned long long* sp = peers.slot[min(r, world - 1)] + (long)(epoch & 1u) * slot_words + (long)row * hw + 2 * c;
           v0[r] = ld_sys64(sp); v1[r] = ld_sys64(sp + 1);
         }
         const u32x4_t rv = res_in[(size_t)row * H8 + c];
 #pragma unroll
-        for (int r = 0; r < AR_MAX_RANKS; ++r)
+        for (int r = 0; r < W; ++r)
           if (r < world) {
             a[0] += bf2f((unsigned)(v0[r] & 0xffffu)); a[1] += bf2f((unsigned)((v0[r] >> 16) & 0xffffu));
             a[2] += bf2f((unsigned)((v0[r] >> 32) & 0xffffu)); a[3] += bf2f((unsigned)(v0[r] >> 48));
@@ -253,20 +257,21 @@ __device__ __forceinline__ unsigned long long gr_make(unsigned int payload, unsi
 }
 
 // poll NG granules of every peer source (own rank skipped) until all carry `epoch`; returns false on a timeout
-template <int NG>
+template <int NG, int W>
 __device__ __forceinline__ bool gr_collect(const unsigned long long* mybox, long src_stride, long g0, int rank, int world,
-                                           unsigned int epoch, long spin_budget, unsigned long long (&v)[AR_MAX_RANKS][NG]) {
+                                           unsigned int epoch, long spin_budget, unsigned long long (&v)[W][NG]) {
   long spins = 0;
   while (true) {
     bool ok = true;
+    if (W == 1) return true;        // no peer
 #pragma unroll
-    for (int r = 0; r < AR_MAX_RANKS; ++r) {
+    for (int r = 0; r < W; ++r) {
       const int rr = min(r, world - 1);
 #pragma unroll
       for (int g = 0; g < NG; ++g) v[r][g] = ld_sys64(mybox + (long)rr * src_stride + g0 + g);
     }
 #pragma unroll
-    for (int r = 0; r < AR_MAX_RANKS; ++r)
+    for (int r = 0; r < W; ++r)
       if (r < world && r != rank) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) ok = ok && ((unsigned int)(v[r][g] >> 32) == epoch);
@@ -277,6 +282,7 @@ __device__ __forceinline__ bool gr_collect(const unsigned long long* mybox, long
   }
 }
 
+template <int W>
 __global__ void __launch_bounds__(AR_THREADS)
 allreduce_gr_kernel(const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out, long n8, long gr_cap,
                     GrPeers peers, int rank, int world, unsigned int* __restrict__ counters, unsigned int* __restrict__ err,
@@ -317,11 +323,11 @@ allreduce_gr_kernel(const unsigned long long* __restrict__ in, unsigned long lon
   for (int k = 0; k < MAXI; ++k) {
     const long i = i0 + threadIdx.x + (long)k * AR_THREADS;
     if (i < i1 && !fail) {
-      unsigned long long v[AR_MAX_RANKS][2];
-      if (!gr_collect<2>(mybox, gr_cap, 2 * i, rank, world, epoch, spin_budget, v)) { fail = true; break; }
+      unsigned long long v[W][2];
+      if (!gr_collect<2, W>(mybox, gr_cap, 2 * i, rank, world, epoch, spin_budget, v)) { fail = true; break; }
       float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-      for (int r = 0; r < AR_MAX_RANKS; ++r)
+      for (int r = 0; r < W; ++r)
         if (r < world) {
           const unsigned int lo = r == rank ? (unsigned int)w[k] : (unsigned int)v[r][0];
           const unsigned int hi = r == rank ? (unsigned int)(w[k] >> 32) : (unsigned int)v[r][1];
@@ -339,7 +345,7 @@ allreduce_gr_kernel(const unsigned long long* __restrict__ in, unsigned long lon
   }
 }
 
-template <int ARN_THREADS>
+template <int ARN_THREADS, int W>
 __global__ void __launch_bounds__(ARN_THREADS)
 allreduce_add_rmsnorm_gr_kernel(const unsigned long long* __restrict__ in, const u32x4_t* __restrict__ res_in,
                                 u32x4_t* __restrict__ res_out, const u32x4_t* __restrict__ w, float eps,
@@ -393,11 +399,11 @@ allreduce_add_rmsnorm_gr_kernel(const unsigned long long* __restrict__ in, const
         const u32x4_t rv = res_in[(size_t)row * H8 + c];
         const unsigned long long* src = in + (long)row * hw + 2 * c;
         const unsigned long long x0 = src[0], x1 = src[1];
-        unsigned long long gv[AR_MAX_RANKS][4];
-        if (!gr_collect<4>(mybox, gr_cap, ((long)row * H8 + c) * 4, rank, world, epoch, spin_budget, gv)) { fail = true; }
+        unsigned long long gv[W][4];
+        if (!gr_collect<4, W>(mybox, gr_cap, ((long)row * H8 + c) * 4, rank, world, epoch, spin_budget, gv)) { fail = true; }
         float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < AR_MAX_RANKS; ++r)
+        for (int r = 0; r < W; ++r)
           if (r < world) {
             unsigned int u[4];
             if (r == rank) { u[0] = (unsigned int)x0; u[1] = (unsigned int)(x0 >> 32); u[2] = (unsigned int)x1; u[3] = (unsigned int)(x1 >> 32); }
@@ -493,9 +499,12 @@ extern "C" int ssd_allreduce_bf16(const void* in, void* out, long n, int rank, i
     peers.flags[r] = (unsigned int*)(r < world ? flags[r] : nullptr);
   }
   const long n8 = n / 4;
-  hipLaunchKernelGGL(allreduce_bf16_kernel, dim3(AR_BLOCKS), dim3(AR_THREADS), 0, (hipStream_t)stream,
-                     (const unsigned long long*)in, (unsigned long long*)out, n8, slot_elems / 4, peers, rank, world,
-                     (unsigned int*)counters, (unsigned int*)err, spin_budget, 0, ar_fences());
+#define AR_GO(WV)                                                                                                        \
+  hipLaunchKernelGGL(allreduce_bf16_kernel<WV>, dim3(AR_BLOCKS), dim3(AR_THREADS), 0, (hipStream_t)stream,              \
+                     (const unsigned long long*)in, (unsigned long long*)out, n8, slot_elems / 4, peers, rank, world,   \
+                     (unsigned int*)counters, (unsigned int*)err, spin_budget, 0, ar_fences())
+  if (world == 1) AR_GO(1); else if (world == 2) AR_GO(2); else if (world <= 4) AR_GO(4); else AR_GO(8);
+#undef AR_GO
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
@@ -510,9 +519,12 @@ extern "C" int ssd_allgather_u64(const void* in, void* out, long n8, int rank, i
     peers.slot[r] = (unsigned long long*)(r < world ? slots[r] : nullptr);
     peers.flags[r] = (unsigned int*)(r < world ? flags[r] : nullptr);
   }
-  hipLaunchKernelGGL(allreduce_bf16_kernel, dim3(AR_BLOCKS), dim3(AR_THREADS), 0, (hipStream_t)stream,
-                     (const unsigned long long*)in, (unsigned long long*)out, n8, slot_elems / 4, peers, rank, world,
-                     (unsigned int*)counters, (unsigned int*)err, spin_budget, 1, ar_fences());
+#define AR_GO(WV)                                                                                                        \
+  hipLaunchKernelGGL(allreduce_bf16_kernel<WV>, dim3(AR_BLOCKS), dim3(AR_THREADS), 0, (hipStream_t)stream,              \
+                     (const unsigned long long*)in, (unsigned long long*)out, n8, slot_elems / 4, peers, rank, world,   \
+                     (unsigned int*)counters, (unsigned int*)err, spin_budget, 1, ar_fences())
+  if (world == 1) AR_GO(1); else if (world == 2) AR_GO(2); else if (world <= 4) AR_GO(4); else AR_GO(8);
+#undef AR_GO
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
@@ -533,17 +545,15 @@ extern "C" int ssd_allreduce_add_rmsnorm_bf16(const void* in, const void* res_in
     peers.slot[r] = (unsigned long long*)(r < world ? slots[r] : nullptr);
     peers.flags[r] = (unsigned int*)(r < world ? flags[r] : nullptr);
   }
-  if (ssd_norm_threads(H) == 1024) {
-    hipLaunchKernelGGL(allreduce_add_rmsnorm_kernel<1024>, dim3(AR_BLOCKS), dim3(1024), 0, (hipStream_t)stream,
-                       (const unsigned long long*)in, (const u32x4_t*)res_in, (u32x4_t*)res_out, (const u32x4_t*)weight, eps,
-                       (u32x4_t*)out_rows, (u32x4_t*)out_frag, T, H, slot_elems / 4, peers, rank, world,
-                       (unsigned int*)counters, (unsigned int*)err, spin_budget, ar_fences());
-  } else {
-    hipLaunchKernelGGL(allreduce_add_rmsnorm_kernel<256>, dim3(AR_BLOCKS), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned long long*)in, (const u32x4_t*)res_in, (u32x4_t*)res_out, (const u32x4_t*)weight, eps,
-                       (u32x4_t*)out_rows, (u32x4_t*)out_frag, T, H, slot_elems / 4, peers, rank, world,
-                       (unsigned int*)counters, (unsigned int*)err, spin_budget, ar_fences());
-  }
+#define ARN_GO(TH, WV)                                                                                                   \
+  hipLaunchKernelGGL((allreduce_add_rmsnorm_kernel<TH, WV>), dim3(AR_BLOCKS), dim3(TH), 0, (hipStream_t)stream,           \
+                     (const unsigned long long*)in, (const u32x4_t*)res_in, (u32x4_t*)res_out, (const u32x4_t*)weight, eps, \
+                     (u32x4_t*)out_rows, (u32x4_t*)out_frag, T, H, slot_elems / 4, peers, rank, world,                    \
+                     (unsigned int*)counters, (unsigned int*)err, spin_budget, ar_fences())
+#define ARN_W(TH) do { if (world == 1) ARN_GO(TH, 1); else if (world == 2) ARN_GO(TH, 2); else if (world <= 4) ARN_GO(TH, 4); else ARN_GO(TH, 8); } while (0)
+  if (ssd_norm_threads(H) == 1024) ARN_W(1024); else ARN_W(256);
+#undef ARN_W
+#undef ARN_GO
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
@@ -557,9 +567,12 @@ extern "C" int ssd_allreduce_gr_bf16(const void* in, void* out, long n, int rank
     return SSD_ERR_SHAPE;
   GrPeers peers;
   for (int r = 0; r < AR_MAX_RANKS; ++r) peers.inbox[r] = (unsigned long long*)(r < world ? inboxes[r] : nullptr);
-  hipLaunchKernelGGL(allreduce_gr_kernel, dim3(AR_BLOCKS), dim3(AR_THREADS), 0, (hipStream_t)stream,
-                     (const unsigned long long*)in, (unsigned long long*)out, n / 4, gr_cap, peers, rank, world,
-                     (unsigned int*)counters, (unsigned int*)err, spin_budget);
+#define GR_GO(WV)                                                                                                        \
+  hipLaunchKernelGGL(allreduce_gr_kernel<WV>, dim3(AR_BLOCKS), dim3(AR_THREADS), 0, (hipStream_t)stream,                \
+                     (const unsigned long long*)in, (unsigned long long*)out, n / 4, gr_cap, peers, rank, world,        \
+                     (unsigned int*)counters, (unsigned int*)err, spin_budget)
+  if (world == 1) GR_GO(1); else if (world == 2) GR_GO(2); else if (world <= 4) GR_GO(4); else GR_GO(8);
+#undef GR_GO
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
@@ -573,16 +586,14 @@ extern "C" int ssd_allreduce_add_rmsnorm_gr_bf16(const void* in, const void* res
   if (!in || !res_in || !res_out || !weight) return SSD_ERR_ARG;
   GrPeers peers;
   for (int r = 0; r < AR_MAX_RANKS; ++r) peers.inbox[r] = (unsigned long long*)(r < world ? inboxes[r] : nullptr);
-  if (ssd_norm_threads(H) == 1024) {
-    hipLaunchKernelGGL(allreduce_add_rmsnorm_gr_kernel<1024>, dim3(AR_BLOCKS), dim3(1024), 0, (hipStream_t)stream,
-                       (const unsigned long long*)in, (const u32x4_t*)res_in, (u32x4_t*)res_out, (const u32x4_t*)weight, eps,
-                       (u32x4_t*)out_rows, (u32x4_t*)out_frag, T, H, gr_cap, peers, rank, world, (unsigned int*)counters,
-                       (unsigned int*)err, spin_budget);
-  } else {
-    hipLaunchKernelGGL(allreduce_add_rmsnorm_gr_kernel<256>, dim3(AR_BLOCKS), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned long long*)in, (const u32x4_t*)res_in, (u32x4_t*)res_out, (const u32x4_t*)weight, eps,
-                       (u32x4_t*)out_rows, (u32x4_t*)out_frag, T, H, gr_cap, peers, rank, world, (unsigned int*)counters,
-                       (unsigned int*)err, spin_budget);
-  }
+#define GRN_GO(TH, WV)                                                                                                   \
+  hipLaunchKernelGGL((allreduce_add_rmsnorm_gr_kernel<TH, WV>), dim3(AR_BLOCKS), dim3(TH), 0, (hipStream_t)stream,        \
+                     (const unsigned long long*)in, (const u32x4_t*)res_in, (u32x4_t*)res_out, (const u32x4_t*)weight, eps, \
+                     (u32x4_t*)out_rows, (u32x4_t*)out_frag, T, H, gr_cap, peers, rank, world, (unsigned int*)counters,     \
+                     (unsigned int*)err, spin_budget)
+#define GRN_W(TH) do { if (world == 1) GRN_GO(TH, 1); else if (world == 2) GRN_GO(TH, 2); else if (world <= 4) GRN_GO(TH, 4); else GRN_GO(TH, 8); } while (0)
+  if (ssd_norm_threads(H) == 1024) GRN_W(1024); else GRN_W(256);
+#undef GRN_W
+#undef GRN_GO
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
