@@ -280,6 +280,47 @@ def _selftest_main() -> int:
                 print(f"[custom_ar selftest] rank {rank}: interleaved mismatched-shape sequence broke at it={it} failed={ar.failed()}", flush=True)
                 ok = False
                 break
+    # SSD_AR_STRESS=n (tests): n more rounds of randomly sized plain / fused / gather calls in random order -- message
+    # sizes on both sides of the granule / flag protocol boundary, every result compared bit for bit with the rank-order sum
+    stress = int(os.environ.get("SSD_AR_STRESS", "0"))
+    if ok and stress > 0:
+        import random
+        from ssd_amd.hip import ops as H
+        rnd = random.Random(99)                  # the same sequence on every rank
+        for it in range(stress):
+            kind = rnd.choice(("plain", "plain", "fused", "gather"))
+            if kind == "plain":
+                n = 4 * rnd.randint(1, (GR_MAX_ELEMS * 3) // 4)
+                xs = [torch.randn(n, generator=g).to(torch.bfloat16) for _ in range(world)]
+                t = xs[rank].to(dev)
+                ar.all_reduce(t)
+                torch.cuda.synchronize()
+                good = torch.equal(t.cpu().view(torch.int16), _rank_order_sum(xs).view(torch.int16))
+            elif kind == "fused":
+                Hd = 32 * rnd.randint(1, 256)
+                T = rnd.randint(1, max(1, min(24, (2 * GR_MAX_ELEMS) // Hd)))
+                xs = [torch.randn(T, Hd, generator=g).to(torch.bfloat16) for _ in range(world)]
+                res0 = torch.randn(T, Hd, generator=g).to(torch.bfloat16)
+                w = (1 + 0.1 * torch.randn(Hd, generator=g)).to(torch.bfloat16).to(dev)
+                res = res0.to(dev)
+                rows = torch.zeros(T, Hd, dtype=torch.bfloat16, device=dev)
+                ar.all_reduce_add_rmsnorm(xs[rank].to(dev), res, res, w, 1e-5, T, Hd, out_rows=rows)
+                ref_res = torch.zeros(T, Hd, dtype=torch.bfloat16, device=dev)
+                ref_rows = torch.zeros(T, Hd, dtype=torch.bfloat16, device=dev)
+                H.rmsnorm(_rank_order_sum(xs).to(dev), w, 1e-5, T, Hd, res_in=res0.to(dev), res_out=ref_res, out_rows=ref_rows)
+                torch.cuda.synchronize()
+                good = torch.equal(res.view(torch.int16), ref_res.view(torch.int16)) and torch.equal(rows.view(torch.int16), ref_rows.view(torch.int16))
+            else:
+                ng = rnd.randint(1, 64)
+                gs = [torch.randint(0, 1 << 40, (ng,), generator=g) for _ in range(world)]
+                gout = torch.zeros(world, ng, dtype=torch.int64, device=dev)
+                ar.all_gather_words(gs[rank].to(dev), gout, ng)
+                torch.cuda.synchronize()
+                good = torch.equal(gout.cpu(), torch.stack(gs))
+            if ar.failed() or not good:
+                print(f"[custom_ar selftest] rank {rank}: stress round {it} ({kind}) mismatch, failed={ar.failed()}", flush=True)
+                ok = False
+                break
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     dist.barrier()

@@ -11,6 +11,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The oracle's bf16 GEMV-shaped matmuls stop scaling -- and then collapse -- beyond a few tens of threads: on the GPU box's
+    # 256-core host the full-size oracle engines (8B target + 1B draft) ran minutes per test with torch's default of one thread per
+    # core (bench.py's cpu_baseline leg found the same: 256 threads ~1000x slower than 16).  Results do not depend on the count.
+    import torch
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
 
 
 # Tests that start SEVERAL processes on the one test GPU (ranks that spin on each other's flags in the one-shot all-reduce,
