@@ -243,7 +243,7 @@ def gemm_roofline(legs):
     # HBM traffic per launch: PMC counters cannot be collected from inside this process; the committed separate
     # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (profiles/collect.sh; FETCH_SIZE doubled as the gfx950
     # guide prescribes) give read+write bytes = ratio x algorithmic bytes for this kernel family
-    for fn in ("traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
+    for fn in ("traffic_r04.json", "traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
         try:
             with open(os.path.join(ROOT, "profiles", fn)) as f:
                 t = json.load(f)
