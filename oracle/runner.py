@@ -313,7 +313,12 @@ class OracleRunner:
         lg, pre = self._eagle_logits(torch.tensor(ids), torch.tensor(pos), torch.cat(conds, dim=0), ctx)
         rows = torch.tensor([cu[b] + counts[b] + j for b in range(B) for j in range(K + 1)])    # the K+1 [recovery | spec] rows
         self._glue_pre = pre[rows].view(B, K + 1, -1)
-        return O.fork_topf(lg[rows].view(B, K + 1, -1), glue_ids, fan_lists)
+        glg = lg[rows].view(B, K + 1, -1)
+        if self.log_decisions:
+            ex = glg.clone()        # the fork never picks the token that follows in the chain (async_spec_helpers.py:45-52)
+            ex[:, :-1, :] = ex[:, :-1, :].scatter(2, glue_ids[:, 1:].unsqueeze(2), float("-inf"))
+            self.decision_gaps.append(("glue", self._gap(ex, max(max(f) for f in fan_lists) + 1)))
+        return O.fork_topf(glg, glue_ids, fan_lists)
 
     def _mirror_response_init(self, B):
         """Random-stream bookkeeping for seeded replays of a reference run at temperature > 0 (tests/test_ref_engine_golden.py):

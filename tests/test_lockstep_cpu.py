@@ -55,3 +55,24 @@ def test_resynchronisation_carries_the_run_to_the_end(mode):
                            thr=float("inf"), max_restarts=64, what=mode)
     assert rep.tokens == 40 and rep.tokens_compared == 40, rep.summary()        # the target's stream is the same whatever the draft says
     assert rep.restarts > 0 and rep.rounds_compared < rep.rounds and all(e[0] != "target" for e in rep.excused), rep.summary()
+
+
+def test_eagle3_engines_compare_everything():
+    """The harness over the EAGLE-3 path (target taps, activations on the wire, extend rows, cached prenorms): identical oracle
+    engines on the constructed agreeing pair (weights.eagle_pair_recipe) compare every token and round; hits and acceptances occur."""
+    from ssd_amd.utils.topology import Topology
+    import torch
+    from tests.eagle_util import TAPS
+    hd = 32
+    t = ModelConfig("llama", 128, 4, 4, 2, hd, 256, 2048, 1e-5, 5e5, 1024, False)
+    d = ModelConfig("eagle3", 128, 1, 4, 2, hd, 256, 2048, 1e-5, 5e5, 1024, False, draft_vocab_size=512, d_model_target=128, eagle_taps=len(TAPS))
+    rec = W.eagle_pair_recipe(t, d, draft_seed=1)
+    tw, dw = W.synthetic_state_dict(t, 0, 0.1, recipe=rec), W.synthetic_state_dict(d, 1, 0.1, recipe=rec)
+    kw = dict(hf_config=t, draft="e", draft_hf_config=d, speculate=True, speculate_k=3, draft_async=True, async_fan_out=2, jit_speculate=True,
+              use_eagle=True, eagle_layers=list(TAPS), max_num_seqs=1, max_model_len=512, max_num_batched_tokens=512, kvcache_block_size=16,
+              num_kvcache_blocks=40, num_draft_kvcache_blocks=60)
+    cpu = Topology(0, 1, torch.device("cpu"), "target", 0, 1)
+    engs = [LLMEngine("t", runner_factory=oracle_runner_factory(tw, dw), inprocess_draft=True, topology=cpu, **kw) for _ in range(2)]
+    rep = compare_lockstep(engs[0], engs[1], [(7 * j + 1) % 2048 for j in range(13)], 40, _sp, fan_out=2, what="eagle3")
+    assert rep.tokens == 40 and rep.tokens_compared == 40 and rep.rounds_compared == rep.rounds and not rep.excused, rep.summary()
+    assert rep.hits > 0 and max(rep.accepted_lens) > 2, rep.summary()
