@@ -90,6 +90,8 @@ class LLMEngine:
                 dev = torch.device("cuda", 0) if torch.cuda.is_available() else torch.device("cpu")
                 topology = Topology(0, 1, dev, "target", 0, 1)
         self.topo = topology or resolve_topology(config)
+        from ssd_amd.utils import watchdog
+        watchdog.stage("runner_init (weights, KV cache, buffers)")
         factory = runner_factory or hip_runner_factory
 
         self.draft_runner = None

@@ -70,3 +70,23 @@ def test_three_ranks_target_tp2_plus_draft_the_draft_wedges():
     assert rc != 0 and dt < 60, (rc, dt)
     assert len(lines) == 1, (lines, err[-2000:])
     assert lines[0]["failure"] == "timeout" and lines[0]["stage"] == "timed_steps", lines[0]
+
+
+def test_bench_py_itself_without_a_gpu_prints_one_failure_record():
+    """The real `python bench.py --gpus 2` (self-launching, relaying launcher + RunGuard in every rank) on a box WITHOUT a GPU: the
+    product path has no CPU fallback, so both ranks raise during start-up -- the launch must end at once with ONE json line that
+    carries the benchmark's keys, value null, the error and the stage."""
+    if __import__("torch").cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "2", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert p.returncode != 0 and time.time() - t0 < 60
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = lines[0]
+    assert rec["value"] is None and rec["n_gpus"] == 2 and "no CPU fallback" in rec["error"] and rec["stage"].startswith("runner_init"), rec
+    assert {"metric", "unit", "steps", "warmup", "higher_is_better", "config"} <= set(rec)
