@@ -160,6 +160,18 @@ int ssd_attn_paged(const void* q_rows, const void* k_cache, const void* v_cache,
                    int tree_mq, int tree_step, int tree_F, const int32_t* tree_jidx, int splits, int flags,
                    void* ws_o, void* ws_ml, void* out_rows, void* out_frag, void* stream);
 
+/* ssd_rope_store_kv + ssd_attn_paged in ONE launch for the decode-side shapes (round 4): q_per_seq <= 32 new tokens per sequence
+ * (single-token decode, K+1-row verify / glue, the MQ_LEN-branch tree step), context within one workgroup scan (buckets <= 1024).
+ * qkv_rows: the QKV projection's rows [T][(nh + 2 nkv) * hd]; every workgroup norms (q_norm_w / k_norm_w: Qwen3's per-head
+ * RMSNorm, or NULL), rotates and stores the new K / V rows of its (sequence, kv head), then builds its Q fragments from the raw
+ * rows with the same arithmetic: bit-identical to the two calls.  Replaces ssd/models/qwen3.py:96-104 + ssd/layers/
+ * rotary_embedding.py:40-60 + ssd/layers/attention.py:10-41 + :105-131 wherever RoPE cannot ride the QKV GEMM's epilogue. */
+int ssd_attn_paged_qkv(const void* qkv_rows, const int64_t* positions, const float* cos_sin, const int32_t* slot_mapping,
+                       const void* q_norm_w, const void* k_norm_w, float eps, int qkv_perm, void* k_cache, void* v_cache,
+                       const int32_t* block_tables, int max_blocks, const int32_t* context_lens, int q_per_seq, int B, int T,
+                       int nh, int nkv, int hd, int block_size, float scale, int mode, int tree_K, int tree_mq, int tree_step,
+                       int tree_F, const int32_t* tree_jidx, int flags, void* out_rows, void* out_frag, void* stream);
+
 /* Attention + o_proj in ONE launch for the single-GPU drafts' decode / glue forwards: flash_attn_with_kvcache
  * (ssd/layers/attention.py:105-111,126-131) followed by RowParallelLinear o_proj (ssd/layers/linear.py:186-199, no all-reduce
  * at tp = 1).  One sequence, T causal (bottom-right aligned) query rows; parts = fp32 slabs [nkv][T][N], slab h = o_proj

@@ -46,6 +46,9 @@ SIGNATURES = {
     "ssd_attn_paged": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                        c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int,
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "ssd_attn_paged_qkv": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                           c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                           c_int, c_void_p, c_void_p, c_void_p],
     "ssd_attn_oproj_parts": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                              c_void_p, c_int, c_void_p, c_void_p],
     "ssd_gemm_wf_argmax_parts": [c_int, c_int, c_int],

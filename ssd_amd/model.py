@@ -111,6 +111,9 @@ class HipDecoder:
         if self.use_parts and not all(fits(self.h, k, f) for k in (self.qn, self.I) for f in ((False, True) if fused_possible else (False,))):
             self.use_parts = False
         self.fuse_attn_o = os.environ.get("SSD_FUSE_ATTN_O", "1") != "0"
+        # models whose RoPE cannot ride the QKV GEMM's epilogue (Qwen3: a per-head q / k RMSNorm sits in between): the norm, the
+        # rotation and the KV store happen inside the attention launch instead of a launch of their own (csrc/attention.hip QKV)
+        self.fuse_qkv_attn = os.environ.get("SSD_FUSE_QKV_ATTN", "1") != "0"
         self.pf_parts = os.environ.get("SSD_PF_PARTS", "1") != "0"
         self._prefill_waves = int(os.environ.get("SSD_ATTN_PREFILL_WAVES", "0"))
         self._last_parts = False        # set by forward() for the compute_logits that follows it
@@ -340,9 +343,19 @@ class HipDecoder:
         small = T <= 16 and not self.cfg.qk_norm
         return small, small and not self.use_coll and T * self.h // 8 <= 1024
 
+    def qkv_attn_plan(self, T: int, meta: AttnMeta, splits: int) -> bool:
+        """RoPE (+ Qwen3's q / k norm) + KV store inside the attention launch: decode-side shapes (<= 32 new tokens per sequence,
+        fixed rows per sequence), the context scanned inside one workgroup, and only where launch_qkv would otherwise end in a
+        separate ssd_rope_store_kv launch."""
+        small, _ = self.fusion_plan(T)
+        rope_in_gemm = small or (16 < T <= 32 and not self.cfg.qk_norm)
+        return (self.fuse_qkv_attn and not rope_in_gemm and meta.cu_q is None and 0 < meta.q_per_seq <= 32
+                and T == meta.B * meta.q_per_seq and splits == 1)
+
     def launch_qkv(self, li: int, T: int, positions, slot_mapping, gemm_only: bool = False, pre_normed: bool = False,
-                   parts: bool | None = None, pf_src: int = 0) -> None:
+                   parts: bool | None = None, pf_src: int = 0, defer_rope: bool = False) -> None:
         """gemm_only: skip the separate add+RMSNorm / RoPE launches of the unfused variants (kernel timing).
+        defer_rope: the attention launch that follows does the norm + RoPE + KV store itself (qkv_attn_plan): stop at buf_qkv.
         pre_normed: buf_xf / buf_res already hold this layer's normalised input and residual (written by the fused
         all-reduce + add + RMSNorm that closed the previous layer)."""
         cfg, w = self.cfg, self.w
@@ -373,7 +386,7 @@ class HipDecoder:
         if small or (16 < T <= 32 and not cfg.qk_norm):      # T in 17..32 (tree-decode step): the two-token-tile variant
             H.gemm_fused(w[p + "self_attn.qkv_proj.weight"], T, self.qkv_n, self.h, H.FEPI_QKV_ROPE, x_frag=xf,
                          bias=w.get(p + "self_attn.qkv_proj.bias"), **rope)
-        elif (not gemm_only and w.get(p + "self_attn.qkv_proj.bias") is None and self._pf_partials_ok(T, self.qkv_n, self.h)
+        elif (not gemm_only and not defer_rope and w.get(p + "self_attn.qkv_proj.bias") is None and self._pf_partials_ok(T, self.qkv_n, self.h)
               and self._pf_splits(T, self.qkv_n, self.h) > 1):
             # single-chunk prefill of a big QKV matrix: its split-K slabs stay in the workspace and the RoPE / KV-store kernel
             # sums them (bit-identical to the GEMM's epilogue launch + rope_store_kv; one launch less per layer)
@@ -384,7 +397,7 @@ class HipDecoder:
         else:
             self._gemm(xf, self.h, w[p + "self_attn.qkv_proj.weight"], self.qkv_n, self.buf_qkv, T, self.qkv_n,
                        bias=w.get(p + "self_attn.qkv_proj.bias"))
-            if gemm_only:
+            if gemm_only or defer_rope:
                 return
             H.rope_store_kv(self.buf_qkv, positions, self.cos_sin, slot_mapping, self.buf_q, kc, vc, T, self.nh, self.nkv,
                             self.hd, self.block_size, q_norm_w=w.get(p + "self_attn.q_norm.weight"),
@@ -453,6 +466,7 @@ class HipDecoder:
         parts = self.parts_plan(T) and meta.cu_q is None
         self._fwd_T, self._last_parts = T, parts
         fuse_ao = parts and self.attn_o_plan(T, meta, splits)
+        qkv_attn = not fuse_ao and self.qkv_attn_plan(T, meta, splits)
         # tensor parallel with the one-shot collective: the all-reduce after o_proj / down_proj absorbs the residual add
         # and the RMSNorm that follow it (csrc/comm.hip), 2 launches fewer per half layer
         ar = self.custom_ar
@@ -461,7 +475,7 @@ class HipDecoder:
         L = cfg.num_layers
         pf_d = 0            # split-K slabs the previous layer's down_proj left for this layer's input norm (single-chunk prefill)
         for li in range(L):
-            self.launch_qkv(li, T, positions, meta.slot_mapping, pre_normed=fuse and li > 0, parts=parts, pf_src=pf_d)
+            self.launch_qkv(li, T, positions, meta.slot_mapping, pre_normed=fuse and li > 0, parts=parts, pf_src=pf_d, defer_rope=qkv_attn)
             if self.taps is not None and li in self.taps:
                 # launch_qkv has just written x + residual: to buf_res2 on the fused-prologue path, to buf_res otherwise
                 src = self.buf_res2 if self.fusion_plan(T)[1] else res
@@ -472,6 +486,15 @@ class HipDecoder:
                 H.attn_oproj_parts(self.buf_q, self.kv_cache[li, 0], self.kv_cache[li, 1], meta.block_tables, self.max_blocks,
                                    meta.context_lens, T, self.nh, self.nkv, self.hd, self.block_size, scale,
                                    w[f"model.layers.{li}.self_attn.o_proj.weight"], self.h, self.buf_parts_o)
+            elif qkv_attn:
+                p_ = f"model.layers.{li}.self_attn."
+                H.attn_paged_qkv(self.buf_qkv, positions, self.cos_sin, meta.slot_mapping, self.kv_cache[li, 0], self.kv_cache[li, 1],
+                                 meta.block_tables, self.max_blocks, meta.context_lens, meta.B, T, meta.q_per_seq, self.nh, self.nkv,
+                                 self.hd, self.block_size, scale, q_norm_w=w.get(p_ + "q_norm.weight"), k_norm_w=w.get(p_ + "k_norm.weight"),
+                                 eps=cfg.rms_norm_eps, qkv_perm=1, mode=meta.mode, tree_K=meta.tree_K, tree_mq=meta.tree_mq,
+                                 tree_step=meta.tree_step, tree_F=meta.tree_F, tree_jidx=meta.tree_jidx, out_frag=self.buf_af,
+                                 waves=attn_waves)
+                pf_o = self.launch_o(li, T, parts=parts, pf_partials=not parts)
             else:
                 H.attn_paged(self.buf_q, self.kv_cache[li, 0], self.kv_cache[li, 1], meta.block_tables, self.max_blocks,
                              meta.context_lens, meta.B, T, meta.max_q, self.nh, self.nkv, self.hd, self.block_size, scale,
