@@ -112,8 +112,12 @@ class HipDecoder:
             self.use_parts = False
         self.fuse_attn_o = os.environ.get("SSD_FUSE_ATTN_O", "1") != "0"
         # models whose RoPE cannot ride the QKV GEMM's epilogue (Qwen3: a per-head q / k RMSNorm sits in between): the norm, the
-        # rotation and the KV store happen inside the attention launch instead of a launch of their own (csrc/attention.hip QKV)
-        self.fuse_qkv_attn = os.environ.get("SSD_FUSE_QKV_ATTN", "1") != "0"
+        # rotation and the KV store can happen inside the attention launch instead of a launch of their own (csrc/attention.hip
+        # QKV; bit-identical, tests/test_hip_attn_qkv.py).  Measured on MI355X (profiles/r04_bench_c5t_qkvattn_ab.txt, Qwen3-32B +
+        # 0.6B async): 20.54 ms / step fused vs 19.92 separate -- the new K / V rows make a store -> vmcnt(0) -> barrier -> load
+        # round trip through memory in front of the key scan, which costs each of the few attention workgroups more than the
+        # launch it saves.  OFF by default; the way to make it pay (new keys kept in LDS for the tail tile) is noted in DESIGN 8c.
+        self.fuse_qkv_attn = os.environ.get("SSD_FUSE_QKV_ATTN", "0") == "1"
         self.pf_parts = os.environ.get("SSD_PF_PARTS", "1") != "0"
         self._prefill_waves = int(os.environ.get("SSD_ATTN_PREFILL_WAVES", "0"))
         self._last_parts = False        # set by forward() for the compute_logits that follows it
