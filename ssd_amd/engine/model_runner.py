@@ -157,7 +157,10 @@ class ModelRunner:
             watchdog.stage("one_shot_allreduce_ipc_exchange (hipIpc handles)", 120.0)
             m.custom_ar = CA.OneShotAllReduce(self.tp_group, self.device)
             watchdog.stage("engine_init")
-            self.custom_ar_status = "validated on every rank" if world > 1 else "single rank (nothing to validate)"
+            arch = getattr(torch.cuda.get_device_properties(self.device), "gcnArchName", "?")
+            proto = "granules <= 64 Ki elements, flag protocol above" if m.custom_ar.granules else "flag protocol"
+            self.custom_ar_status = (f"validated on every rank of this node ({arch}; {proto})" if world > 1
+                                     else f"single rank (nothing to validate; {arch}; {proto})")
         except Exception as e:
             m.custom_ar = None
             self.custom_ar_status = f"set-up raised {type(e).__name__}: {e}: fell back to RCCL"
