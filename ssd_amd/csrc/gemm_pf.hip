@@ -35,6 +35,8 @@ gemm_pf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, f
                int M, int N, int K, int kt_per_split, int mt_valid, const bf16_t* __restrict__ bias,
                void* __restrict__ Yv, int ldy) {
   __shared__ u32x4_t xs[2 * BPS][MT][64];                // ring of two phases of BPS k-steps, MT fragment tiles per k-step
+  constexpr int KTS = 16 + DIRECT;                        // trace slot (profiling builds only)
+  KTRACE(KTS, 0);
   constexpr int U = UU;                                   // W k-steps in flight per wave (nk is a multiple of it)
   static_assert(UU % (2 * BPS) == 0, "an even number of phases per unrolled pass");
   constexpr int FPW = (MT + PF_WAVES - 1) / PF_WAVES;     // x fragment tiles each wave fetches per k-step
@@ -101,7 +103,9 @@ gemm_pf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, f
   for (int b = 0; b < BPS; ++b) stage_x(xr[0][b], b);
 #pragma unroll
   for (int b = 0; b < BPS; ++b) load_x(xr[0][b], min(2 * BPS + b, klast));
+  KTRACE(KTS, 1);
   __syncthreads();
+  KTRACE(KTS, 2);
   for (int kt = 0; kt < nk; kt += U) {
 #pragma unroll
     for (int u = 0; u < U; u += BPS) {
@@ -146,6 +150,7 @@ gemm_pf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, f
     }
   }
 
+  KTRACE(KTS, 3);
   const int mcol = lane & 15, nrow = (lane >> 4) * 4;
   if constexpr (DIRECT == 1) {
 #pragma unroll
@@ -165,6 +170,7 @@ gemm_pf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, f
         }
       }
     }
+    KTRACE(KTS, 4);
     return;
   }
   if constexpr (DIRECT == 2) {
@@ -191,6 +197,7 @@ gemm_pf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, f
         }
       }
     }
+    KTRACE(KTS, 4);
     return;
   }
   // fp32 partial tile of this split: ws[z][m][n]
@@ -204,6 +211,7 @@ gemm_pf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf, f
       if (m < M) *reinterpret_cast<f32x4_t*>(out + (size_t)m * N + n) = acc[nt][mt];
     }
   }
+  KTRACE(KTS, 4);
 }
 
 // Sum the K-splits in order, + bias, one rounding to bf16, then the same epilogues as gemm.hip.
@@ -397,3 +405,5 @@ extern "C" int ssd_gemm_pf(const void* x_frag, const void* w_frag, const void* b
   return ssd_gemm_pf_cfg(x_frag, w_frag, bias, y, M, N, K, ldy, epilogue, workspace, workspace_bytes,
                          nt | (waves << 8) | (bps << 24) | (bpre << 28), s, stream);
 }
+
+KT_DEFINE_SETTER(gemm_pf)
