@@ -197,6 +197,27 @@ int ssd_attn_oproj_parts(const void* q_rows, const void* k_cache, const void* v_
 int ssd_gemm_wf_argmax_parts(int M, int N, int K);
 int ssd_gemm_wf_argmax(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K, int ldy,
                        float* part_val, int32_t* part_idx, int part_stride, void* stream);
+
+/* The single-token decode chain (one sequence, M = 1: SpeculatorSync's draft chain, ssd/engine/speculator_sync.py:25-69, and the
+ * JIT chain of ssd/engine/draft_runner.py:186-378): everything of a decoder layer between two attention launches in ONE launch --
+ * LlamaDecoderLayer.forward (ssd/models/llama3.py:128-199) minus the attention call: o_proj, residual add + post-attention
+ * RMSNorm, gate_up + SiluAndMul, down_proj, residual add, and then EITHER the next layer's input RMSNorm + QKV projection + RoPE +
+ * store_kvcache (w_qkv_next != NULL; q_out / k_cache / v_cache / positions / slots / cos_sin are the NEXT layer's) OR, on the last
+ * layer (h_out != NULL), the hand-over to the final norm: h_out = down_proj rows, res_out = the residual they are added to.
+ * 256 resident workgroups; the three all-to-all edges inside are all-gathers of finished bf16 vectors through data-tagged
+ * 8-byte granules (csrc/chain.hip).  Same rounding points as the separate launches; fp32 summation order differs (tolerance).
+ *   granules  ssd_chain_granule_bytes(h, I) bytes, zeroed ONCE at allocation
+ *   gen       uint32 device word; ssd_chain_tick(gen, stream) once per forward, before its first segment
+ *   err       uint32 device word, set to 1 if a bounded wait gave up (the forward's results are then invalid)
+ * Shapes: ssd_chain_segment_ok(...) == SSD_OK (h, qn, I multiples of 128; h <= 4096; I <= 16384; no biases, no q/k norm). */
+int ssd_chain_tick(void* gen, void* stream);
+int ssd_chain_granule_bytes(int h, int I);
+int ssd_chain_segment_ok(int h, int qn, int I, int qkv_n, int nh, int nkv, int hd);
+int ssd_chain_segment(const void* a_frag, const void* res_in, void* res_out, void* h_out, const void* w_o, const void* w_gu,
+                      const void* w_d, const void* w_qkv_next, const void* ln_post, const void* ln_next, float eps,
+                      const int64_t* positions, const float* cos_sin, const int32_t* slots, void* q_out, void* k_cache, void* v_cache,
+                      int h, int qn, int I, int qkv_n, int nh, int nkv, int hd, int block_size, int layer, void* granules,
+                      const void* gen, void* err, void* stream);
 int ssd_argmax_parts(const float* part_val, const int32_t* part_idx, int nparts, long part_stride, int T, long idx_offset,
                      int64_t* out, int64_t* out2, int64_t* out3, long out3_stride, float* out_val, void* stream);
 int ssd_argmax_parts_verify(const float* part_val, const int32_t* part_idx, int nparts, long part_stride,

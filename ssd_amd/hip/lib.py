@@ -52,6 +52,12 @@ SIGNATURES = {
     "ssd_attn_oproj_parts": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                              c_void_p, c_int, c_void_p, c_void_p],
     "ssd_gemm_wf_argmax_parts": [c_int, c_int, c_int],
+    "ssd_chain_tick": [c_void_p, c_void_p],
+    "ssd_chain_granule_bytes": [c_int, c_int],
+    "ssd_chain_segment_ok": [c_int, c_int, c_int, c_int, c_int, c_int, c_int],
+    "ssd_chain_segment": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                          c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "ssd_gemm_wf_argmax": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "ssd_argmax_parts": [c_void_p, c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p],
     "ssd_argmax_parts_verify": [c_void_p, c_void_p, c_int, c_long, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],

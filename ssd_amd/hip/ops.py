@@ -187,6 +187,31 @@ def gemm_argmax(x_frag, w_frag, y, M: int, N: int, K: int, ldy: int, part_val, p
                                              part_stride, _stream()), "ssd_gemm_wf_argmax")
 
 
+def chain_segment_ok(h: int, qn: int, I: int, qkv_n: int, nh: int, nkv: int, hd: int) -> bool:
+    return load_library().ssd_chain_segment_ok(h, qn, I, qkv_n, nh, nkv, hd) == 0
+
+
+def chain_granule_bytes(h: int, I: int) -> int:
+    return load_library().ssd_chain_granule_bytes(h, I)
+
+
+def chain_tick(gen):
+    """Bumps the forward generation the chain segments tag their hand-offs with (once per forward, before the first segment)."""
+    _check(load_library().ssd_chain_tick(_p(gen), _stream()), "ssd_chain_tick")
+
+
+def chain_segment(a_frag, res_in, res_out, w_o, w_gu, w_d, ln_post, eps: float, h: int, qn: int, I: int, qkv_n: int, nh: int, nkv: int,
+                  hd: int, block_size: int, layer: int, granules, gen, err, *, h_out=None, w_qkv_next=None, ln_next=None, positions=None,
+                  cos_sin=None, slots=None, q_out=None, k_cache=None, v_cache=None):
+    """One single-token decoder layer between two attention launches as ONE launch (csrc/chain.hip): o_proj, residual add + RMSNorm,
+    gate_up + SiLU * mul, down_proj, residual add, and either the next layer's norm + QKV + RoPE + KV store (w_qkv_next given) or the
+    last layer's hand-over to the final norm (h_out given)."""
+    _check(load_library().ssd_chain_segment(_p(a_frag), _p(res_in), _p(res_out), _p(h_out), _p(w_o), _p(w_gu), _p(w_d), _p(w_qkv_next),
+                                            _p(ln_post), _p(ln_next), eps, _p(positions), _p(cos_sin), _p(slots), _p(q_out), _p(k_cache),
+                                            _p(v_cache), h, qn, I, qkv_n, nh, nkv, hd, block_size, layer, _p(granules), _p(gen), _p(err),
+                                            _stream()), "ssd_chain_segment")
+
+
 def argmax_parts(part_val, part_idx, nparts: int, part_stride: int, T: int, out=None, out2=None, out3=None, out3_stride: int = 0,
                  out_val=None, idx_offset: int = 0):
     _check(load_library().ssd_argmax_parts(_p(part_val), _p(part_idx), nparts, part_stride, T, idx_offset, _p(out), _p(out2), _p(out3),

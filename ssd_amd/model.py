@@ -119,6 +119,14 @@ class HipDecoder:
         # launch it saves.  OFF by default; the way to make it pay (new keys kept in LDS for the tail tile) is noted in DESIGN 8c.
         self.fuse_qkv_attn = os.environ.get("SSD_FUSE_QKV_ATTN", "0") == "1"
         self.pf_parts = os.environ.get("SSD_PF_PARTS", "1") != "0"
+        # the single-token chain (one sequence, T = 1) with everything between two attention launches in ONE resident launch
+        # (csrc/chain.hip): 1 + 2 per layer launches instead of 4 per layer
+        self.chain_seg = (os.environ.get("SSD_CHAIN_SEG", "0") == "1" and not cfg.qk_norm and tp_size == 1 and not self.use_coll
+                          and taps is None and H.chain_segment_ok(self.h, self.qn, self.I, self.qkv_n, self.nh, self.nkv, self.hd))
+        if self.chain_seg:
+            self.chain_gr = z(H.chain_granule_bytes(self.h, self.I) // 8, dtype=torch.int64)
+            self.chain_gen = z(1, dtype=torch.int32)
+            self.chain_err = z(1, dtype=torch.int32)
         self._prefill_waves = int(os.environ.get("SSD_ATTN_PREFILL_WAVES", "0"))
         self._last_parts = False        # set by forward() for the compute_logits that follows it
         pt = min(T, 32)
@@ -347,6 +355,34 @@ class HipDecoder:
         small = T <= 16 and not self.cfg.qk_norm
         return small, small and not self.use_coll and T * self.h // 8 <= 1024
 
+    def chain_plan(self, T: int, meta: AttnMeta, splits: int) -> bool:
+        """The resident single-token chain (csrc/chain.hip): one sequence, one new token, causal attention scanned inside one
+        workgroup, the fused norm + QKV launch available for layer 0, no biases."""
+        return (self.chain_seg and T == 1 and meta.B == 1 and meta.cu_q is None and meta.mode == H.MODE_CAUSAL and splits == 1
+                and self.fusion_plan(T)[1] and "model.layers.0.self_attn.qkv_proj.bias" not in self.w)
+
+    def _forward_chain(self, positions, meta: AttnMeta, attn_waves: int) -> None:
+        cfg, w = self.cfg, self.w
+        L = cfg.num_layers
+        scale = self.hd ** -0.5
+        H.chain_tick(self.chain_gen)
+        self.launch_qkv(0, 1, positions, meta.slot_mapping, parts=False)       # layer 0: norm(embedding) + QKV + RoPE + KV store
+        for li in range(L):
+            H.attn_paged(self.buf_q, self.kv_cache[li, 0], self.kv_cache[li, 1], meta.block_tables, self.max_blocks,
+                         meta.context_lens, meta.B, 1, meta.max_q, self.nh, self.nkv, self.hd, self.block_size, scale,
+                         cu_q=None, q_per_seq=meta.q_per_seq, mode=meta.mode, splits=1, ws_o=self.ws_o, ws_ml=self.ws_ml,
+                         out_frag=self.buf_af, waves=attn_waves)
+            p = f"model.layers.{li}."
+            last = li + 1 == L
+            nxt = {} if last else dict(
+                w_qkv_next=w[f"model.layers.{li + 1}.self_attn.qkv_proj.weight"], ln_next=w[f"model.layers.{li + 1}.input_layernorm.weight"],
+                positions=positions, cos_sin=self.cos_sin, slots=meta.slot_mapping, q_out=self.buf_q,
+                k_cache=self.kv_cache[li + 1, 0], v_cache=self.kv_cache[li + 1, 1])
+            H.chain_segment(self.buf_af, self.buf_res2, self.buf_res if last else self.buf_res2, w[p + "self_attn.o_proj.weight"],
+                            w[p + "mlp.gate_up_proj.weight"], w[p + "mlp.down_proj.weight"], w[p + "post_attention_layernorm.weight"],
+                            cfg.rms_norm_eps, self.h, self.qn, self.I, self.qkv_n, self.nh, self.nkv, self.hd, self.block_size, li,
+                            self.chain_gr, self.chain_gen, self.chain_err, h_out=self.buf_h if last else None, **nxt)
+
     def qkv_attn_plan(self, T: int, meta: AttnMeta, splits: int) -> bool:
         """RoPE (+ Qwen3's q / k norm) + KV store inside the attention launch: decode-side shapes (<= 32 new tokens per sequence,
         fixed rows per sequence), the context scanned inside one workgroup, and only where launch_qkv would otherwise end in a
@@ -469,6 +505,10 @@ class HipDecoder:
         # in the same Python body, must know whether the last down_proj left rows or partial slabs
         parts = self.parts_plan(T) and meta.cu_q is None
         self._fwd_T, self._last_parts = T, parts
+        if self.chain_plan(T, meta, splits):
+            self._last_parts = False            # the last segment leaves rows (buf_h) + the residual (buf_res) for compute_logits
+            self._forward_chain(positions, meta, attn_waves)
+            return
         fuse_ao = parts and self.attn_o_plan(T, meta, splits)
         qkv_attn = not fuse_ao and self.qkv_attn_plan(T, meta, splits)
         # tensor parallel with the one-shot collective: the all-reduce after o_proj / down_proj absorbs the residual add

@@ -1,0 +1,137 @@
+"""The resident single-token chain (csrc/chain.hip, ssd_chain_segment: o_proj -> add + norm -> gate_up + SiLU -> down_proj -> add + norm
+-> next layer's QKV + RoPE + KV store in ONE launch) against the separate launches it replaces and against the oracle model
+(LlamaDecoderLayer.forward, reference ssd/models/llama3.py:128-199): same rounding points, a different fp32 summation order inside the
+projections, so the bar is the propagated-noise bar of tests/test_real_shapes_gpu.py, identical argmax outside near-ties, and the
+chain must be no further from the oracle than the separate launches are."""
+import dataclasses
+import math
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from ssd_amd.model_config import PRESETS
+
+
+@pytest.fixture(scope="module")
+def H():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ssd_amd.hip import ops
+    return ops
+
+
+def build(cfg, full, chain: bool, monkeypatch, nblocks=3, bs=256):
+    from ssd_amd.model import HipDecoder
+    monkeypatch.setenv("SSD_CHAIN_SEG", "1" if chain else "0")
+    dec = HipDecoder(cfg, max_tokens=64, max_seqs=1, max_blocks=4, block_size=bs, max_model_len=1024, device=torch.device("cuda", 0))
+    dec.load_weights(iter(full.items()))
+    dec.alloc_kv(nblocks)
+    assert dec.chain_seg == chain
+    return dec
+
+
+@pytest.mark.parametrize("layers", [1, 4])
+def test_chain_forward_vs_separate_launches_and_oracle(H, monkeypatch, layers):
+    from oracle.model import OracleModel, Ctx
+    from ssd_amd import weights as W
+    from ssd_amd.model import AttnMeta
+    cfg = dataclasses.replace(PRESETS["llama-3.2-1b"], num_layers=layers)
+    full = W.synthetic_state_dict(cfg, seed=11, std=0.02)
+    bs, nblocks = 256, 3
+    decs = {c: build(cfg, full, c, monkeypatch) for c in (False, True)}
+    orc = OracleModel(cfg, full, nblocks, bs)
+    random.seed(2)
+    P = 37
+    prompt = [random.randint(0, 10000) for _ in range(P)]
+    table = [2, 0, 1]
+    bt = torch.tensor([table + [-1]], dtype=torch.int32)
+
+    def slots(ps):
+        return torch.tensor([table[p // bs] * bs + p % bs for p in ps], dtype=torch.int32)
+
+    def i64(x):
+        return torch.tensor(list(x), dtype=torch.int64)
+
+    cu = torch.tensor([0, P], dtype=torch.int32)
+    orc.forward(i64(prompt), i64(range(P)), Ctx("prefill", slot_mapping=slots(range(P)), cu_q=cu, cu_k=cu))
+    for dec in decs.values():
+        meta = AttnMeta(H.MODE_CAUSAL, 1, P, slots(range(P)).cuda(), torch.tensor([P], dtype=torch.int32).cuda(), bt.cuda(), cu_q=cu.cuda())
+        dec.forward(i64(prompt).cuda(), i64(range(P)).cuda(), P, meta)
+    pos = P
+    worst = 0.0
+    for step in range(6):                                   # a chain of single-token forwards, each attending to the previous ones' K / V
+        tok = [random.randint(0, 10000)]
+        ps = [pos]
+        ctx = Ctx("verify", slot_mapping=slots(ps), context_lens=torch.tensor([pos + 1], dtype=torch.int32), block_tables=bt,
+                  cu_q=torch.tensor([0, 1], dtype=torch.int32))
+        ref = orc.compute_logits(orc.forward(i64(tok), i64(ps), ctx)).float()
+        got = {}
+        for c, dec in decs.items():
+            meta = AttnMeta(H.MODE_CAUSAL, 1, 1, slots(ps).cuda(), torch.tensor([pos + 1], dtype=torch.int32).cuda(), bt.cuda(), q_per_seq=1)
+            dec.forward(i64(tok).cuda(), i64(ps).cuda(), 1, meta)
+            n = dec.compute_logits(1)
+            got[c] = dec.logits[:n].float().cpu()
+        assert int(decs[True].chain_err.item()) == 0, "a bounded wait inside the chain gave up"
+        scale = max(1.0, ref.std().item())
+        d_sep = (got[False] - ref).abs()
+        d_chain = (got[True] - ref).abs()
+        d_pair = (got[True] - got[False]).abs()
+        print(f"layers {layers} step {step}: |sep - oracle| max {d_sep.max():.4f} mean {d_sep.mean():.5f}; |chain - oracle| max "
+              f"{d_chain.max():.4f} mean {d_chain.mean():.5f}; |chain - sep| max {d_pair.max():.4f}")
+        assert torch.isfinite(got[True]).all()
+        assert d_chain.max().item() <= 0.05 * scale and d_chain.mean().item() <= 0.01 * scale
+        assert d_chain.mean().item() <= 1.5 * d_sep.mean().item() + 1e-4, "the chain is further from the oracle than the separate launches"
+        top2 = ref.topk(2, dim=-1).values
+        assert bool(((got[True].argmax(-1) == ref.argmax(-1)) | ((top2[:, 0] - top2[:, 1]) < 0.0625)).all())
+        worst = max(worst, d_pair.max().item())
+        # the new token's K / V rows of the LAST layer (written by the previous layer's segment; layer 0's by the fused QKV launch)
+        li = layers - 1
+        for which in (0, 1):
+            ref_rows = orc.kv_cache[which, li, table[pos // bs], pos % bs].float()
+            rows = {c: dec.kv_cache[li, which, table[pos // bs], :, pos % bs, :].cpu().float() for c, dec in decs.items()}
+            tol = 2.0 ** (math.floor(math.log2(ref_rows.abs().max().item())) - 6)
+            dkv, dsep = (rows[True] - ref_rows).abs(), (rows[False] - ref_rows).abs()
+            # (noise propagated through `layers` layers of bf16 intermediates: held to the separate launches' own distance)
+            assert dkv.max().item() <= max(tol, 1.5 * dsep.max().item()), (which, dkv.max().item(), dsep.max().item(), tol)
+            assert dkv.mean().item() <= max(tol / 8, 1.25 * dsep.mean().item() + tol / 64), (which, dkv.mean().item(), dsep.mean().item())
+        pos += 1
+    print(f"layers {layers}: worst |chain - separate| over the chain {worst:.4f}")
+
+
+def test_chain_is_replayable_in_a_graph(H, monkeypatch):
+    """hipGraph replay: the tag comes from a device word bumped inside the graph, so replays need no re-initialisation and two
+    replays of the same inputs give the same bits."""
+    from ssd_amd import weights as W
+    from ssd_amd.model import AttnMeta
+    cfg = dataclasses.replace(PRESETS["llama-3.2-1b"], num_layers=3)
+    full = W.synthetic_state_dict(cfg, seed=5, std=0.02)
+    dec = build(cfg, full, True, monkeypatch)
+    bs = 256
+    bt = torch.tensor([[0, 1, 2, -1]], dtype=torch.int32).cuda()
+    ids = torch.tensor([77], dtype=torch.int64).cuda()
+    pos = torch.tensor([5], dtype=torch.int64).cuda()
+    meta = AttnMeta(H.MODE_CAUSAL, 1, 1, torch.tensor([5], dtype=torch.int32).cuda(), torch.tensor([6], dtype=torch.int32).cuda(), bt, q_per_seq=1)
+    dec.kv_cache.normal_(0, 0.5)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        dec.forward(ids, pos, 1, meta)
+        dec.compute_logits(1)
+        s.synchronize()
+        eager = dec.logits[:1].clone()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            dec.forward(ids, pos, 1, meta)
+            dec.compute_logits(1)
+        outs = []
+        for _ in range(3):
+            dec.logits.zero_()
+            g.replay()
+            s.synchronize()
+            outs.append(dec.logits[:1].clone())
+    assert int(dec.chain_err.item()) == 0
+    for o in outs:
+        assert torch.equal(o.view(torch.int16), eager.view(torch.int16))
+    assert int(dec.chain_gen.item()) >= 4
