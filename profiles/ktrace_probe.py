@@ -27,7 +27,8 @@ from ssd_amd.utils.topology import Topology  # noqa: E402
 MARKS, MAXWG, SLOTS = 8, 4096, 32
 NAMES = {0: "fused norm+QKV+RoPE+store (M<=16)", 1: "fused norm+gate_up+SiLU (M<=16)", 2: "fused GEMM without prologue", 3: "qkv+RoPE m32",
          4: "gemm_sp o_proj -> slabs", 5: "gemm_sp down_proj -> slabs", 6: "attention", 7: "attention + o_proj -> slabs",
-         8: "gemm_wf gate_up + SiLU", 9: "gemm_wf rows (LM head)", 10: "rmsnorm over slabs", 11: "rmsnorm"}
+         8: "gemm_wf gate_up + SiLU", 9: "gemm_wf rows (LM head)", 10: "rmsnorm over slabs", 11: "rmsnorm",
+         12: "chain segment (o -> gate_up -> down -> next QKV), csrc/chain.hip", 13: "chain segment, last layer (o -> gate_up -> down)"}
 MARK_NAMES = {
     0: ["entry", "weight loads issued", "x / slabs arrived (barrier)", "x^ in LDS (barrier)", "MFMAs done (weights arrived)", "combine barrier", "stores issued"],
     1: ["entry", "weight loads issued", "x / slabs arrived (barrier)", "x^ in LDS (barrier)", "MFMAs done (weights arrived)", "combine barrier", "stores issued"],
@@ -40,6 +41,10 @@ MARK_NAMES = {
     9: ["entry", "-", "-", "-", "last tile's MFMAs done", "combine barrier", "stores issued"],
     10: ["entry", "-", "-", "-", "-", "-", "stored"],
     11: ["entry", "-", "-", "-", "-", "-", "stored"],
+    12: ["entry", "o_proj published", "edge 1: gathered, x^ ready", "gate_up published", "edge 2: activations gathered", "down_proj published",
+         "edge 3: gathered, x^ ready", "QKV + RoPE stored"],
+    13: ["entry", "o_proj published", "edge 1: gathered, x^ ready", "gate_up published", "edge 2: activations gathered", "down_proj published",
+         "edge 3: gathered, rows stored"],
 }
 
 
@@ -88,7 +93,7 @@ def main():
     dr = hip_runner_factory(cfg, PRESETS[name], is_draft=True, topo=topo, num_kvcache_blocks=10)
     lib = L.load_library()
     buf = torch.zeros(SLOTS * MAXWG * MARKS, dtype=torch.int64, device="cuda")
-    for tu in ("gemm", "gemm_fused", "gemm_sk", "attention", "norm"):
+    for tu in ("gemm", "gemm_fused", "gemm_sk", "attention", "norm", "chain"):
         fn = getattr(lib, f"ssd_ktrace_set_{tu}")
         fn.argtypes, fn.restype = [C.c_void_p], C.c_int
         assert fn(buf.data_ptr()) == 0, tu
@@ -104,7 +109,7 @@ def main():
         torch.cuda.synchronize()
 
     settle(lambda: dr.draft_jit(rec, nt, tables))
-    report(buf, f"{name}: single-token forward (last layer + tail of the last chained forward), ctx {ctx}", [0, 7, 1, 5, 11, 10, 9])
+    report(buf, f"{name}: single-token forward (last layer + tail of the last chained forward), ctx {ctx}", [0, 6, 12, 7, 1, 5, 13, 11, 10, 9])
     toks = dr.draft_jit(rec, nt, tables)
     glue = torch.cat([torch.tensor([rec], device=toks.device), toks], dim=1)
     fan, jl = [[F] * (K + 1)], [[j for j in range(K + 1) for _ in range(F)]]

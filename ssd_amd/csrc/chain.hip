@@ -236,6 +236,8 @@ __global__ void __launch_bounds__(SEG_THREADS) chain_segment_kernel(const SegPar
     L.xlds = reinterpret_cast<u32x4_t*>(s); s += (size_t)p.h * 2;
     L.xact = reinterpret_cast<u32x4_t*>(s);
   }
+  const int KTS = last ? 13 : 12;          // trace slots (profiling builds only)
+  KTRACE(KTS, 0);
   const unsigned tag0 = ((*p.gen & 0xffffffu) << 8) | ((unsigned)p.layer << 2);
   const int KTq = p.qn >> 5, KTh = p.h >> 5, KTi = p.I >> 5;
 
@@ -262,11 +264,13 @@ __global__ void __launch_bounds__(SEG_THREADS) chain_segment_kernel(const SegPar
     }
   }
 
+  KTRACE(KTS, 1);
   // ---------------- phase 2: gate_up + SiLU * mul (first unit's weights fly during the edge) ----------------
   const int pairs = p.I >> 4;          // (gate, up) row-group pairs
   SegGemv<2, 4, false, false> g2;
   if (b < pairs) { g2.init(p.Wgu, 2 * b, KTh, 0, nullptr, wave, lane); g2.prefetch(); }
   seg_add_norm<false>(p, L, p.gr_o, tag0 | 1u, p.res_in, p.ln_post, last ? p.res_out : nullptr, nullptr, true, wave, lane);
+  KTRACE(KTS, 2);
   for (int pr = b; pr < pairs; pr += SEG_GRID) {
     f32x4_t acc[2];
     g2.run(L.xlds, acc, lane);
@@ -290,6 +294,7 @@ __global__ void __launch_bounds__(SEG_THREADS) chain_segment_kernel(const SegPar
     __syncthreads();
   }
 
+  KTRACE(KTS, 3);
   // ---------------- phase 3: down_proj, half row groups (first tiles fly during the edge) ----------------
   {
     const int units = (p.h >> 4) * 2;
@@ -297,6 +302,7 @@ __global__ void __launch_bounds__(SEG_THREADS) chain_segment_kernel(const SegPar
     if (b < units) { g.init(p.Wd, b >> 1, KTi, b & 1, nullptr, wave, lane); g.prefetch(); }
     for (int c = threadIdx.x; c < (p.I >> 3); c += SEG_THREADS) L.xact[c] = seg_gather_chunk(p.gr_act + c * 4, tag0 | 2u, p);
     __syncthreads();
+    KTRACE(KTS, 4);
     for (int u = b; u < units; u += SEG_GRID) {
       const int grp = u >> 1, half = u & 1;
       f32x4_t acc[1];
@@ -315,15 +321,18 @@ __global__ void __launch_bounds__(SEG_THREADS) chain_segment_kernel(const SegPar
     }
   }
 
+  KTRACE(KTS, 5);
   // ---------------- the MLP add (+ next layer's norm), then phase 4: next layer's QKV + RoPE + KV store ----------------
   if (last) {
     seg_add_norm<true>(p, L, p.gr_d, tag0 | 3u, nullptr, nullptr, nullptr, p.h_out, false, wave, lane);
+    KTRACE(KTS, 6);
     return;
   }
   const int groups = p.qkv_n >> 4;
   SegGemv<1, 4, false, false> g4;
   if (b < groups) { g4.init(p.Wqkv, b, KTh, 0, nullptr, wave, lane); g4.prefetch(); }
   seg_add_norm<true>(p, L, p.gr_d, tag0 | 3u, nullptr, p.ln_next, p.res_out, nullptr, true, wave, lane);
+  KTRACE(KTS, 6);
   for (int grp = b; grp < groups; grp += SEG_GRID) {
     f32x4_t acc[1];
     g4.run(L.xlds, acc, lane);
@@ -378,6 +387,7 @@ __global__ void __launch_bounds__(SEG_THREADS) chain_segment_kernel(const SegPar
     }
     __syncthreads();
   }
+  KTRACE(KTS, 7);
 }
 
 __global__ void chain_tick_kernel(unsigned* gen) { *gen = *gen + 1u; }
@@ -429,3 +439,5 @@ extern "C" int ssd_chain_segment(const void* a_frag, const void* res_in, void* r
   hipLaunchKernelGGL(chain_segment_kernel, dim3(SEG_GRID), dim3(SEG_THREADS), lds, (hipStream_t)stream, p);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
+
+KT_DEFINE_SETTER(chain)
