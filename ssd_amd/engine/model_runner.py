@@ -191,6 +191,9 @@ class ModelRunner:
         if ar is not None and ar.failed():
             raise RuntimeError("one-shot all-reduce timed out waiting for a peer; results of this step are invalid "
                                "(rerun with SSD_CUSTOM_AR=0 to use RCCL)")
+        if getattr(self.model, "chain_seg", False) and int(self.model.chain_err.item()):
+            raise RuntimeError("a bounded wait inside the resident single-token chain (csrc/chain.hip) gave up; the forwards since the "
+                               "last check are invalid (rerun with SSD_CHAIN_SEG=0 for the separate launches)")
 
     # ---------------------------------------------------------------------------------------------
     # host -> device input staging

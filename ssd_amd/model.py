@@ -121,7 +121,13 @@ class HipDecoder:
         self.pf_parts = os.environ.get("SSD_PF_PARTS", "1") != "0"
         # the single-token chain (one sequence, T = 1) with everything between two attention launches in ONE resident launch
         # (csrc/chain.hip): 1 + 2 per layer launches instead of 4 per layer
-        self.chain_seg = (os.environ.get("SSD_CHAIN_SEG", "0") == "1" and not cfg.qk_norm and tp_size == 1 and not self.use_coll
+        # Default ("auto"): on at the geometry it was validated and measured at on the MI355X -- Llama-3.2-1B's, the draft of every
+        # Llama configuration in BASELINE.json (tests/test_hip_chain.py, the full-size lock-step tests; draft forward 0.740 ->
+        # 0.705 ms, c2 7.78 -> 7.50 ms / step, profiles/r04_chain_segment.txt).  SSD_CHAIN_SEG=1 forces it for every shape the
+        # kernel accepts, =0 turns it off.
+        _cs = os.environ.get("SSD_CHAIN_SEG", "auto")
+        _validated = (self.h, self.qn, self.I, self.qkv_n, self.hd) == (2048, 2048, 8192, 3072, 64)
+        self.chain_seg = ((_cs == "1" or (_cs == "auto" and _validated)) and not cfg.qk_norm and tp_size == 1 and not self.use_coll
                           and taps is None and H.chain_segment_ok(self.h, self.qn, self.I, self.qkv_n, self.nh, self.nkv, self.hd))
         if self.chain_seg:
             self.chain_gr = z(H.chain_granule_bytes(self.h, self.I) // 8, dtype=torch.int64)
