@@ -101,6 +101,7 @@ def test_chain_forward_vs_separate_launches_and_oracle(H, monkeypatch, layers):
     print(f"layers {layers}: worst |chain - separate| over the chain {worst:.4f}")
 
 
+@torch.inference_mode()          # (as the runners: the capture touches generator state an earlier engine test created in inference mode)
 def test_chain_is_replayable_in_a_graph(H, monkeypatch):
     """hipGraph replay: the tag comes from a device word bumped inside the graph, so replays need no re-initialisation and two
     replays of the same inputs give the same bits."""
