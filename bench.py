@@ -182,14 +182,36 @@ def gemm_roofline(legs):
                  ("o", m.h * m.qn * 2, lambda li: m.launch_o(li, M)),
                  ("gate_up", 2 * m.I * m.h * 2, lambda li: m.launch_gate_up(li, M, gemm_only=True)),
                  ("down", m.h * m.I * 2, lambda li: m.launch_down(li, M))]
+        chain = bool(getattr(m, "chain_seg", False)) and M == 1
+        if chain:
+            # the single-token chain runs the layer's o_proj / gate_up / down_proj and the next layer's QKV as ONE resident launch
+            # (csrc/chain.hip): that launch is the kind that is timed, with its own algorithmic bytes
+            from ssd_amd.hip import ops as H_
+
+            def seg(li, m=m, runner=runner):
+                w, last = m.w, li + 1 == m.cfg.num_layers
+                p_ = f"model.layers.{li}."
+                nxt = {} if last else dict(
+                    w_qkv_next=w[f"model.layers.{li + 1}.self_attn.qkv_proj.weight"], ln_next=w[f"model.layers.{li + 1}.input_layernorm.weight"],
+                    positions=runner.d_pos, cos_sin=m.cos_sin, slots=runner.d_slots, q_out=m.buf_q, k_cache=m.kv_cache[li + 1, 0],
+                    v_cache=m.kv_cache[li + 1, 1])
+                H_.chain_segment(m.buf_af, m.buf_res2, m.buf_res if last else m.buf_res2, w[p_ + "self_attn.o_proj.weight"],
+                                 w[p_ + "mlp.gate_up_proj.weight"], w[p_ + "mlp.down_proj.weight"], w[p_ + "post_attention_layernorm.weight"],
+                                 m.cfg.rms_norm_eps, m.h, m.qn, m.I, m.qkv_n, m.nh, m.nkv, m.hd, m.block_size, li, m.chain_gr, m.chain_gen,
+                                 m.chain_err, h_out=m.buf_h if last else None, **nxt)
+            kinds = [("chain_segment", (m.h * m.qn + 3 * m.I * m.h) * 2 + m.qkv_n * m.h * 2 * (L - 1) // L, seg)]
         runner.d_slots[:max(M, 1)].fill_(-1)          # timing only: do not touch the KV cache
         for kind, b, launch in kinds:
+            if chain:
+                H_.chain_tick(m.chain_gen)
             for li in range(min(2, L)):
                 launch(li)
             reps = max(2, 128 // L)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with capture(graph):
+                if chain:
+                    H_.chain_tick(m.chain_gen)       # (a forward's segments carry its generation in their hand-off tags)
                 for li in range(L):
                     launch(li)
             graph.replay()
@@ -216,7 +238,9 @@ def gemm_roofline(legs):
     dom = per_kind[dom_tag]
     dom_bytes = dom["MB"] * 1e6
     achieved = dom_bytes / (dom["us"] * 1e-6)
-    out = {"bound": "hbm", "kernel": f"{dom_tag} (skinny weight-streaming GEMM: gemm_wf_kernel / gemm_fused_kernel, csrc/gemm*.hip)",
+    out = {"bound": "hbm", "kernel": (f"{dom_tag} (chain_segment_kernel, csrc/chain.hip: o_proj + gate_up + down_proj + next QKV of a single-token "
+                                      f"forward in one resident launch)" if "chain_segment" in dom_tag else
+                                      f"{dom_tag} (skinny weight-streaming GEMM: gemm_wf_kernel / gemm_fused_kernel, csrc/gemm*.hip)"),
            "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4),
            "traffic": None, "bytes_per_launch": int(dom_bytes), "avg_launch_us": dom["us"],
            "share_of_gemm_time": round(dom["us"] * dom["launches_per_step"] / (tot_time * 1e6), 4),
