@@ -36,3 +36,10 @@ def test_product_never_imports_oracle():
                     if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_integration_doc_covers_every_symbol():
+    """INTEGRATION.md shows the reference-side binding (or states the role) of every entry point the header declares."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [s for s in header_symbols() if s not in doc]
+    assert not missing, missing
