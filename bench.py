@@ -38,7 +38,8 @@ depend on the pair.
 
 Extra objects on the line: ``roofline`` (dominant kernel family = the skinny weight-streaming GEMMs, timed with HIP
 events on the launch stream while rotating through all layers' weights so nothing is cache-resident; per-rank shard
-shapes at N > 1), ``collective`` (N > 1: which all-reduce carries the tensor-parallel sums and its measured latency)
+shapes at N > 1; where the draft's single-token forwards run as one resident launch per layer, csrc/chain.hip, that launch is
+timed as its own kind ``draft.chain_segment.M1``), ``collective`` (N > 1: which all-reduce carries the tensor-parallel sums and its measured latency)
 and ``cpu_baseline`` (the oracle engine -- the reference's own modules restated -- timed on the host cores on a
 bounded sample; baseline only).
 """
