@@ -29,6 +29,10 @@
 extern "C" {
 #endif
 
+/* Bumped whenever a signature or a semantic of this header changes; ssd_abi_version() returns the value the library was built
+ * with, so a consumer compiled against another header can tell (tests/abi_consumer.c does). */
+#define SSD_HIP_ABI_VERSION 2
+
 #define SSD_OK 0
 #define SSD_ERR_SHAPE (-1)
 #define SSD_ERR_LAUNCH (-2)
@@ -78,10 +82,6 @@ int ssd_rmsnorm_pair(const void* x0_rows, const void* weight0, const void* x1_ro
  * SSD_EPI_SILU_FRAG additionally fuses SiluAndMul.forward -- ssd/layers/activation.py:11-14. */
 int ssd_gemm_wf(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K, int ldy,
                 int epilogue, void* stream);
-/* Same with an explicit decomposition: nt = 16-row groups per workgroup (1,2,4), waves = K-split (1..16). */
-int ssd_gemm_wf_cfg(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K, int ldy,
-                    int epilogue, int nt, int waves, void* stream);
-
 /* The same F.linear for matrices with too few 16-row groups to fill the chip (csrc/gemm_sk.hip; the 1B draft's o_proj /
  * down_proj): K is split across `splits` workgroups per row group, the last one to arrive reduces the fp32 partials in a
  * fixed order.  workspace >= (N/16)*splits KiB; counters >= N/16 uint32, zeroed once.  M <= 16, bf16 rows. */
@@ -106,10 +106,6 @@ int ssd_gemm_parts(const void* x_frag, const void* w_frag, const void* bias, voi
 int ssd_gemm_pf_workspace_bytes(int M, int N, int K, int64_t* bytes);
 int ssd_gemm_pf(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K, int ldy,
                 int epilogue, void* workspace, int64_t workspace_bytes, int splits, void* stream);
-/* Same with an explicit decomposition: nt = 16-row groups per wave (2 or 4; a workgroup owns 4*nt), splits of K. */
-int ssd_gemm_pf_cfg(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K, int ldy,
-                    int epilogue, void* workspace, int64_t workspace_bytes, int nt, int splits, void* stream);
-
 /* Fused decode-layer GEMM for M <= 16 (csrc/gemm_fused.hip): [residual add + RMSNorm] -> F.linear ->
  * [RoPE + paged KV store | SiLU*mul | rows] in ONE launch; replaces add_norm_forward (layernorm.py:76-88) + F.linear
  * (linear.py:97-98) + RotaryEmbedding.forward (rotary_embedding.py:40-60) + store_kvcache (attention.py:10-41), or
@@ -160,18 +156,6 @@ int ssd_attn_paged(const void* q_rows, const void* k_cache, const void* v_cache,
                    int tree_mq, int tree_step, int tree_F, const int32_t* tree_jidx, int splits, int flags,
                    void* ws_o, void* ws_ml, void* out_rows, void* out_frag, void* stream);
 
-/* ssd_rope_store_kv + ssd_attn_paged in ONE launch for the decode-side shapes (round 4): q_per_seq <= 32 new tokens per sequence
- * (single-token decode, K+1-row verify / glue, the MQ_LEN-branch tree step), context within one workgroup scan (buckets <= 1024).
- * qkv_rows: the QKV projection's rows [T][(nh + 2 nkv) * hd]; every workgroup norms (q_norm_w / k_norm_w: Qwen3's per-head
- * RMSNorm, or NULL), rotates and stores the new K / V rows of its (sequence, kv head), then builds its Q fragments from the raw
- * rows with the same arithmetic: bit-identical to the two calls.  Replaces ssd/models/qwen3.py:96-104 + ssd/layers/
- * rotary_embedding.py:40-60 + ssd/layers/attention.py:10-41 + :105-131 wherever RoPE cannot ride the QKV GEMM's epilogue. */
-int ssd_attn_paged_qkv(const void* qkv_rows, const int64_t* positions, const float* cos_sin, const int32_t* slot_mapping,
-                       const void* q_norm_w, const void* k_norm_w, float eps, int qkv_perm, void* k_cache, void* v_cache,
-                       const int32_t* block_tables, int max_blocks, const int32_t* context_lens, int q_per_seq, int B, int T,
-                       int nh, int nkv, int hd, int block_size, float scale, int mode, int tree_K, int tree_mq, int tree_step,
-                       int tree_F, const int32_t* tree_jidx, int flags, void* out_rows, void* out_frag, void* stream);
-
 /* Attention + o_proj in ONE launch for the single-GPU drafts' decode / glue forwards: flash_attn_with_kvcache
  * (ssd/layers/attention.py:105-111,126-131) followed by RowParallelLinear o_proj (ssd/layers/linear.py:186-199, no all-reduce
  * at tp = 1).  One sequence, T causal (bottom-right aligned) query rows; parts = fp32 slabs [nkv][T][N], slab h = o_proj
@@ -218,6 +202,23 @@ int ssd_chain_segment(const void* a_frag, const void* res_in, void* res_out, voi
                       const int64_t* positions, const float* cos_sin, const int32_t* slots, void* q_out, void* k_cache, void* v_cache,
                       int h, int qn, int I, int qkv_n, int nh, int nkv, int hd, int block_size, int layer, void* granules,
                       const void* gen, void* err, void* stream);
+
+/* The same layer segment for 2..30 token rows (csrc/tree_segment.hip): the MQ_LEN-branch tree-decode step of asynchronous speculation
+ * (DraftRunner._decode_tree, ssd/engine/draft_runner.py:713-812: K forwards of (K+1)*F rows through LlamaDecoderLayer.forward,
+ * ssd/models/llama3.py:128-199) and the K+1-row glue decode (draft_runner.py:560-640).  Operands as ssd_chain_segment with M rows:
+ * a_frag frag [M][qn], res_in / res_out / h_out rows [M][h] (res_out != res_in), positions / slots [M], q_out rows [M][nh*hd].
+ * 256 resident workgroups; the all-to-all edges are 16-byte write-through stores + one flag word per producer workgroup, payload
+ * read with sc1 loads; x^ of all M rows lives in LDS.  h in {1024, 2048}; no biases, no q/k norm.
+ *   workspace  ssd_tree_segment_workspace_bytes(h, I) bytes, zeroed ONCE at allocation (flags + the three hand-off buffers)
+ *   gen / err  as ssd_chain_segment (one ssd_chain_tick per forward)
+ * Returns SSD_ERR_LAUNCH when the device cannot keep 256 of its workgroups resident at once (they wait for each other). */
+int ssd_tree_segment_workspace_bytes(int h, int I);
+int ssd_tree_segment_ok(int M, int h, int qn, int I, int qkv_n, int nh, int nkv, int hd);
+int ssd_tree_segment(const void* a_frag, const void* res_in, void* res_out, void* h_out, const void* w_o, const void* w_gu,
+                     const void* w_d, const void* w_qkv_next, const void* ln_post, const void* ln_next, float eps,
+                     const int64_t* positions, const float* cos_sin, const int32_t* slots, void* q_out, void* k_cache, void* v_cache,
+                     int M, int h, int qn, int I, int qkv_n, int nh, int nkv, int hd, int block_size, int layer, void* workspace,
+                     const void* gen, void* err, void* stream);
 int ssd_argmax_parts(const float* part_val, const int32_t* part_idx, int nparts, long part_stride, int T, long idx_offset,
                      int64_t* out, int64_t* out2, int64_t* out3, long out3_stride, float* out_val, void* stream);
 int ssd_argmax_parts_verify(const float* part_val, const int32_t* part_idx, int nparts, long part_stride,
@@ -330,12 +331,6 @@ int ssd_allreduce_gr_bf16(const void* in, void* out, long n, int rank, int world
 int ssd_allreduce_add_rmsnorm_gr_bf16(const void* in, const void* res_in, void* res_out, const void* weight, float eps,
                                       void* out_rows, void* out_frag, int T, int H, int rank, int world, void* const* inboxes,
                                       long gr_cap, void* counters, void* err, long spin_budget, void* stream);
-
-/* A stream restricted to the compute units whose bit is set in cu_mask (bit i of word i/32 = CU i): partitions the chip
- * between the co-located draft server and the target's verify of asynchronous speculation (the reference gives the draft
- * a GPU of its own, ssd/engine/llm_engine.py:82-89; on one GPU the two rounds otherwise serialise).  Start-up only. */
-int ssd_stream_create_cu_mask(void** out_stream, const uint32_t* cu_mask, int mask_words);
-int ssd_stream_destroy(void* stream);
 
 #ifdef __cplusplus
 }

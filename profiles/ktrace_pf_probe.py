@@ -15,7 +15,7 @@ import ssd_amd.hip.lib as L  # noqa: E402
 L.lib_path = lambda: os.path.join(ROOT, "ssd_amd", "_lib", "libssdhip_trace.so")
 from ssd_amd.hip import ops as H  # noqa: E402
 
-MARKS, MAXWG, SLOTS = 8, 4096, 32
+MARKS, MAXWG, SLOTS = 12, 4096, 32
 NAMES = ["entry", "prologue loads issued", "first barrier (x staged)", "k loop done", "stores issued"]
 
 

@@ -24,11 +24,12 @@ from ssd_amd.engine.llm_engine import hip_runner_factory  # noqa: E402
 from ssd_amd.model_config import PRESETS  # noqa: E402
 from ssd_amd.utils.topology import Topology  # noqa: E402
 
-MARKS, MAXWG, SLOTS = 8, 4096, 32
+MARKS, MAXWG, SLOTS = 12, 4096, 32
 NAMES = {0: "fused norm+QKV+RoPE+store (M<=16)", 1: "fused norm+gate_up+SiLU (M<=16)", 2: "fused GEMM without prologue", 3: "qkv+RoPE m32",
          4: "gemm_sp o_proj -> slabs", 5: "gemm_sp down_proj -> slabs", 6: "attention", 7: "attention + o_proj -> slabs",
          8: "gemm_wf gate_up + SiLU", 9: "gemm_wf rows (LM head)", 10: "rmsnorm over slabs", 11: "rmsnorm",
-         12: "chain segment (o -> gate_up -> down -> next QKV), csrc/chain.hip", 13: "chain segment, last layer (o -> gate_up -> down)"}
+         12: "chain segment (o -> gate_up -> down -> next QKV), csrc/chain.hip", 13: "chain segment, last layer (o -> gate_up -> down)",
+         14: "M-row segment (o -> gate_up -> down -> next QKV), csrc/tree_segment.hip", 15: "M-row segment, last layer (o -> gate_up -> down)"}
 MARK_NAMES = {
     0: ["entry", "weight loads issued", "x / slabs arrived (barrier)", "x^ in LDS (barrier)", "MFMAs done (weights arrived)", "combine barrier", "stores issued"],
     1: ["entry", "weight loads issued", "x / slabs arrived (barrier)", "x^ in LDS (barrier)", "MFMAs done (weights arrived)", "combine barrier", "stores issued"],
@@ -45,6 +46,10 @@ MARK_NAMES = {
          "edge 3: gathered, x^ ready", "QKV + RoPE stored"],
     13: ["entry", "o_proj published", "edge 1: gathered, x^ ready", "gate_up published", "edge 2: activations gathered", "down_proj published",
          "edge 3: gathered, rows stored"],
+    14: ["entry", "o_proj rows stored", "o_proj published", "edge 1: all flags seen", "add + norm done, x^ in LDS", "gate_up published",
+         "edge 2: all flags seen, x issued", "down_proj published", "edge 3: all flags seen", "add + norm done, x^ in LDS", "QKV + RoPE stored"],
+    15: ["entry", "o_proj rows stored", "o_proj published", "edge 1: all flags seen", "add + norm done, x^ in LDS", "gate_up published",
+         "edge 2: all flags seen, x issued", "down_proj rows stored"],
 }
 
 
@@ -93,7 +98,7 @@ def main():
     dr = hip_runner_factory(cfg, PRESETS[name], is_draft=True, topo=topo, num_kvcache_blocks=10)
     lib = L.load_library()
     buf = torch.zeros(SLOTS * MAXWG * MARKS, dtype=torch.int64, device="cuda")
-    for tu in ("gemm", "gemm_fused", "gemm_sk", "attention", "norm", "chain"):
+    for tu in ("gemm", "gemm_fused", "gemm_sk", "attention", "norm", "chain", "tree_segment"):
         fn = getattr(lib, f"ssd_ktrace_set_{tu}")
         fn.argtypes, fn.restype = [C.c_void_p], C.c_int
         assert fn(buf.data_ptr()) == 0, tu
@@ -114,10 +119,10 @@ def main():
     glue = torch.cat([torch.tensor([rec], device=toks.device), toks], dim=1)
     fan, jl = [[F] * (K + 1)], [[j for j in range(K + 1) for _ in range(F)]]
     settle(lambda: dr.draft_glue_fork(glue, nt, tables, fan))
-    report(buf, f"{name}: glue forward, M = {K + 1}", [0, 6, 7, 4, 1, 5, 10, 11, 9])
+    report(buf, f"{name}: glue forward, M = {K + 1}", [0, 6, 14, 7, 4, 1, 5, 15, 10, 11, 9])
     forks = dr.draft_glue_fork(glue, nt, tables, fan)
     settle(lambda: dr.draft_tree(forks, nt, tables, jl))
-    report(buf, f"{name}: tree step, M = {F * (K + 1)} (last layer + tail of the last step)", [3, 6, 4, 10, 8, 5, 11, 9])
+    report(buf, f"{name}: tree step, M = {F * (K + 1)} (last layer + tail of the last step)", [3, 6, 14, 4, 10, 8, 5, 15, 11, 9])
 
 
 if __name__ == "__main__":

@@ -461,6 +461,7 @@ allreduce_add_rmsnorm_gr_kernel(const unsigned long long* __restrict__ in, const
 
 // ---- host-side helpers (setup time only; never called on the hot path) ----
 extern "C" int ssd_comm_alloc(void** out, long bytes) {
+  if (!out || bytes <= 0) return SSD_ERR_ARG;
   void* p = nullptr;
   if (hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained) != hipSuccess) return SSD_ERR_LAUNCH;
   if (hipMemset(p, 0, (size_t)bytes) != hipSuccess) return SSD_ERR_LAUNCH;
@@ -468,8 +469,12 @@ extern "C" int ssd_comm_alloc(void** out, long bytes) {
   *out = p;
   return SSD_OK;
 }
-extern "C" int ssd_comm_free(void* p) { return hipFree(p) == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH; }
+extern "C" int ssd_comm_free(void* p) {
+  if (!p) return SSD_ERR_ARG;
+  return hipFree(p) == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
 extern "C" int ssd_comm_ipc_export(void* p, void* handle64) {
+  if (!p || !handle64) return SSD_ERR_ARG;
   hipIpcMemHandle_t h;
   if (hipIpcGetMemHandle(&h, p) != hipSuccess) return SSD_ERR_LAUNCH;
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "ipc handle size");
@@ -477,6 +482,7 @@ extern "C" int ssd_comm_ipc_export(void* p, void* handle64) {
   return SSD_OK;
 }
 extern "C" int ssd_comm_ipc_open(const void* handle64, void** out) {
+  if (!handle64 || !out) return SSD_ERR_ARG;
   hipIpcMemHandle_t h;
   memcpy(&h, handle64, 64);
   void* p = nullptr;
@@ -484,7 +490,10 @@ extern "C" int ssd_comm_ipc_open(const void* handle64, void** out) {
   *out = p;
   return SSD_OK;
 }
-extern "C" int ssd_comm_ipc_close(void* p) { return hipIpcCloseMemHandle(p) == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH; }
+extern "C" int ssd_comm_ipc_close(void* p) {
+  if (!p) return SSD_ERR_ARG;
+  return hipIpcCloseMemHandle(p) == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
 
 // in / out: bf16 [n] device buffers (n % 4 == 0, 8-byte aligned; in == out allowed); slots / flags: per-rank pointers
 // (own allocation for `rank`, IPC-opened mappings for the peers); slot_elems: capacity of one staging slot in bf16

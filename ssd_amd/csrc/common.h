@@ -12,10 +12,10 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 
-#define SSD_OK 0
-#define SSD_ERR_SHAPE -1
-#define SSD_ERR_LAUNCH -2
-#define SSD_ERR_ARG -3
+// The public C ABI: every translation unit sees the declarations its extern "C" definitions must match (a mismatch is a compile
+// error: conflicting types), and the error codes / ABI version exist in ONE place.
+#include "ssd_hip.h"
+#include "ssd_hip_tune.h"
 
 __device__ __forceinline__ float bf2f(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
 
@@ -27,6 +27,16 @@ __device__ __forceinline__ uint32_t f2bf(float f) {
   return u >> 16;
 }
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return f2bf(lo) | (f2bf(hi) << 16); }
+
+// The same conversion on gfx950's converter (v_cvt_pk_bf16_f32: one instruction for two values instead of ~12): round-to-nearest-even,
+// bit-identical to f2bf on every non-NaN input (checked exhaustively over all 2^32 patterns on the MI355X by ssd_selftest_bf16_cvt,
+// tests/test_hip_ops.py); used where a kernel converts tens of values per thread (csrc/tree_segment.hip).
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ uint32_t pack_bf2_hw(float lo, float hi) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
+}
+__device__ __forceinline__ float round_bf_hw(float f) { return bf2f(pack_bf2_hw(f, 0.f) & 0xffffu); }
 
 // Round an fp32 value through bf16 (models "store bf16, reload" between two reference kernels).
 __device__ __forceinline__ float round_bf(float f) { return bf2f(f2bf(f)); }
@@ -130,7 +140,7 @@ static inline void ssd_pick_skinny_cfg(int groups, int KT, bool silu_pairs, int*
 // time to the first weight tile, time after the last, boundary to the next kernel.
 // ---------------------------------------------------------------------------------------------------------------------
 #ifdef SSD_KTRACE
-#define KT_MARKS 8
+#define KT_MARKS 12
 #define KT_MAXWG 4096
 #define KT_SLOTS 32
 static __device__ unsigned long long* kt_dev_buf;       // one copy per translation unit (no -fgpu-rdc): ssd_ktrace_set_<tu>

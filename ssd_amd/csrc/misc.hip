@@ -1,9 +1,29 @@
 // Small device-side state kernels that keep the draft->verify loop free of host round trips.
 #include "common.h"
 
-#define SSD_HIP_ABI_VERSION 1
 
 extern "C" int ssd_abi_version(void) { return SSD_HIP_ABI_VERSION; }
+
+// Diagnostic: the hardware fp32 -> bf16 conversion (common.h pack_bf2_hw) against the integer form (f2bf) over ALL 2^32 fp32 bit
+// patterns.  counts[0] = mismatches on non-NaN inputs (must be 0), counts[1] = NaN inputs whose result is not a NaN (must be 0).
+__global__ void bf16_cvt_selftest_kernel(unsigned long long* counts) {
+  unsigned long long bad = 0, badnan = 0;
+  const uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) << 12;
+  for (uint32_t i = 0; i < 4096u; ++i) {
+    const uint32_t u = base + i;
+    const float f = __uint_as_float(u);
+    const uint32_t sw = f2bf(f), hw = pack_bf2_hw(f, 0.f) & 0xffffu, hw2 = pack_bf2_hw(0.f, f) >> 16;
+    if ((u & 0x7fffffffu) > 0x7f800000u) badnan += ((hw & 0x7fffu) <= 0x7f80u) || ((hw2 & 0x7fffu) <= 0x7f80u);
+    else bad += (sw != hw) || (sw != hw2);
+  }
+  if (bad) atomicAdd(counts, bad);
+  if (badnan) atomicAdd(counts + 1, badnan);
+}
+extern "C" int ssd_selftest_bf16_cvt(void* counts2, void* stream) {
+  if (!counts2) return SSD_ERR_ARG;
+  hipLaunchKernelGGL(bf16_cvt_selftest_kernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, (unsigned long long*)counts2);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
 
 // After one single-token draft forward + argmax (`next[b]`): record the token as speculation step+1 and
 // turn the static decode inputs into the inputs of the next draft step -- what the reference does on the
@@ -95,5 +115,6 @@ extern "C" int ssd_stream_create_cu_mask(void** out_stream, const uint32_t* cu_m
   return SSD_OK;
 }
 extern "C" int ssd_stream_destroy(void* stream) {
+  if (!stream) return SSD_ERR_ARG;          // the null stream is not ours to destroy
   return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }

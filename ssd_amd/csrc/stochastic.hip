@@ -146,6 +146,7 @@ extern "C" int ssd_sample_rows(const void* logits, long ld, int T, int V, const 
 
 __global__ void rng_advance_kernel(uint64_t* rng) { *rng = mix64(*rng + 0x632be59bd9b4e019ull); }
 extern "C" int ssd_rng_advance(void* rng_state, void* stream) {
+  if (!rng_state) return SSD_ERR_ARG;
   hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (uint64_t*)rng_state);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }

@@ -113,6 +113,7 @@ class ModelRunner:
         self.d_packed = torch.zeros(B, self.K + 3, dtype=torch.int64, **dev)
         self.h_packed = torch.zeros(B, self.K + 3, dtype=torch.int64).pin_memory()
         self.h_next = torch.zeros(max(self.max_decode_tokens, B), dtype=torch.int64).pin_memory()
+        self._chain_err_host = torch.zeros(1, dtype=torch.int32).pin_memory()     # mirror of model.chain_err (_post_chain_err)
         self._setup_custom_ar(custom_ar)
         watchdog.stage("engine_init")           # (whatever the set-up's outcome: its stage limits end here)
         self._stage: dict = {}
@@ -191,9 +192,28 @@ class ModelRunner:
         if ar is not None and ar.failed():
             raise RuntimeError("one-shot all-reduce timed out waiting for a peer; results of this step are invalid "
                                "(rerun with SSD_CUSTOM_AR=0 to use RCCL)")
-        if getattr(self.model, "chain_seg", False) and int(self.model.chain_err.item()):
-            raise RuntimeError("a bounded wait inside the resident single-token chain (csrc/chain.hip) gave up; the forwards since the "
-                               "last check are invalid (rerun with SSD_CHAIN_SEG=0 for the separate launches)")
+        if self._has_chain_err() and (int(self._chain_err_host[0]) or int(self.model.chain_err.item())):
+            self._raise_chain_err()
+
+    # The resident layer segments (csrc/chain.hip, csrc/tree_segment.hip) report a given-up bounded wait in a device word.  The
+    # draft-side paths never read tokens on the host themselves (speculate_chain / draft_jit / draft_glue_fork / draft_tree /
+    # deposit_pending return device tensors), so each of them mirrors the word into pinned host memory behind its launches
+    # (_post_chain_err: one 4-byte async copy) and looks at the mirror of the PREVIOUS call on entry (_check_chain_host: no sync; a
+    # host sync always lies between two rounds -- the verify read-back, or the draft server's cache-lookup read-back).
+    def _has_chain_err(self) -> bool:
+        return getattr(self.model, "chain_seg", False) or getattr(self.model, "tree_seg", False)
+
+    def _raise_chain_err(self):
+        raise RuntimeError("a bounded wait inside a resident layer segment (csrc/chain.hip / csrc/tree_segment.hip) gave up; the draft "
+                           "forwards since the last check are invalid (rerun with SSD_CHAIN_SEG=0 SSD_TREE_SEG=0 for the separate launches)")
+
+    def _post_chain_err(self) -> None:
+        if self._has_chain_err():
+            self._chain_err_host.copy_(self.model.chain_err, non_blocking=True)
+
+    def _check_chain_host(self) -> None:
+        if self._has_chain_err() and int(self._chain_err_host[0]):
+            self._raise_chain_err()
 
     # ---------------------------------------------------------------------------------------------
     # host -> device input staging
@@ -516,6 +536,7 @@ class ModelRunner:
         speculations [B, K+1] = (recovery, x_1..x_K); nothing is read back.  The reference's (K+1)-th forward, which
         only deposits x_K's KV, is deferred to `deposit_pending`: that KV is needed only if x_K gets accepted."""
         B, K = len(seqs), self.K
+        self._check_chain_host()
         temps = self._seq_temps(seqs)
         sample = any(t > 0 for t in temps)
         key = ("decode_chain_s" if sample else "decode_chain", B)
@@ -537,6 +558,7 @@ class ModelRunner:
         if self._launch(key, chain) == "captured":
             stage()                      # the warm-up + capture runs disturbed the chained state
             self.graphs[(*key, self._ctx_hint)].replay()
+        self._post_chain_err()
         return self.d_spec[:B]
 
     @torch.inference_mode()
@@ -552,6 +574,7 @@ class ModelRunner:
             self._stage_set = 0
         if self._launch(("decode_deposit", B), lambda: self._body_decode(B, False, head=False)) == "captured":
             self.graphs[("decode_deposit", B, self._ctx_hint)].replay()     # idempotent: same token, same slot
+        self._post_chain_err()
 
     def logits_q(self, B: int) -> torch.Tensor:
         """[B, K, V] draft logits of the last sampled chain (temperature > 0 only)."""
@@ -668,6 +691,7 @@ class ModelRunner:
         """K chained single-token decodes from the recovery token at P = n - 1 (no host sync).  With some
         temperature > 0 the tokens are sampled and the K rows of draft logits are kept for `logits_q`."""
         B, K = len(rec), self.K
+        self._check_chain_host()
         sample = temps is not None and any(t > 0 for t in temps)
         key = ("decode_chain_s" if sample else "decode_chain", B)
         self._note_ctx(max(num_tokens) + self._async_lookahead())
@@ -693,6 +717,7 @@ class ModelRunner:
         if self._launch(key, chain) == "captured":
             stage()
             self.graphs[(*key, self._ctx_hint)].replay()
+        self._post_chain_err()
         return self.d_spec[:B, 1:].clone()
 
     def _body_glue_fork(self, B: int) -> None:
@@ -725,6 +750,7 @@ class ModelRunner:
     def draft_glue_fork(self, glue_ids: torch.Tensor, num_tokens, tables, fan_lists) -> torch.Tensor:
         """Glue decode over [rec, x_1..x_K] at P..P+K, then top-F fork per position on the device."""
         self._ensure_tree_buffers()
+        self._check_chain_host()
         B, K = glue_ids.shape[0], self.K
         key = ("glue_fork", B)
         self._note_ctx(max(num_tokens) + self._async_lookahead())
@@ -748,6 +774,7 @@ class ModelRunner:
         if self._launch(key, lambda: self._body_glue_fork(B)) == "captured":
             stage()
             self.graphs[(*key, self._ctx_hint)].replay()
+        self._post_chain_err()
         return self.d_forks[:B].clone()
 
     def _body_tree(self, B: int, d: int, sample: bool = False, mq: int | None = None) -> None:
@@ -824,6 +851,7 @@ class ModelRunner:
         if self._launch(key, all_steps) == "captured":
             self.d_ids[:T].copy_(forks.reshape(-1))      # the eager warm-up consumed the inputs
             self.graphs[(*key, self._ctx_hint)].replay()
+        self._post_chain_err()
         return self.d_tree_tokens[:T].clone()
 
     def tree_logits(self, T: int) -> torch.Tensor:

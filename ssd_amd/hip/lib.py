@@ -16,7 +16,9 @@ _LIB = None
 
 c_void_p, c_int, c_long, c_float, c_int64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_int64
 
-# name -> argtypes, exactly include/ssd_hip.h
+ABI_VERSION = 2       # include/ssd_hip.h SSD_HIP_ABI_VERSION (tests/test_abi.py compares the two)
+
+# name -> argtypes, exactly include/ssd_hip.h (+ include/ssd_hip_tune.h)
 SIGNATURES = {
     "ssd_abi_version": [],
     "ssd_rows_to_frag": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
@@ -58,6 +60,12 @@ SIGNATURES = {
     "ssd_chain_segment": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                           c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "ssd_tree_segment_workspace_bytes": [c_int, c_int],
+    "ssd_tree_segment_ok": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
+    "ssd_tree_segment": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                         c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "ssd_selftest_bf16_cvt": [c_void_p, c_void_p],
     "ssd_gemm_wf_argmax": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "ssd_argmax_parts": [c_void_p, c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p],
     "ssd_argmax_parts_verify": [c_void_p, c_void_p, c_int, c_long, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
@@ -132,7 +140,7 @@ def load_library():
             raise SsdHipError(f"libssdhip.so does not export {name}") from e
         fn.argtypes = args
         fn.restype = c_int
-    if lib.ssd_abi_version() != 1:
+    if lib.ssd_abi_version() != ABI_VERSION:
         raise SsdHipError("libssdhip.so ABI version mismatch")
     _LIB = lib
     return lib

@@ -212,6 +212,28 @@ def chain_segment(a_frag, res_in, res_out, w_o, w_gu, w_d, ln_post, eps: float, 
                                             _stream()), "ssd_chain_segment")
 
 
+def tree_segment_ok(M: int, h: int, qn: int, I: int, qkv_n: int, nh: int, nkv: int, hd: int) -> bool:
+    return load_library().ssd_tree_segment_ok(M, h, qn, I, qkv_n, nh, nkv, hd) == 0
+
+
+def tree_segment_workspace_bytes(h: int, I: int) -> int:
+    return load_library().ssd_tree_segment_workspace_bytes(h, I)
+
+
+def tree_segment(a_frag, res_in, res_out, w_o, w_gu, w_d, ln_post, eps: float, M: int, h: int, qn: int, I: int, qkv_n: int, nh: int,
+                 nkv: int, hd: int, block_size: int, layer: int, workspace, gen, err, *, h_out=None, w_qkv_next=None, ln_next=None,
+                 positions=None, cos_sin=None, slots=None, q_out=None, k_cache=None, v_cache=None):
+    """chain_segment for M token rows (csrc/tree_segment.hip): the tree-decode step / the glue decode of the async draft."""
+    _check(load_library().ssd_tree_segment(_p(a_frag), _p(res_in), _p(res_out), _p(h_out), _p(w_o), _p(w_gu), _p(w_d), _p(w_qkv_next),
+                                           _p(ln_post), _p(ln_next), eps, _p(positions), _p(cos_sin), _p(slots), _p(q_out), _p(k_cache),
+                                           _p(v_cache), M, h, qn, I, qkv_n, nh, nkv, hd, block_size, layer, _p(workspace), _p(gen), _p(err),
+                                           _stream()), "ssd_tree_segment")
+
+
+def selftest_bf16_cvt(counts2):
+    _check(load_library().ssd_selftest_bf16_cvt(_p(counts2), _stream()), "ssd_selftest_bf16_cvt")
+
+
 def argmax_parts(part_val, part_idx, nparts: int, part_stride: int, T: int, out=None, out2=None, out3=None, out3_stride: int = 0,
                  out_val=None, idx_offset: int = 0):
     _check(load_library().ssd_argmax_parts(_p(part_val), _p(part_idx), nparts, part_stride, T, idx_offset, _p(out), _p(out2), _p(out3),

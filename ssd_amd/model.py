@@ -129,10 +129,21 @@ class HipDecoder:
         _validated = (self.h, self.qn, self.I, self.qkv_n, self.hd) == (2048, 2048, 8192, 3072, 64)
         self.chain_seg = ((_cs == "1" or (_cs == "auto" and _validated)) and not cfg.qk_norm and tp_size == 1 and not self.use_coll
                           and taps is None and H.chain_segment_ok(self.h, self.qn, self.I, self.qkv_n, self.nh, self.nkv, self.hd))
+        # the same segment for 2..30 token rows (csrc/tree_segment.hip): the async draft's MQ_LEN-row tree steps and its K+1-row glue
+        # decode run attention + ONE resident launch per layer instead of 7 launches.  "auto" = on at the 1B draft's geometry
+        # (validated and measured there: tests/test_hip_tree_segment.py, profiles/r05_draft_probe.txt); 1 = every accepted shape.
+        _ts = os.environ.get("SSD_TREE_SEG", "auto")
+        self.tree_seg = ((_ts == "1" or (_ts == "auto" and _validated)) and not cfg.qk_norm and tp_size == 1 and not self.use_coll
+                         and taps is None and max_tokens >= 2
+                         and H.tree_segment_ok(2, self.h, self.qn, self.I, self.qkv_n, self.nh, self.nkv, self.hd))
         if self.chain_seg:
             self.chain_gr = z(H.chain_granule_bytes(self.h, self.I) // 8, dtype=torch.int64)
+        if self.chain_seg or self.tree_seg:
             self.chain_gen = z(1, dtype=torch.int32)
             self.chain_err = z(1, dtype=torch.int32)
+        if self.tree_seg:
+            self.tree_ws = z(H.tree_segment_workspace_bytes(self.h, self.I) // 8, dtype=torch.int64)
+            self.buf_res_b = z(min(T, 32), self.h)        # the residual ping-pongs: every workgroup re-reads a layer's input residual
         self._prefill_waves = int(os.environ.get("SSD_ATTN_PREFILL_WAVES", "0"))
         self._last_parts = False        # set by forward() for the compute_logits that follows it
         pt = min(T, 32)
@@ -389,6 +400,41 @@ class HipDecoder:
                             cfg.rms_norm_eps, self.h, self.qn, self.I, self.qkv_n, self.nh, self.nkv, self.hd, self.block_size, li,
                             self.chain_gr, self.chain_gen, self.chain_err, h_out=self.buf_h if last else None, **nxt)
 
+    def tree_plan(self, T: int, meta: AttnMeta) -> bool:
+        """The resident M-row layer segment (csrc/tree_segment.hip): decode-side forwards of 2..30 rows (tree steps, glue), no biases."""
+        return (self.tree_seg and 2 <= T <= 32 and meta.cu_q is None and "model.layers.0.self_attn.qkv_proj.bias" not in self.w
+                and H.tree_segment_ok(T, self.h, self.qn, self.I, self.qkv_n, self.nh, self.nkv, self.hd))
+
+    def _forward_tree_seg(self, positions, T: int, meta: AttnMeta, splits: int, attn_waves: int) -> None:
+        """embedding rows in buf_h -> [norm + QKV + RoPE + KV store of layer 0] -> per layer: attention, segment."""
+        cfg, w = self.cfg, self.w
+        L = cfg.num_layers
+        scale = self.hd ** -0.5
+        res = [self.buf_res, self.buf_res_b]
+        start = L % 2               # layer li reads res[(start + li) % 2] and writes the other: the last layer's lands in buf_res
+        H.chain_tick(self.chain_gen)
+        H.rmsnorm(self.buf_h, w["model.layers.0.input_layernorm.weight"], cfg.rms_norm_eps, T, self.h, res_in=None, res_out=res[start],
+                  out_frag=self.buf_xf)
+        H.gemm_fused(w["model.layers.0.self_attn.qkv_proj.weight"], T, self.qkv_n, self.h, H.FEPI_QKV_ROPE, x_frag=self.buf_xf,
+                     positions=positions, cos_sin=self.cos_sin, slots=meta.slot_mapping, q_out=self.buf_q, k_cache=self.kv_cache[0, 0],
+                     v_cache=self.kv_cache[0, 1], nh=self.nh, nkv=self.nkv, hd=self.hd, block_size=self.block_size)
+        for li in range(L):
+            H.attn_paged(self.buf_q, self.kv_cache[li, 0], self.kv_cache[li, 1], meta.block_tables, self.max_blocks,
+                         meta.context_lens, meta.B, T, meta.max_q, self.nh, self.nkv, self.hd, self.block_size, scale,
+                         cu_q=None, q_per_seq=meta.q_per_seq, mode=meta.mode, tree_K=meta.tree_K, tree_mq=meta.tree_mq,
+                         tree_step=meta.tree_step, tree_F=meta.tree_F, tree_jidx=meta.tree_jidx, splits=splits,
+                         ws_o=self.ws_o, ws_ml=self.ws_ml, out_frag=self.buf_af, waves=attn_waves)
+            p = f"model.layers.{li}."
+            last = li + 1 == L
+            nxt = {} if last else dict(
+                w_qkv_next=w[f"model.layers.{li + 1}.self_attn.qkv_proj.weight"], ln_next=w[f"model.layers.{li + 1}.input_layernorm.weight"],
+                positions=positions, cos_sin=self.cos_sin, slots=meta.slot_mapping, q_out=self.buf_q,
+                k_cache=self.kv_cache[li + 1, 0], v_cache=self.kv_cache[li + 1, 1])
+            H.tree_segment(self.buf_af, res[(start + li) % 2], res[(start + li + 1) % 2], w[p + "self_attn.o_proj.weight"],
+                           w[p + "mlp.gate_up_proj.weight"], w[p + "mlp.down_proj.weight"], w[p + "post_attention_layernorm.weight"],
+                           cfg.rms_norm_eps, T, self.h, self.qn, self.I, self.qkv_n, self.nh, self.nkv, self.hd, self.block_size, li,
+                           self.tree_ws, self.chain_gen, self.chain_err, h_out=self.buf_h if last else None, **nxt)
+
     def qkv_attn_plan(self, T: int, meta: AttnMeta, splits: int) -> bool:
         """RoPE (+ Qwen3's q / k norm) + KV store inside the attention launch: decode-side shapes (<= 32 new tokens per sequence,
         fixed rows per sequence), the context scanned inside one workgroup, and only where launch_qkv would otherwise end in a
@@ -514,6 +560,10 @@ class HipDecoder:
         if self.chain_plan(T, meta, splits):
             self._last_parts = False            # the last segment leaves rows (buf_h) + the residual (buf_res) for compute_logits
             self._forward_chain(positions, meta, attn_waves)
+            return
+        if self.tree_plan(T, meta):
+            self._last_parts = False            # rows (buf_h) + the residual (buf_res), as above
+            self._forward_tree_seg(positions, T, meta, splits, attn_waves)
             return
         fuse_ao = parts and self.attn_o_plan(T, meta, splits)
         qkv_attn = not fuse_ao and self.qkv_attn_plan(T, meta, splits)

@@ -117,6 +117,54 @@ def truth_forward(cfg, w: dict, tokens: list[int]) -> torch.Tensor:
     return x @ head.to(D).t()
 
 
+def truth_forward_masked(cfg, w: dict, tokens: list[int], positions: list[int], visible: torch.Tensor) -> torch.Tensor:
+    """truth_forward with explicit RoPE positions and an explicit visibility matrix (bool [T][T], row = query): the exact-arithmetic
+    (float64, nothing rounded) logits of EVERY row of a speculation tree in one pass -- prompt + glue rows causal, tree rows under the
+    structural mask of ssd/engine/helpers/mask_helpers.py:12-21 (oracle/ops.py tree_mask) -- mathematically equal to prefill + glue
+    decode + K cached tree steps.  One layer's fp64 weights at a time."""
+    D = torch.float64
+    T = len(tokens)
+    h = w["model.embed_tokens.weight"][torch.tensor(tokens)].to(D)
+    hd, nh, nkv = cfg.head_dim, cfg.num_heads, cfg.num_kv_heads
+    inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, hd, 2, dtype=D) / hd))
+    fr = torch.tensor(positions, dtype=D)[:, None] * inv[None, :]
+    cos, sin = fr.cos()[:, None, :], fr.sin()[:, None, :]
+
+    def norm(x, wt, eps):
+        return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps) * wt.to(D)
+
+    def rot(x):
+        x1, x2 = x.chunk(2, -1)
+        return torch.cat((x1 * cos - x2 * sin, x2 * cos + x1 * sin), -1)
+
+    mask = torch.zeros(T, T, dtype=D).masked_fill(~visible, float("-inf"))
+    res = None
+    for li in range(cfg.num_layers):
+        p = f"model.layers.{li}."
+        res = h if res is None else h + res
+        x = norm(res, w[p + "input_layernorm.weight"], cfg.rms_norm_eps)
+        qkv = x @ w[p + "self_attn.qkv_proj.weight"].to(D).t()
+        q, k, v = qkv.split([nh * hd, nkv * hd, nkv * hd], -1)
+        q, k, v = q.view(T, nh, hd), k.view(T, nkv, hd), v.view(T, nkv, hd)
+        if cfg.qk_norm:
+            q = norm(q, w[p + "self_attn.q_norm.weight"], cfg.rms_norm_eps)
+            k = norm(k, w[p + "self_attn.k_norm.weight"], cfg.rms_norm_eps)
+        q, k = rot(q), rot(k)
+        g = nh // nkv
+        k, v = k.repeat_interleave(g, 1), v.repeat_interleave(g, 1)
+        s = torch.einsum("qhd,khd->hqk", q, k) * hd ** -0.5 + mask
+        o = torch.einsum("hqk,khd->qhd", s.softmax(-1), v).reshape(T, nh * hd)
+        h = o @ w[p + "self_attn.o_proj.weight"].to(D).t()
+        res = h + res
+        x = norm(res, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
+        gu = x @ w[p + "mlp.gate_up_proj.weight"].to(D).t()
+        a, b = gu.chunk(2, -1)
+        h = (a * torch.sigmoid(a) * b) @ w[p + "mlp.down_proj.weight"].to(D).t()
+    x = norm(h + res, w["model.norm.weight"], cfg.rms_norm_eps)
+    head = w["model.embed_tokens.weight"] if cfg.tie_word_embeddings else w["lm_head.weight"]
+    return x @ head.to(D).t()
+
+
 def eagle_models_from_golden(g):
     """(target ModelConfig, target weights, draft ModelConfig (family eagle3), draft weights incl. d2t, taps, K, F) of
     tests/golden/tiny_eagle3.npz (written by the reference's own LlamaForCausalLM / Eagle3DraftForCausalLM)."""
