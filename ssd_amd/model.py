@@ -129,10 +129,14 @@ class HipDecoder:
         _validated = (self.h, self.qn, self.I, self.qkv_n, self.hd) == (2048, 2048, 8192, 3072, 64)
         self.chain_seg = ((_cs == "1" or (_cs == "auto" and _validated)) and not cfg.qk_norm and tp_size == 1 and not self.use_coll
                           and taps is None and H.chain_segment_ok(self.h, self.qn, self.I, self.qkv_n, self.nh, self.nkv, self.hd))
-        # the same segment for 2..30 token rows (csrc/tree_segment.hip): the async draft's MQ_LEN-row tree steps and its K+1-row glue
-        # decode run attention + ONE resident launch per layer instead of 7 launches.  "auto" = on at the 1B draft's geometry
-        # (validated and measured there: tests/test_hip_tree_segment.py, profiles/r05_draft_probe.txt); 1 = every accepted shape.
+        # the same segment for 2..30 token rows (csrc/tree_segment.hip): attention + ONE resident launch per layer instead of 7
+        # launches.  Measured on MI355X at the 1B draft's geometry (profiles/r05_tree_seg_probe_v1.txt, parity tests/test_hip_tree_segment.py):
+        # the K+1 = 8-row glue decode 0.945 -> 0.857 ms (kept), the 24-row tree step 0.943 -> 0.965 ms (NOT kept: at 24 rows every
+        # all-to-all edge costs ~4.5 us of flag latency + ~5 us to read 96-192 KB of freshly written rows in every workgroup -- what the
+        # six kernel boundaries it replaces cost).  "auto" = on at that geometry for forwards of 2..16 rows;
+        # 1 = every shape and row count the kernel accepts (tests); 0 = off.
         _ts = os.environ.get("SSD_TREE_SEG", "auto")
+        self.tree_seg_rows = 32 if _ts == "1" else 16
         self.tree_seg = ((_ts == "1" or (_ts == "auto" and _validated)) and not cfg.qk_norm and tp_size == 1 and not self.use_coll
                          and taps is None and max_tokens >= 2
                          and H.tree_segment_ok(2, self.h, self.qn, self.I, self.qkv_n, self.nh, self.nkv, self.hd))
@@ -402,7 +406,7 @@ class HipDecoder:
 
     def tree_plan(self, T: int, meta: AttnMeta) -> bool:
         """The resident M-row layer segment (csrc/tree_segment.hip): decode-side forwards of 2..30 rows (tree steps, glue), no biases."""
-        return (self.tree_seg and 2 <= T <= 32 and meta.cu_q is None and "model.layers.0.self_attn.qkv_proj.bias" not in self.w
+        return (self.tree_seg and 2 <= T <= self.tree_seg_rows and meta.cu_q is None and "model.layers.0.self_attn.qkv_proj.bias" not in self.w
                 and H.tree_segment_ok(T, self.h, self.qn, self.I, self.qkv_n, self.nh, self.nkv, self.hd))
 
     def _forward_tree_seg(self, positions, T: int, meta: AttnMeta, splits: int, attn_waves: int) -> None:
