@@ -272,6 +272,12 @@ int ssd_verify_ratio(const void* logits_p, long ld_p, const void* logits_q, long
  * counts/offsets int32 [B][K+1]: fan-out and output offset of each glue position. */
 int ssd_fork_topf(const void* logits_rows, long ld, int V, const int64_t* returned_tokens, const int32_t* counts,
                   const int32_t* offsets, int B, int K, int mq, int64_t* out, void* stream);
+/* The same selection spread over the chip (every row cut into slices of <= 4096 logits, per-slice top-F candidates in `workspace`
+ * -- ssd_fork_topf_workspace_bytes(V, B, K) bytes -- then one wave per row merges them): bit-equal to ssd_fork_topf, two short
+ * launches instead of B*(K+1) workgroups walking whole vocabulary rows F times (84.7 -> ~8 us at V = 128256).  V % 8 == 0. */
+int ssd_fork_topf_workspace_bytes(int V, int B, int K);
+int ssd_fork_topf_split(const void* logits_rows, long ld, int V, const int64_t* returned_tokens, const int32_t* counts,
+                        const int32_t* offsets, int B, int K, int mq, void* workspace, int64_t* out, void* stream);
 
 /* Speculation-cache lookup -- the tensor compare of DraftRunner.hit_cache_and_respond, ssd/engine/draft_runner.py:215-252.
  * The cache of a round has Bc * W entries: entry c = b * W + i has key (cache_seq[b], cache_j[c], cache_forks[c]) =

@@ -10,6 +10,7 @@ import sys
 
 d = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/evidence2"
 rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+wl = sys.argv[3] if len(sys.argv) > 3 else "c3"       # round 5: c4 (the metric's own workload: async k = 7 f = 3, M = 8 verify rows)
 
 
 def rows(name):
@@ -28,9 +29,20 @@ KNOWN = {
     ("gemm_fused_kernel<1, 3, true", 196608): ("draft norm+qkv+RoPE 3072x2048 (slab prologue)", 12.583),
     ("gemm_sp_kernel<8, 1>", 262144): ("draft down 2048x8192 (2 slabs)", 33.554),
     ("gemm_sp_kernel<2, 1>", 262144): ("draft o 2048x2048 (2 slabs)", 8.389),
+    # c4 (round 5): the target at M = 8 launches the QKV kernel with 16 waves; the draft's glue / tree / chain kinds
+    ("gemm_fused_kernel<4, 3, false", 163840): ("target qkv+RoPE+KV-store 10240x8192", 167.772),
+    ("gemm_wf_kernel<1, 2, 3>", 513024): ("target LM head 128256x8192 + argmax candidates", 2101.346),
+    ("gemm_wf_kernel<1, 2, 3>", 2052096): ("draft LM head 128256x2048 + argmax candidates (M <= 16)", 525.337),
+    ("gemm_wf_kernel<2, 2, 3>", 2052096): ("draft LM head 128256x2048 + argmax candidates (M = 24)", 525.337),
+    ("gemm_wf_kernel<2, 2, 1>", 131072): ("draft tree-step gate_up+SiLU 16384x2048 (M = 24)", 67.109),
+    ("gemm_sp_kernel<8, 2>", 262144): ("draft tree-step down 2048x8192 (M = 24, slabs)", 33.554),
+    ("gemm_sp_kernel<2, 2>", 262144): ("draft tree-step o 2048x2048 (M = 24, slabs)", 8.389),
+    ("gemm_qkv_rope_m32_kernel<1>", 196608): ("draft tree-step qkv+RoPE+KV-store 3072x2048 (M = 24)", 12.583),
+    ("chain_segment_kernel", 131072): ("draft chain segment (o + gate_up + down + next qkv, M = 1)", 121.635),
+    ("tree_segment_kernel<1, 4>", 131072): ("draft M-row segment (o + gate_up + down + next qkv, glue M = 8)", 121.635),
 }
-out = {"source": f"profiles/{rnd}_c3_pmc_fetch.csv + {rnd}_c3_pmc_write.csv + {rnd}_c3_mfma.csv (separate rocprofv3 --pmc passes on "
-                 "`bench.py --workload c3`, 70B + 1B; FETCH_SIZE x2 gfx950 correction)", "per_kernel": {}}
+out = {"source": f"profiles/{rnd}_{wl}_pmc_fetch.csv + {rnd}_{wl}_pmc_write.csv + {rnd}_{wl}_mfma.csv (separate rocprofv3 --pmc passes on "
+                 f"`bench.py --workload {wl}`, 70B + 1B; FETCH_SIZE x2 gfx950 correction)", "per_kernel": {}}
 fetch = rows("pmc_FETCH_SIZE.csv")
 tot_read = tot_alg = 0.0
 for r in fetch:

@@ -174,6 +174,124 @@ extern "C" int ssd_fork_topf(const void* logits, long ld, int V, const int64_t* 
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
+// The same fork, spread over the chip (round 5).  ssd_fork_topf puts ONE workgroup on each of the B * (K + 1) glue rows and walks the
+// 128 K-logit row F times: 8 workgroups, 84.7 us per launch on the draft's critical path (profiles/r04_c4_kernel_stats.csv).  Here a row
+// is cut into S slices of <= 4096 logits; workgroup (slice, row) loads its slice ONCE (16 values per thread, one round trip), picks the
+// slice's top-F with the same comparison (larger value, then lower index; x_{j+1} excluded for rows j < K) and leaves F candidates;
+// a second, one-wave-per-row launch picks the row's top-F from the S * F candidates.  The top-F of a union is the top-F of the
+// per-slice top-Fs, and ties resolve by index in both stages: bit-equal to ssd_fork_topf.  V % 8 == 0.
+constexpr int FS_THREADS = 256;
+constexpr int FS_PER = 2;                        // 16-byte chunks per thread
+constexpr int FS_SLICE = FS_THREADS * FS_PER * 8;
+
+__global__ void __launch_bounds__(FS_THREADS)
+fork_slice_kernel(const bf16_t* __restrict__ logits, long ld, int V, const int64_t* __restrict__ returned, const int32_t* __restrict__ counts,
+                  int K, int S, int chunks_per_slice, float* __restrict__ cand_val, int* __restrict__ cand_idx) {
+  __shared__ ArgBest sm[FS_THREADS / 64];
+  const int row = blockIdx.y, sl = blockIdx.x, b = row / (K + 1), j = row % (K + 1);
+  const int cnt = min(counts[row], FORK_MAXF - 1);
+  const int excl = j < K ? (int)returned[(size_t)b * (K + 1) + j + 1] : -1;
+  const int V8 = V >> 3, c_end = min(V8, (sl + 1) * chunks_per_slice);
+  float v[FS_PER * 8];
+  int base[FS_PER];
+#pragma unroll
+  for (int u = 0; u < FS_PER; ++u) {
+    const int c = sl * chunks_per_slice + u * FS_THREADS + (int)threadIdx.x;
+    base[u] = c * 8;
+    u32x4_t q = {0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u};      // -inf: a chunk past the slice never wins
+    if (c < c_end) q = *reinterpret_cast<const u32x4_t*>(logits + (size_t)row * ld + (size_t)c * 8);
+    else base[u] = 0x7fffff00;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[u * 8 + 2 * e] = bf2f(q[e] & 0xffffu); v[u * 8 + 2 * e + 1] = bf2f(q[e] >> 16); }
+  }
+  unsigned taken = 0;                             // elements of this thread that are excluded or already picked
+#pragma unroll
+  for (int u = 0; u < FS_PER; ++u)
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (base[u] + e == excl || base[u] == 0x7fffff00) taken |= 1u << (u * 8 + e);
+  for (int f = 0; f < cnt; ++f) {
+    ArgBest best = {-INFINITY, 0x7fffffff};
+#pragma unroll
+    for (int u = 0; u < FS_PER; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (!((taken >> (u * 8 + e)) & 1u)) best = better(best, ArgBest{v[u * 8 + e], base[u] + e});
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = better(best, ArgBest{__shfl_xor(best.v, o, 64), __shfl_xor(best.i, o, 64)});
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = best;
+    __syncthreads();
+    ArgBest r = sm[0];
+#pragma unroll
+    for (int w = 1; w < FS_THREADS / 64; ++w) r = better(r, sm[w]);
+#pragma unroll
+    for (int u = 0; u < FS_PER; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (base[u] + e == r.i) taken |= 1u << (u * 8 + e);
+    if (threadIdx.x == 0) {
+      const size_t o = ((size_t)row * S + sl) * FORK_MAXF + f;
+      cand_val[o] = r.v;
+      cand_idx[o] = r.i;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64)
+fork_merge_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx, const int32_t* __restrict__ counts,
+                  const int32_t* __restrict__ offsets, int K, int S, int mq, int64_t* __restrict__ out) {
+  const int row = blockIdx.x, b = row / (K + 1), lane = threadIdx.x;
+  const int cnt = min(counts[row], FORK_MAXF - 1);
+  const int n = S * cnt;                          // candidate (slice s, rank f) at (row * S + s) * FORK_MAXF + f
+  constexpr int PER = 12;                         // 64 lanes x 12 >= 48 slices x 15
+  ArgBest c[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int q = u * 64 + lane;
+    c[u] = ArgBest{-INFINITY, 0x7fffffff};
+    if (q < n) {
+      const size_t o = ((size_t)row * S + q / cnt) * FORK_MAXF + q % cnt;
+      c[u] = ArgBest{cand_val[o], cand_idx[o]};
+    }
+  }
+  unsigned taken = 0;
+  for (int f = 0; f < cnt; ++f) {
+    ArgBest best = {-INFINITY, 0x7fffffff};
+#pragma unroll
+    for (int u = 0; u < PER; ++u)
+      if (!((taken >> u) & 1u)) best = better(best, c[u]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = better(best, ArgBest{__shfl_xor(best.v, o, 64), __shfl_xor(best.i, o, 64)});
+#pragma unroll
+    for (int u = 0; u < PER; ++u)
+      if (c[u].i == best.i) taken |= 1u << u;
+    if (lane == 0) out[(size_t)b * mq + offsets[row] + f] = best.i == 0x7fffffff ? 0 : best.i;   // (as ssd_fork_topf: never the sentinel)
+  }
+}
+
+extern "C" int ssd_fork_topf_workspace_bytes(int V, int B, int K) {
+  if (V <= 0 || B <= 0 || K < 0) return SSD_ERR_SHAPE;
+  const int S = (V + FS_SLICE - 1) / FS_SLICE;
+  return B * (K + 1) * S * FORK_MAXF * 8;
+}
+
+extern "C" int ssd_fork_topf_split(const void* logits, long ld, int V, const int64_t* returned_tokens, const int32_t* counts,
+                                   const int32_t* offsets, int B, int K, int mq, void* workspace, int64_t* out, void* stream) {
+  if (B <= 0 || K < 0 || V <= 0 || (V & 7) || (ld & 7)) return SSD_ERR_SHAPE;
+  if (!logits || !returned_tokens || !counts || !offsets || !workspace || !out) return SSD_ERR_ARG;
+  const int S = (V + FS_SLICE - 1) / FS_SLICE;
+  if (S > 48) return SSD_ERR_SHAPE;              // fork_merge_kernel keeps S * F <= 768 candidates in one wave's registers
+  const int rows = B * (K + 1);
+  const int chunks = ((V >> 3) + S - 1) / S;      // <= FS_THREADS * FS_PER
+  float* cv = (float*)workspace;
+  int* ci = (int*)(cv + (size_t)rows * S * FORK_MAXF);
+  hipLaunchKernelGGL(fork_slice_kernel, dim3(S, rows), dim3(FS_THREADS), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, V,
+                     returned_tokens, counts, K, S, chunks, cv, ci);
+  hipLaunchKernelGGL(fork_merge_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, cv, ci, counts, offsets, K, S, mq, out);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Argmax from the LM-head GEMM's per-workgroup candidates (gemm.hip EPI_ROWS_ARGMAX: part_val / part_idx
 // [row * part_stride + p], p < nparts) -- and, in the same launch, what the loop does with the token next:

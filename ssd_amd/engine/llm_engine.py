@@ -154,6 +154,13 @@ class LLMEngine:
                     total = torch.cuda.get_device_properties(self.topo.device).multi_processor_count
                     side = masked_stream(self.topo.device, 0, ncu)
                     self._target_stream = masked_stream(self.topo.device, ncu, total)
+                # the M-row resident segment (csrc/tree_segment.hip) keeps 256 workgroups waiting for each other: beside a verify that owns
+                # the CUs they come up one by one and spin -- measured on c4 (profiles/r05_c4_kernel_stats_with_glue_segment.txt): 85.6 us
+                # per glue launch against 27 us alone, and the CUs they hold are taken from the target.  "auto" keeps it for draft
+                # servers that have the GPU to themselves (dedicated placement); the single-token chain segment only runs on misses,
+                # with the target waiting for its reply, and stays on.
+                if side is not None and on_gpu and os.environ.get("SSD_TREE_SEG", "auto") == "auto" and hasattr(self.draft_runner, "model"):
+                    self.draft_runner.model.tree_seg_colocated = True
                 self.draft_server = DraftServer(config, self.draft_runner, server_end, stream=side, deferred=side is not None)
                 if side is not None:
                     self.model_runner.overlap_hook = self.draft_server.run_deferred

@@ -76,6 +76,8 @@ SIGNATURES = {
     "ssd_argmax_merge": [c_void_p, c_void_p, c_int, c_int, c_long, c_long, c_void_p, c_void_p, c_void_p],
     "ssd_verify_greedy": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "ssd_fork_topf": [c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "ssd_fork_topf_workspace_bytes": [c_int, c_int, c_int],
+    "ssd_fork_topf_split": [c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "ssd_comm_alloc": [C.POINTER(c_void_p), c_long],
     "ssd_comm_free": [c_void_p],
     "ssd_comm_ipc_export": [c_void_p, c_void_p],

@@ -137,6 +137,7 @@ class HipDecoder:
         # 1 = every shape and row count the kernel accepts (tests); 0 = off.
         _ts = os.environ.get("SSD_TREE_SEG", "auto")
         self.tree_seg_rows = 32 if _ts == "1" else 16
+        self.tree_seg_colocated = False     # set by the engine for a draft server that shares its GPU with the target (llm_engine.py)
         self.tree_seg = ((_ts == "1" or (_ts == "auto" and _validated)) and not cfg.qk_norm and tp_size == 1 and not self.use_coll
                          and taps is None and max_tokens >= 2
                          and H.tree_segment_ok(2, self.h, self.qn, self.I, self.qkv_n, self.nh, self.nkv, self.hd))
@@ -212,6 +213,17 @@ class HipDecoder:
                     self.w["lm_head.weight"] = out
             else:
                 self.w[name] = w
+        torch.cuda.synchronize(self.device)
+
+    def overwrite_weights(self, weight_iter) -> None:
+        """New VALUES into the existing weight tensors (same names and shapes): captured hipGraphs keep pointing at the same memory, so a
+        model can be given other weights without recapturing anything (bench.py: the independent-draft leg after the correlated one)."""
+        old, self.w = self.w, {}
+        self.load_weights(weight_iter)
+        new, self.w = self.w, old
+        assert set(new) == set(old), sorted(set(new) ^ set(old))
+        for n, t in new.items():
+            old[n].copy_(t)
         torch.cuda.synchronize(self.device)
 
     def _qkv_row_perm(self) -> torch.Tensor:
@@ -406,7 +418,7 @@ class HipDecoder:
 
     def tree_plan(self, T: int, meta: AttnMeta) -> bool:
         """The resident M-row layer segment (csrc/tree_segment.hip): decode-side forwards of 2..30 rows (tree steps, glue), no biases."""
-        return (self.tree_seg and 2 <= T <= self.tree_seg_rows and meta.cu_q is None and "model.layers.0.self_attn.qkv_proj.bias" not in self.w
+        return (self.tree_seg and not self.tree_seg_colocated and 2 <= T <= self.tree_seg_rows and meta.cu_q is None and "model.layers.0.self_attn.qkv_proj.bias" not in self.w
                 and H.tree_segment_ok(T, self.h, self.qn, self.I, self.qkv_n, self.nh, self.nkv, self.hd))
 
     def _forward_tree_seg(self, positions, T: int, meta: AttnMeta, splits: int, attn_waves: int) -> None:

@@ -551,6 +551,47 @@ def test_fork_golden(H, golden):
     assert torch.equal(out.cpu(), g["f_idx"])
 
 
+def test_fork_split_golden_and_equal_to_the_row_walk(H, golden):
+    """ssd_fork_topf_split (per-slice top-F candidates + one merge launch, round 5) == the reference fork golden (logic_golden.npz:
+    get_forked_recovery_tokens_from_logits, async_spec_helpers.py:26-78) and == ssd_fork_topf bit for bit at the real vocabulary sizes,
+    with non-uniform fan-out lists and logits quantised to a handful of values (ties everywhere: the lowest index must win in the
+    slices AND in the merge, also across slice borders)."""
+    from oracle import ops as O
+    g = golden("logic_golden")
+    lg = g["f_logits"]                      # [2, 4, 500]
+    B, Kp1, V = lg.shape
+    lists = [g["f_list_hit"].tolist() if h else g["f_list_miss"].tolist() for h in g["f_hits"].tolist()]
+    counts = torch.tensor(lists, dtype=torch.int32)
+    offsets = torch.cumsum(counts, 1).to(torch.int32) - counts
+    mq = int(counts[0].sum())
+    ld = 504                                # V = 500 padded to a multiple of 8 with -inf logits (never picked)
+    padded = torch.full((B * Kp1, ld), float("-inf"), dtype=BF)
+    padded[:, :V] = lg.view(B * Kp1, V)
+    out = torch.zeros(B, mq, dtype=torch.int64, device="cuda")
+    ws = torch.zeros(H.fork_topf_workspace_bytes(ld, B, Kp1 - 1) // 8, dtype=torch.int64, device="cuda")
+    H.fork_topf_split(dev(padded), ld, ld, dev(g["f_returned"]), dev(counts), dev(offsets), B, Kp1 - 1, mq, ws, out)
+    assert torch.equal(out.cpu(), g["f_idx"])
+    for V, B, K, levels, seed in ((128256, 1, 7, 0, 0), (128256, 2, 7, 9, 1), (151936, 3, 5, 5, 2), (4096, 1, 2, 3, 3), (32, 1, 1, 0, 4)):
+        torch.manual_seed(seed)
+        x = torch.randn(B * (K + 1), V)
+        if levels:
+            x = (x * levels).round() / levels * 0.5          # a handful of distinct values: ties by the thousand
+        x = x.to(BF)
+        returned = torch.randint(0, V, (B, K + 1), dtype=torch.int64)
+        returned[:, 1] = x[::K + 1].float().argmax(-1)       # the draft's own next token IS the row's maximum: the exclusion matters
+        row0 = torch.randint(1, 6, (K + 1,), dtype=torch.int32)             # every sequence: the same fan-outs in another order (MQ_LEN is fixed)
+        cnt = torch.stack([row0[torch.randperm(K + 1)] for _ in range(B)]).contiguous()
+        offs = torch.cumsum(cnt, 1).to(torch.int32) - cnt
+        mq = int(row0.sum())
+        a = torch.full((B, mq), -1, dtype=torch.int64, device="cuda")
+        b_ = torch.full((B, mq), -1, dtype=torch.int64, device="cuda")
+        H.fork_topf(dev(x), V, V, dev(returned), dev(cnt), dev(offs), B, K, mq, a)
+        ws = torch.zeros(H.fork_topf_workspace_bytes(V, B, K) // 8, dtype=torch.int64, device="cuda")
+        H.fork_topf_split(dev(x), V, V, dev(returned), dev(cnt), dev(offs), B, K, mq, ws, b_)
+        assert torch.equal(a.cpu(), b_.cpu()), (V, B, K)
+        assert torch.equal(b_.cpu(), O.fork_topf(x.view(B, K + 1, V), returned, cnt.tolist())), (V, B, K)
+
+
 def test_draft_advance(H):
     B, K, bs, mb = 3, 4, 16, 8
     bt = torch.arange(B * mb, dtype=torch.int32).view(B, mb)

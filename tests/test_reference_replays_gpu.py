@@ -152,7 +152,7 @@ def test_hip_draft_server_replays_the_reference_runner_rounds(gpu, golden, name,
         assert compared[0] >= 60 and len(excused) <= 4, f"compared {compared[0]} decisions, excused {excused}"
 
 
-def _full_size_pair():
+def _full_size_pair(layer_gain: float = 0.05):
     """Llama-3.1-8B shapes (32 layers, h 4096, V 128256) + the full Llama-3.2-1B draft (16 layers): the correlated synthetic
     pair (ssd_amd/weights.py _pair_tensor), generated on the GPU (18.5 GB of bf16) and copied to the host once for the oracle."""
     import dataclasses
@@ -160,13 +160,14 @@ def _full_size_pair():
     from ssd_amd.model_config import PRESETS
     tcfg = PRESETS["llama-3.1-8b"]
     dcfg = dataclasses.replace(PRESETS["llama-3.2-1b"], tie_word_embeddings=False)     # the pair recipe unties the 1B head
-    recipe = {"kind": "pair", "shared": dcfg.hidden_size, "snr": 8.0, "layer_gain": 0.05}
+    recipe = {"kind": "pair", "shared": dcfg.hidden_size, "snr": 8.0, "layer_gain": layer_gain}
     wt = {n: t.cpu() for n, t in W.synthetic_weights(tcfg, 0, 0.02, gen_device="cuda", recipe=recipe)}
     wd = {n: t.cpu() for n, t in W.synthetic_weights(dcfg, 1, 0.02, gen_device="cuda", recipe=recipe)}
     return tcfg, dcfg, wt, wd
 
 
-def _lockstep_full_size(mode: str, n_new: int):
+def _lockstep_full_size(mode: str, n_new: int, layer_gain: float = 0.05, thr: float | None = None, min_rounds: float = 0.85,
+                        min_tokens: float = 0.9, max_restarts: int = 16):
     """Product engine on the MI355X against the oracle engine on the host, round by round (tests/lockstep.py): hit flags,
     speculated tokens, accepted suffixes; an excused near-tie re-synchronises both runs on the oracle's tokens."""
     import random
@@ -174,7 +175,8 @@ def _lockstep_full_size(mode: str, n_new: int):
     from ssd_amd.engine.llm_engine import LLMEngine, hip_runner_factory
     from ssd_amd.sampling_params import SamplingParams
     from tests.lockstep import compare_lockstep
-    tcfg, dcfg, wt, wd = _full_size_pair()
+    from tests.lockstep import NEAR_TIE
+    tcfg, dcfg, wt, wd = _full_size_pair(layer_gain)
     random.seed(5)
     prompt = [random.randint(0, 10000) for _ in range(96)]
     kw = dict(hf_config=tcfg, max_num_seqs=1, max_model_len=1024, max_num_batched_tokens=1024, kvcache_block_size=256,
@@ -192,12 +194,13 @@ def _lockstep_full_size(mode: str, n_new: int):
     cpu_eng = LLMEngine("t", runner_factory=oracle_runner_factory(wt, wd), inprocess_draft=mode == "async",
                         topology=Topology(0, 1, torch.device("cpu"), "target", 0, 1), **kw)      # (the oracle's tensors live on the host)
     rep = compare_lockstep(gpu_eng, cpu_eng, prompt, n_new, lambda n: SamplingParams(temperature=0, max_new_tokens=n, ignore_eos=True),
-                           fan_out=3 if mode == "async" else None, what=f"8B+1B {mode}")
+                           fan_out=3 if mode == "async" else None, thr=NEAR_TIE if thr is None else thr, max_restarts=max_restarts,
+                           what=f"8B+1B {mode} layer_gain {layer_gain}")
     gpu_eng.exit()
-    print(f"full size 8B + 1B {mode}: {rep.summary()}")
+    print(f"full size 8B + 1B {mode} (layer_gain {layer_gain}): {rep.summary()}")
     assert rep.tokens == n_new
-    assert rep.tokens_compared >= 0.9 * rep.tokens, rep.summary()         # only the disputed near-tie tokens themselves go uncompared
-    assert rep.rounds_compared >= 0.6 * rep.rounds, rep.summary()
+    assert rep.tokens_compared >= min_tokens * rep.tokens, rep.summary()  # only the disputed near-tie tokens themselves go uncompared
+    assert rep.rounds_compared >= min_rounds * rep.rounds, rep.summary()  # (round 4 accepted 0.6; measured: sync 27 / 32, async 33 / 37)
     return rep
 
 
@@ -208,7 +211,7 @@ def test_full_size_configs1_llama8b_target_1b_draft_sync_k6(gpu):
     difference is admissible only where the ORACLE's own margin at that very decision is a near-tie, and then both runs are
     re-synchronised on the oracle's token and the comparison goes on to the end (round 3 stopped at the first near-tie, 16 of
     40 tokens, and its accepted-length comparison read one shared METRICS dict twice)."""
-    rep = _lockstep_full_size("sync", 56)
+    rep = _lockstep_full_size("sync", 56, min_rounds=0.8)
     assert max(rep.accepted_lens) > 1 and min(rep.accepted_lens) < 7, "the pair should produce both accepts and rejections"
 
 
@@ -221,6 +224,21 @@ def test_full_size_async_k7_f3_llama8b_target_1b_draft(gpu):
     rep = _lockstep_full_size("async", 64)
     assert rep.hits > 0 and rep.real_misses > 0, rep.summary()        # misses beyond each run's first request: JIT chains on real misses
     assert rep.partial_accepts > 0 and max(rep.accepted_lens) > 2, rep.summary()
+
+
+@pytest.mark.parametrize("mode", ["sync", "async"])
+def test_full_size_lockstep_with_undamped_layers(gpu, mode):
+    """The same two lock-step runs with layer_gain 1.0: o_proj / down_proj at their plain N(0, 0.02) scale, so
+    every attention / MLP kernel's error reaches the token decisions unattenuated (at 0.05 it arrives 20x smaller: those runs pin the
+    protocol, these pin the layer kernels through it).  The decoder layers now drown the shared embedding: the pair agrees rarely,
+    nearly every async round is a miss -> JIT chain + glue + fork at V = 128256 + 7 tree steps of 24 branches, all with undamped
+    layers, compared decision by decision with the oracle.  Near-tie threshold: two bf16 pipelines of 32 (target) / 16 (draft)
+    undamped layers differ by up to ~0.1-0.15 on a logit (measured: tests/test_hip_tree_segment.py 16 layers 0.10,
+    test_eight_layer_70b_cut... 8 layers), so a decision whose ORACLE margin is under 0.25 cannot be held to either side; everything
+    else must match, and every excused decision re-synchronises both runs (teacher forcing) so the comparison reaches the last token."""
+    rep = _lockstep_full_size(mode, 24, layer_gain=1.0, thr=0.25, min_rounds=0.6, min_tokens=0.75, max_restarts=24)
+    if mode == "async":
+        assert rep.real_misses > 0, rep.summary()
 
 
 def test_full_size_eagle3_llama8b_lockstep(gpu):
