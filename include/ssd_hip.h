@@ -71,6 +71,16 @@ int ssd_rmsnorm(const void* x_rows, const void* res_in, void* res_out, const voi
 int ssd_rmsnorm_parts(const void* parts, int splits, int slab_rows, const void* res_in, void* res_out, const void* weight,
                       float eps, void* out_rows, void* out_frag, int T, int H, void* stream);
 
+/* RMSHeadNorm.forward -- ssd/layers/layernorm.py:16-40 (Qwen3's q_norm / k_norm, ssd/models/qwen3.py:96-104) as a call of its own:
+ * x_rows [T][heads][hd] normalised over hd per (token, head), weight bf16[hd].  The hot path runs it inside ssd_rope_store_kv
+ * (q_norm_w / k_norm_w); this entry point is bit-identical to that fused form and exists for a binding at the module boundary. */
+int ssd_head_rmsnorm(const void* x_rows, const void* weight, float eps, void* out_rows, int T, int heads, int hd, void* stream);
+
+/* SiluAndMul.forward -- ssd/layers/activation.py:11-14 as a call of its own: x_rows [T][2 I] = [gate | up] ->
+ * bf16(silu(gate) * up) as rows [T][I] and / or fragment-major (either may be NULL).  The hot path runs it as the gate_up GEMM's
+ * epilogue (SSD_EPI_SILU_FRAG), same arithmetic. */
+int ssd_silu_mul(const void* x_rows, void* out_rows, void* out_frag, int T, int I, void* stream);
+
 /* The EAGLE-3 draft layer's QKV input, torch.cat([input_layernorm(token_embeddings), conditioning_feature_ln(features)], -1)
  * -- ssd/models/eagle3_draft_llama3.py:148-150 -- written directly as ONE fragment-major [T][2H] activation (each half is
  * RMSDNorm.norm_forward as in ssd_rmsnorm). */

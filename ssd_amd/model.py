@@ -143,6 +143,7 @@ class HipDecoder:
                          and H.tree_segment_ok(2, self.h, self.qn, self.I, self.qkv_n, self.nh, self.nkv, self.hd))
         if self.chain_seg:
             self.chain_gr = z(H.chain_granule_bytes(self.h, self.I) // 8, dtype=torch.int64)
+            self.buf_res3 = z(1, self.h)             # the chain's residual ping-pongs between buf_res2 and this (every workgroup re-reads res_in)
         if self.chain_seg or self.tree_seg:
             self.chain_gen = z(1, dtype=torch.int32)
             self.chain_err = z(1, dtype=torch.int32)
@@ -411,7 +412,8 @@ class HipDecoder:
                 w_qkv_next=w[f"model.layers.{li + 1}.self_attn.qkv_proj.weight"], ln_next=w[f"model.layers.{li + 1}.input_layernorm.weight"],
                 positions=positions, cos_sin=self.cos_sin, slots=meta.slot_mapping, q_out=self.buf_q,
                 k_cache=self.kv_cache[li + 1, 0], v_cache=self.kv_cache[li + 1, 1])
-            H.chain_segment(self.buf_af, self.buf_res2, self.buf_res if last else self.buf_res2, w[p + "self_attn.o_proj.weight"],
+            rin, rout = (self.buf_res2, self.buf_res3) if li % 2 == 0 else (self.buf_res3, self.buf_res2)
+            H.chain_segment(self.buf_af, rin, self.buf_res if last else rout, w[p + "self_attn.o_proj.weight"],
                             w[p + "mlp.gate_up_proj.weight"], w[p + "mlp.down_proj.weight"], w[p + "post_attention_layernorm.weight"],
                             cfg.rms_norm_eps, self.h, self.qn, self.I, self.qkv_n, self.nh, self.nkv, self.hd, self.block_size, li,
                             self.chain_gr, self.chain_gen, self.chain_err, h_out=self.buf_h if last else None, **nxt)

@@ -207,6 +207,42 @@ def test_gemm_silu_epilogue(H, M):
     assert_close_bf16(act, ref, max_ulp=1, max_frac=0.03, rel_floor=2 ** -7, what="gemm+silu")
 
 
+def test_stand_alone_silu_mul_and_head_rmsnorm(H, golden):
+    """The module-level entry points (ssd_silu_mul = SiluAndMul.forward, activation.py:11-14; ssd_head_rmsnorm = RMSHeadNorm.forward,
+    layernorm.py:16-40) against the goldens the reference's own compiled modules wrote (ops_golden.npz), against the oracle at real
+    widths, and against the fused forms the hot path runs: the gate_up epilogue's arithmetic, and -- bit for bit -- the q / k norm
+    inside ssd_rope_store_kv (at position 0 the rotation is the identity, so its q output IS the normalised head)."""
+    g = golden("ops_golden")
+    T, I2 = g["silu_x"].shape
+    y = torch.zeros(T, I2 // 2, dtype=BF, device="cuda")
+    yf = torch.zeros(H.frag_numel(T, I2 // 2), dtype=BF, device="cuda")
+    H.silu_mul(dev(g["silu_x"]), T, I2 // 2, out_rows=y, out_frag=yf)
+    assert_close_bf16(y, g["silu_y"], max_ulp=1, max_frac=0.03, rel_floor=2 ** -7, what="silu_mul golden")
+    assert torch.equal(LY.frag_to_rows_ref(yf.cpu(), T, I2 // 2).view(torch.int16), y.cpu().view(torch.int16))
+    torch.manual_seed(3)
+    x = (torch.randn(24, 2 * 8192) * 2).to(BF)
+    y = torch.zeros(24, 8192, dtype=BF, device="cuda")
+    H.silu_mul(dev(x), 24, 8192, out_rows=y)
+    assert_close_bf16(y, O.silu_mul(x), max_ulp=1, max_frac=0.03, rel_floor=2 ** -7, what="silu_mul 24 x 8192")
+    # head norm: the reference's compiled RMSHeadNorm (28 heads of 64)
+    n, hd = g["hnorm_x"].shape
+    out = torch.zeros(n, hd, dtype=BF, device="cuda")
+    H.head_rmsnorm(dev(g["hnorm_x"]), dev(g["hnorm_w"]), 1e-6, out, 1, n, hd)
+    assert_close_bf16(out, g["hnorm_y"], max_ulp=1, max_frac=0.01, what="head_rmsnorm golden")
+    for hd, nh, nkv in ((128, 16, 8), (64, 4, 2), (256, 2, 1)):
+        T = 5
+        qkv = torch.randn(T, (nh + 2 * nkv) * hd).to(BF)
+        w = (1 + 0.1 * torch.randn(hd)).to(BF)
+        out = torch.zeros(T, nh * hd, dtype=BF, device="cuda")
+        q = qkv[:, :nh * hd].contiguous()
+        H.head_rmsnorm(dev(q), dev(w), 1e-6, out, T, nh, hd)
+        assert_close_bf16(out, O.rmsnorm(q.view(-1, hd), w, 1e-6).view(T, nh * hd), max_ulp=1, max_frac=0.01, what=f"head_rmsnorm hd {hd}")
+        cache = torch.cat([torch.ones(4, hd // 2), torch.zeros(4, hd // 2)], dim=1).float().contiguous()     # cos = 1, sin = 0: no rotation
+        q_out, _, _ = run_rope(H, qkv, torch.zeros(T, dtype=torch.int64), cache, torch.full((T,), -1, dtype=torch.int32), nh, nkv, hd, 16, 2,
+                               qn=w, kn=w, eps=1e-6)
+        assert torch.equal(q_out.view(torch.int16), out.cpu().view(torch.int16)), f"stand-alone head norm != the fused one, hd {hd}"
+
+
 def test_embedding(H, golden):
     g = golden("ops_golden")
     out = torch.zeros(7, 256, dtype=BF, device="cuda")
