@@ -127,15 +127,39 @@ def self_launch(args) -> int:
     th = threading.Thread(target=relay, daemon=True)
     th.start()
     why = None
-    try:
-        rc = p.wait(timeout=deadline)
-    except subprocess.TimeoutExpired:
-        why = f"launch exceeded {deadline:.0f} s: process group killed by the launcher"
+
+    def kill_group(sig):
         try:
-            os.killpg(p.pid, signal.SIGKILL)
+            os.killpg(p.pid, sig)
         except Exception:
-            p.kill()
-        rc = p.wait()
+            pass
+
+    # the ranks live in their own session (so that the launcher can kill ALL of them at the deadline): a SIGINT / SIGTERM sent to the
+    # launcher -- Ctrl-C, a harness time-out -- must be passed on, or the ranks would keep the GPUs until their own watchdogs end them
+    def passed_on(signum, _frame):
+        kill_group(signal.SIGTERM)
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            kill_group(signal.SIGKILL)
+        os._exit(128 + signum)
+    old = {sg: signal.signal(sg, passed_on) for sg in (signal.SIGINT, signal.SIGTERM)}
+    try:
+        try:
+            rc = p.wait(timeout=deadline)
+        except subprocess.TimeoutExpired:
+            why = f"launch exceeded {deadline:.0f} s: process group killed by the launcher"
+            kill_group(signal.SIGKILL)
+            rc = p.wait()
+    finally:
+        if p.poll() is None:            # any other way out of the wait (an exception in the launcher): leave no rank behind
+            kill_group(signal.SIGTERM)
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                kill_group(signal.SIGKILL)
+        for sg, h in old.items():
+            signal.signal(sg, h)
     th.join(timeout=5)
     if not seen:
         rec = base_record(args)
@@ -669,6 +693,13 @@ def run(args, guard, rank, world):
         "tokens_per_s_at_accepted_len": {str(a): round(a / (dt / args.steps), 1) for a in (1, 2, 4, K + 1)},
         "reference_protocol": ref,
     }
+    if world > 1:                     # first contact with a multi-GPU box: say up front which transport carries the sums and how far the
+        # first-run paths of DESIGN.md section 7 got (a failure record carries the same two fields)
+        out = {"collective_one_shot_status": getattr(engine.model_runner, "custom_ar_status", None),
+               "first_run_paths": guard.first_run_paths(), **out}
+        if rank == 0:
+            print(f"[ssd bench] n_gpus {world}: one-shot all-reduce: {out['collective_one_shot_status']}; first-run paths completed: "
+                  f"{out['first_run_paths']['completed']}", file=sys.stderr, flush=True)
     if not args.no_roofline:          # every rank launches the same sequence (shard shapes); rank 0 reports
         guard.stage("roofline_probe")
         with torch.inference_mode():      # the engine's buffers are inference tensors (ModelRunner runs under inference_mode)

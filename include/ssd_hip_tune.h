@@ -37,13 +37,6 @@ int ssd_attn_paged_qkv(const void* qkv_rows, const int64_t* positions, const flo
                        int tree_F, const int32_t* tree_jidx, int flags, void* out_rows, void* out_frag, void* stream);
 
 
-/* EXPERIMENTAL, default off (SSD_COLOCATED_CUS), measured slower (profiles/r02_cu_partition.txt).
-A stream restricted to the compute units whose bit is set in cu_mask (bit i of word i/32 = CU i): partitions the chip
- * between the co-located draft server and the target's verify of asynchronous speculation (the reference gives the draft
- * a GPU of its own, ssd/engine/llm_engine.py:82-89; on one GPU the two rounds otherwise serialise).  Start-up only. */
-int ssd_stream_create_cu_mask(void** out_stream, const uint32_t* cu_mask, int mask_words);
-int ssd_stream_destroy(void* stream);
-
 /* Diagnostic (tests only): gfx950's v_cvt_pk_bf16_f32 against the integer round-to-nearest-even used everywhere else, over all 2^32
  * fp32 patterns.  counts2: two uint64 device words, zeroed by the caller: [0] mismatches on non-NaN inputs, [1] NaN inputs that did
  * not stay NaN. */

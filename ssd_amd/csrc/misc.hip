@@ -102,19 +102,3 @@ extern "C" int ssd_store_step_rows(const void* src_rows, long src_ld, void* dst,
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
-// A HIP stream restricted to a subset of the compute units (bit i of cu_mask = CU i enabled).  Used to PARTITION the chip
-// between a co-located draft server and the target's verify (engine/llm_engine.py): a weight-streaming GEMM of the target
-// fills every SIMD's register file (16 waves x 128 VGPRs per CU), so the draft's kernels on an ordinary second stream only
-// run in the gaps between the target's kernels -- the two rounds serialise.  With disjoint CU sets they really overlap and
-// share the HBM bandwidth.  The streams are created once at start-up; nothing here is on the hot path.
-extern "C" int ssd_stream_create_cu_mask(void** out_stream, const uint32_t* cu_mask, int mask_words) {
-  if (!out_stream || !cu_mask || mask_words <= 0) return SSD_ERR_ARG;
-  hipStream_t s = nullptr;
-  if (hipExtStreamCreateWithCUMask(&s, (uint32_t)mask_words, cu_mask) != hipSuccess) return SSD_ERR_LAUNCH;
-  *out_stream = (void*)s;
-  return SSD_OK;
-}
-extern "C" int ssd_stream_destroy(void* stream) {
-  if (!stream) return SSD_ERR_ARG;          // the null stream is not ours to destroy
-  return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
-}

@@ -96,7 +96,6 @@ class LLMEngine:
 
         self.draft_runner = None
         self._capped_ids: set[int] = set()
-        self._target_stream = None
         self.async_link = None
         self.draft_server = None
         if self.topo.role == "draft":               # dedicated draft GPU of async speculation
@@ -137,23 +136,10 @@ class LLMEngine:
                                             memory_utilization=0.75, num_kvcache_blocks=config.num_draft_kvcache_blocks)
                 # co-located draft: its own stream, next-round work parked until the target's verify is in flight
                 on_gpu = self.topo.device.type == "cuda"
-                # (stream priority: -1 = high.  The draft's ~900 small dependent kernels per round are latency chains; with
-                # priority they are dispatched as soon as a CU has room beside the target's 8-wave workgroups)
-                prio = int(os.environ.get("SSD_COLOCATED_PRIORITY", "0"))
-                side = (torch.cuda.Stream(self.topo.device, priority=prio)
-                        if on_gpu and os.environ.get("SSD_COLOCATED_OVERLAP", "1") != "0" else None)
-                # SSD_COLOCATED_CUS = n (experimental, default off): partition the chip -- the draft server's stream gets n
-                # compute units, the target's steps run on a stream confined to the others (ssd_stream_create_cu_mask) -- so
-                # that the speculation tree is decoded WHILE the verify streams its weights instead of in the gaps between
-                # its kernels.  Measured on MI355X (70B + 1B, k=7 f=3): 30.5 ms/step unpartitioned vs 38.5 / 37.0 / 36.2 ms
-                # with 32 / 64 / 96 draft CUs: the target's launches are sized for 256 CUs (224-256 workgroups of 16 waves),
-                # so on fewer CUs every one of them takes a second, nearly empty round (profiles/r02_cu_partition.txt).
-                ncu = int(os.environ.get("SSD_COLOCATED_CUS", "0")) if side is not None else 0
-                if ncu > 0:
-                    from ssd_amd.hip.ops import masked_stream
-                    total = torch.cuda.get_device_properties(self.topo.device).multi_processor_count
-                    side = masked_stream(self.topo.device, 0, ncu)
-                    self._target_stream = masked_stream(self.topo.device, ncu, total)
+                # (retired in round 5, both measured on MI355X and not worth a switch: a high-priority draft stream -- 29.0 vs 28.4 ms per
+                # step, profiles/r02_colocated_overlap.txt -- and a CU-mask partition of the chip between draft and target -- 36-38 vs
+                # 30.5 ms: the target's launches are sized for 256 CUs, profiles/r02_cu_partition.txt)
+                side = torch.cuda.Stream(self.topo.device) if on_gpu and os.environ.get("SSD_COLOCATED_OVERLAP", "1") != "0" else None
                 # the M-row resident segment (csrc/tree_segment.hip) keeps 256 workgroups waiting for each other: beside a verify that owns
                 # the CUs they come up one by one and spin -- measured on c4 (profiles/r05_c4_kernel_stats_with_glue_segment.txt): 85.6 us
                 # per glue launch against 27 us alone, and the CUs they hold are taken from the target.  "auto" keeps it for draft
@@ -197,9 +183,6 @@ class LLMEngine:
         self.scheduler.add(Sequence(prompt, sampling_params))
 
     def step(self, step: InferenceStep):
-        if self._target_stream is not None and torch.cuda.current_stream(self.topo.device) != self._target_stream:
-            with torch.cuda.stream(self._target_stream):
-                return self.step(step)
         t = perf_counter()
         seqs, is_prefill = self.scheduler.schedule()
         capped = []

@@ -103,8 +103,6 @@ SIGNATURES = {
                          c_void_p, c_void_p, c_void_p, c_void_p, C.c_uint, c_void_p, c_void_p, c_void_p, c_void_p,
                          c_void_p, c_int, c_float, c_void_p],
     "ssd_store_step_rows": [c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
-    "ssd_stream_create_cu_mask": [C.POINTER(c_void_p), c_void_p, c_int],
-    "ssd_stream_destroy": [c_void_p],
     "ssd_cache_lookup": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "ssd_draft_advance": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
                           c_void_p, c_int, c_void_p],

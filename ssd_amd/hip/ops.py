@@ -343,15 +343,3 @@ def store_step_rows(src, src_ld: int, dst, B: int, V: int, K: int, step):
     _check(load_library().ssd_store_step_rows(_p(src), src_ld, _p(dst), B, V, K, _p(step), _stream()), "ssd_store_step_rows")
 
 
-def masked_stream(device, cu_lo: int, cu_hi: int):
-    """torch stream confined to compute units [cu_lo, cu_hi) (csrc/misc.hip ssd_stream_create_cu_mask)."""
-    import ctypes as C
-    total = torch.cuda.get_device_properties(device).multi_processor_count
-    words = (total + 31) // 32
-    mask = (C.c_uint32 * words)()
-    for cu in range(max(0, cu_lo), min(total, cu_hi)):
-        mask[cu // 32] |= 1 << (cu % 32)
-    out = C.c_void_p()
-    with torch.cuda.device(device):
-        _check(load_library().ssd_stream_create_cu_mask(C.byref(out), C.cast(mask, C.c_void_p), words), "ssd_stream_create_cu_mask")
-    return torch.cuda.ExternalStream(out.value, device=device)

@@ -57,7 +57,8 @@ class RunGuard:
         self.stage_timeout = stage_timeout if stage_timeout is not None else env_float("SSD_STAGE_TIMEOUT_S", 900.0)
         self.total_deadline = total_deadline if total_deadline is not None else env_float("SSD_TOTAL_DEADLINE_S", 3000.0)
         port = os.environ.get("MASTER_PORT", "0")
-        self.share_dir = share_dir or os.environ.get("SSD_FAIL_DIR") or os.path.join("/tmp", f"ssd_run_{port}")
+        # failure records of one launch meet in a directory only its own user can write (the launcher may name it: SSD_FAIL_DIR)
+        self.share_dir = share_dir or os.environ.get("SSD_FAIL_DIR") or os.path.join("/tmp", f"ssd_run_{os.getuid()}_{port}")
         self.wall0 = time.time()
         self.stdout_rank = stdout_rank
         self.t0 = time.monotonic()
@@ -77,7 +78,30 @@ class RunGuard:
             self.cur_deadline = now + (timeout if timeout is not None else self.stage_timeout)
 
     def done(self) -> None:
+        """The result line is out.  From here on SIGTERM ends the process as it would without a guard (the no-op handler that feeds the
+        reader thread must not swallow it during the farewell barrier)."""
         self._done = True
+        if self._wfd is not None and threading.current_thread() is threading.main_thread():
+            try:
+                signal.set_wakeup_fd(-1)
+                signal.signal(signal.SIGTERM, signal.SIG_DFL)
+            except Exception:
+                pass
+
+    # DESIGN.md section 7: the code paths that execute for the FIRST time on a multi-GPU box, by the stage that contains them.  A path is
+    # "completed" once the run has moved past its stage (paths 6, 7, 9, 10 run inside the first captures / the timed steps).
+    FIRST_RUN_PATHS = (("process_group_init", 1), ("subgroup_creation", 2), ("kv_blocks_agree", 3), ("one_shot_allreduce_validation", 4),
+                       ("one_shot_allreduce_ipc_exchange", 5), ("ttft (", 6), ("ttft (", 7), ("draft_hello", 8), ("timed_steps", 9),
+                       ("timed_steps", 10))
+
+    def first_run_paths(self) -> dict:
+        """Which of DESIGN section 7's first-run paths this rank has been through (stage left behind), and which one it is in now."""
+        with self._lock:
+            past = [n for n, _ in self.history]
+            cur = self.cur
+        done = sorted({k for prefix, k in self.FIRST_RUN_PATHS if any(n.startswith(prefix) for n in past)})
+        inside = sorted({k for prefix, k in self.FIRST_RUN_PATHS if cur.startswith(prefix)})
+        return {"completed": done, "in_progress": inside, "of": "DESIGN.md section 7, rows 1-11 (11 = the final barrier, after the line)"}
 
     # ---- failure record ----
     def record(self, error: str, kind: str) -> dict:
@@ -86,6 +110,8 @@ class RunGuard:
         rec.update({"value": None, "error": error, "failure": kind, "stage": self.cur, "stage_elapsed_s": round(now - self.cur_t0, 2),
                     "elapsed_s": round(now - self.t0, 2), "rank": self.rank, "n_gpus": self.base.get("n_gpus", self.world),
                     "host": socket.gethostname(), "stages_done": [f"{n}:{t}s" for n, t in self.history[-12:]]})
+        if self.world > 1:
+            rec["first_run_paths"] = self.first_run_paths()
         return rec
 
     def _peer_records(self, wait: float) -> list[dict]:
@@ -122,7 +148,9 @@ class RunGuard:
                 time.sleep(1.0)
         rec = self.record(error, kind)
         try:
-            os.makedirs(self.share_dir, exist_ok=True)
+            os.makedirs(self.share_dir, mode=0o700, exist_ok=True)
+            if os.path.islink(self.share_dir) or os.stat(self.share_dir).st_uid != os.getuid():
+                raise PermissionError(f"{self.share_dir} is not ours")
             tmp = os.path.join(self.share_dir, f".fail_rank{self.rank}.tmp")
             with open(tmp, "w") as f:
                 json.dump(rec, f)
