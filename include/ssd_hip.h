@@ -218,7 +218,11 @@ int ssd_chain_segment(const void* a_frag, const void* res_in, void* res_out, voi
  * ssd/models/llama3.py:128-199) and the K+1-row glue decode (draft_runner.py:560-640).  Operands as ssd_chain_segment with M rows:
  * a_frag frag [M][qn], res_in / res_out / h_out rows [M][h] (res_out != res_in), positions / slots [M], q_out rows [M][nh*hd].
  * 256 resident workgroups; the all-to-all edges are 16-byte write-through stores + one flag word per producer workgroup, payload
- * read with sc1 loads; x^ of all M rows lives in LDS.  h in {1024, 2048}; no biases, no q/k norm.
+ * read with sc1 loads; x^ of all M rows lives in LDS.  h in {1024, 2048}; no biases.
+ * qkv_rows_next (models with a per-head q / k RMSNorm, ssd/models/qwen3.py:96-104: the norm needs a whole head, i.e. eight of this
+ * kernel's workgroups): instead of the RoPE + KV-store epilogue the NEXT layer's raw QKV projection rows [M][qkv_n] are written (in the
+ * rotation-paired order of its weights, qkv_perm = 1) for ssd_rope_store_kv / ssd_attn_paged_qkv; positions / cos_sin / slots / q_out /
+ * k_cache / v_cache are then NULL.
  *   workspace  ssd_tree_segment_workspace_bytes(h, I) bytes, zeroed ONCE at allocation (flags + the three hand-off buffers)
  *   gen / err  as ssd_chain_segment (one ssd_chain_tick per forward)
  * Returns SSD_ERR_LAUNCH when the device cannot keep 256 of its workgroups resident at once (they wait for each other). */
@@ -227,8 +231,8 @@ int ssd_tree_segment_ok(int M, int h, int qn, int I, int qkv_n, int nh, int nkv,
 int ssd_tree_segment(const void* a_frag, const void* res_in, void* res_out, void* h_out, const void* w_o, const void* w_gu,
                      const void* w_d, const void* w_qkv_next, const void* ln_post, const void* ln_next, float eps,
                      const int64_t* positions, const float* cos_sin, const int32_t* slots, void* q_out, void* k_cache, void* v_cache,
-                     int M, int h, int qn, int I, int qkv_n, int nh, int nkv, int hd, int block_size, int layer, void* workspace,
-                     const void* gen, void* err, void* stream);
+                     void* qkv_rows_next, int M, int h, int qn, int I, int qkv_n, int nh, int nkv, int hd, int block_size, int layer,
+                     void* workspace, const void* gen, void* err, void* stream);
 int ssd_argmax_parts(const float* part_val, const int32_t* part_idx, int nparts, long part_stride, int T, long idx_offset,
                      int64_t* out, int64_t* out2, int64_t* out3, long out3_stride, float* out_val, void* stream);
 int ssd_argmax_parts_verify(const float* part_val, const int32_t* part_idx, int nparts, long part_stride,

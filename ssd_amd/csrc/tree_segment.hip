@@ -56,6 +56,7 @@ struct TsParams {
   bf16_t* q_out;
   bf16_t* k_cache;
   bf16_t* v_cache;
+  bf16_t* qkv_rows;         // alternative to the RoPE epilogue (models with a per-head q / k norm): the next layer's raw QKV rows [M][qkv_n]
   unsigned* flags;          // [3][TS_GRID]
   const unsigned* gen;
   unsigned* err;
@@ -418,7 +419,12 @@ __global__ void __launch_bounds__(TS_THREADS) tree_segment_kernel(const TsParams
         float x[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) x[r] = round_bf_hw(s[r]);   // the reference stores qkv as bf16 before RoPE
-        if (grp < qk_groups) {
+        if (p.qkv_rows) {
+          // Qwen3: RMSHeadNorm sits between the projection and the rotation and needs a whole head (8 row groups = 8 workgroups here):
+          // the rows leave as the projection wrote them (rotation-paired order) and ssd_rope_store_kv / ssd_attn_paged_qkv go on
+          if (m < M)
+            *reinterpret_cast<u32x2_t*>(p.qkv_rows + (size_t)m * p.qkv_n + grp * 16 + nrow) = u32x2_t{pack_bf2_hw(x[0], x[1]), pack_bf2_hw(x[2], x[3])};
+        } else if (grp < qk_groups) {
           const int head = grp / gph, j = grp % gph;
           float other[4];
 #pragma unroll
@@ -500,11 +506,13 @@ extern "C" int ssd_tree_segment_ok(int M, int h, int qn, int I, int qkv_n, int n
 extern "C" int ssd_tree_segment(const void* a_frag, const void* res_in, void* res_out, void* h_out, const void* w_o, const void* w_gu,
                                 const void* w_d, const void* w_qkv_next, const void* ln_post, const void* ln_next, float eps,
                                 const int64_t* positions, const float* cos_sin, const int32_t* slots, void* q_out, void* k_cache,
-                                void* v_cache, int M, int h, int qn, int I, int qkv_n, int nh, int nkv, int hd, int block_size,
-                                int layer, void* workspace, const void* gen, void* err, void* stream) {
+                                void* v_cache, void* qkv_rows_next, int M, int h, int qn, int I, int qkv_n, int nh, int nkv, int hd,
+                                int block_size, int layer, void* workspace, const void* gen, void* err, void* stream) {
   if (int rc = ssd_tree_segment_ok(M, h, qn, I, qkv_n, nh, nkv, hd)) return rc;
   if (!a_frag || !res_in || !res_out || !w_o || !w_gu || !w_d || !ln_post || !workspace || !gen || !err) return SSD_ERR_ARG;
-  if (w_qkv_next ? (!ln_next || !positions || !cos_sin || !slots || !q_out || !k_cache || !v_cache || h_out) : !h_out) return SSD_ERR_ARG;
+  if (w_qkv_next && qkv_rows_next ? (!ln_next || positions || cos_sin || slots || q_out || k_cache || v_cache || h_out)
+      : w_qkv_next ? (!ln_next || !positions || !cos_sin || !slots || !q_out || !k_cache || !v_cache || h_out) : (!h_out || qkv_rows_next))
+    return SSD_ERR_ARG;
   if (res_out == res_in) return SSD_ERR_ARG;               // every workgroup re-reads res_in while chunk owners write res_out
   if (layer < 0 || layer > 63) return SSD_ERR_ARG;
   static const long budget = [] { const char* e = getenv("SSD_CHAIN_SPIN_BUDGET"); return e ? atol(e) : 200000L; }();
@@ -532,7 +540,7 @@ extern "C" int ssd_tree_segment(const void* a_frag, const void* res_in, void* re
   p.Wo = w_o; p.Wgu = w_gu; p.Wd = w_d; p.Wqkv = w_qkv_next;
   p.ln_post = (const bf16_t*)ln_post; p.ln_next = (const bf16_t*)ln_next;
   p.positions = positions; p.cos_sin = cos_sin; p.slots = slots;
-  p.q_out = (bf16_t*)q_out; p.k_cache = (bf16_t*)k_cache; p.v_cache = (bf16_t*)v_cache;
+  p.q_out = (bf16_t*)q_out; p.k_cache = (bf16_t*)k_cache; p.v_cache = (bf16_t*)v_cache; p.qkv_rows = (bf16_t*)qkv_rows_next;
   p.gen = (const unsigned*)gen; p.err = (unsigned*)err;
   p.eps = eps; p.M = M; p.h = h; p.qn = qn; p.I = I; p.qkv_n = qkv_n; p.nh = nh; p.nkv = nkv; p.hd = hd; p.bs = block_size; p.layer = layer;
   p.spin_budget = budget;

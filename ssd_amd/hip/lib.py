@@ -65,7 +65,7 @@ SIGNATURES = {
     "ssd_tree_segment_workspace_bytes": [c_int, c_int],
     "ssd_tree_segment_ok": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
     "ssd_tree_segment": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
-                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                          c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "ssd_selftest_bf16_cvt": [c_void_p, c_void_p],
     "ssd_gemm_wf_argmax": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],

@@ -232,11 +232,12 @@ def tree_segment_workspace_bytes(h: int, I: int) -> int:
 
 def tree_segment(a_frag, res_in, res_out, w_o, w_gu, w_d, ln_post, eps: float, M: int, h: int, qn: int, I: int, qkv_n: int, nh: int,
                  nkv: int, hd: int, block_size: int, layer: int, workspace, gen, err, *, h_out=None, w_qkv_next=None, ln_next=None,
-                 positions=None, cos_sin=None, slots=None, q_out=None, k_cache=None, v_cache=None):
-    """chain_segment for M token rows (csrc/tree_segment.hip): the tree-decode step / the glue decode of the async draft."""
+                 positions=None, cos_sin=None, slots=None, q_out=None, k_cache=None, v_cache=None, qkv_rows_next=None):
+    """chain_segment for M token rows (csrc/tree_segment.hip): the tree-decode step / the glue decode of the async draft.
+    qkv_rows_next: raw QKV rows of the next layer instead of the RoPE + KV-store epilogue (q / k norm models)."""
     _check(load_library().ssd_tree_segment(_p(a_frag), _p(res_in), _p(res_out), _p(h_out), _p(w_o), _p(w_gu), _p(w_d), _p(w_qkv_next),
                                            _p(ln_post), _p(ln_next), eps, _p(positions), _p(cos_sin), _p(slots), _p(q_out), _p(k_cache),
-                                           _p(v_cache), M, h, qn, I, qkv_n, nh, nkv, hd, block_size, layer, _p(workspace), _p(gen), _p(err),
+                                           _p(v_cache), _p(qkv_rows_next), M, h, qn, I, qkv_n, nh, nkv, hd, block_size, layer, _p(workspace), _p(gen), _p(err),
                                            _stream()), "ssd_tree_segment")
 
 

@@ -126,7 +126,8 @@ class HipDecoder:
         # 0.705 ms, c2 7.78 -> 7.50 ms / step, profiles/r04_chain_segment.txt).  SSD_CHAIN_SEG=1 forces it for every shape the
         # kernel accepts, =0 turns it off.
         _cs = os.environ.get("SSD_CHAIN_SEG", "auto")
-        _validated = (self.h, self.qn, self.I, self.qkv_n, self.hd) == (2048, 2048, 8192, 3072, 64)
+        _geo = (self.h, self.qn, self.I, self.qkv_n, self.hd)
+        _validated = _geo == (2048, 2048, 8192, 3072, 64)
         self.chain_seg = ((_cs == "1" or (_cs == "auto" and _validated)) and not cfg.qk_norm and tp_size == 1 and not self.use_coll
                           and taps is None and H.chain_segment_ok(self.h, self.qn, self.I, self.qkv_n, self.nh, self.nkv, self.hd))
         # the same segment for 2..30 token rows (csrc/tree_segment.hip): attention + ONE resident launch per layer instead of 7
@@ -138,7 +139,10 @@ class HipDecoder:
         _ts = os.environ.get("SSD_TREE_SEG", "auto")
         self.tree_seg_rows = 32 if _ts == "1" else 16
         self.tree_seg_colocated = False     # set by the engine for a draft server that shares its GPU with the target (llm_engine.py)
-        self.tree_seg = ((_ts == "1" or (_ts == "auto" and _validated)) and not cfg.qk_norm and tp_size == 1 and not self.use_coll
+        # (a q / k norm model -- Qwen3-0.6B, the draft of BASELINE configs[4] -- leaves the segment with raw QKV rows; the norm + RoPE +
+        #  KV store stay with ssd_rope_store_kv in front of the attention launch: 3 launches per layer instead of 8)
+        _validated_ts = _validated or _geo == (1024, 2048, 3072, 4096, 128)
+        self.tree_seg = ((_ts == "1" or (_ts == "auto" and _validated_ts)) and tp_size == 1 and not self.use_coll
                          and taps is None and max_tokens >= 2
                          and H.tree_segment_ok(2, self.h, self.qn, self.I, self.qkv_n, self.nh, self.nkv, self.hd))
         if self.chain_seg:
@@ -433,10 +437,19 @@ class HipDecoder:
         H.chain_tick(self.chain_gen)
         H.rmsnorm(self.buf_h, w["model.layers.0.input_layernorm.weight"], cfg.rms_norm_eps, T, self.h, res_in=None, res_out=res[start],
                   out_frag=self.buf_xf)
-        H.gemm_fused(w["model.layers.0.self_attn.qkv_proj.weight"], T, self.qkv_n, self.h, H.FEPI_QKV_ROPE, x_frag=self.buf_xf,
-                     positions=positions, cos_sin=self.cos_sin, slots=meta.slot_mapping, q_out=self.buf_q, k_cache=self.kv_cache[0, 0],
-                     v_cache=self.kv_cache[0, 1], nh=self.nh, nkv=self.nkv, hd=self.hd, block_size=self.block_size)
+        qk = cfg.qk_norm
+        if qk:
+            self._gemm(self.buf_xf, self.h, w["model.layers.0.self_attn.qkv_proj.weight"], self.qkv_n, self.buf_qkv, T, self.qkv_n)
+        else:
+            H.gemm_fused(w["model.layers.0.self_attn.qkv_proj.weight"], T, self.qkv_n, self.h, H.FEPI_QKV_ROPE, x_frag=self.buf_xf,
+                         positions=positions, cos_sin=self.cos_sin, slots=meta.slot_mapping, q_out=self.buf_q, k_cache=self.kv_cache[0, 0],
+                         v_cache=self.kv_cache[0, 1], nh=self.nh, nkv=self.nkv, hd=self.hd, block_size=self.block_size)
         for li in range(L):
+            if qk:      # per-head q / k RMSNorm + RoPE + KV store of the rows the previous segment (or the GEMM above) left in buf_qkv
+                p_ = f"model.layers.{li}.self_attn."
+                H.rope_store_kv(self.buf_qkv, positions, self.cos_sin, meta.slot_mapping, self.buf_q, self.kv_cache[li, 0], self.kv_cache[li, 1],
+                                T, self.nh, self.nkv, self.hd, self.block_size, q_norm_w=w[p_ + "q_norm.weight"],
+                                k_norm_w=w[p_ + "k_norm.weight"], eps=cfg.rms_norm_eps, qkv_perm=1)
             H.attn_paged(self.buf_q, self.kv_cache[li, 0], self.kv_cache[li, 1], meta.block_tables, self.max_blocks,
                          meta.context_lens, meta.B, T, meta.max_q, self.nh, self.nkv, self.hd, self.block_size, scale,
                          cu_q=None, q_per_seq=meta.q_per_seq, mode=meta.mode, tree_K=meta.tree_K, tree_mq=meta.tree_mq,
@@ -445,6 +458,8 @@ class HipDecoder:
             p = f"model.layers.{li}."
             last = li + 1 == L
             nxt = {} if last else dict(
+                w_qkv_next=w[f"model.layers.{li + 1}.self_attn.qkv_proj.weight"], ln_next=w[f"model.layers.{li + 1}.input_layernorm.weight"],
+                qkv_rows_next=self.buf_qkv) if qk else dict(
                 w_qkv_next=w[f"model.layers.{li + 1}.self_attn.qkv_proj.weight"], ln_next=w[f"model.layers.{li + 1}.input_layernorm.weight"],
                 positions=positions, cos_sin=self.cos_sin, slots=meta.slot_mapping, q_out=self.buf_q,
                 k_cache=self.kv_cache[li + 1, 0], v_cache=self.kv_cache[li + 1, 1])

@@ -1,6 +1,6 @@
 """The resident M-row layer segment (csrc/tree_segment.hip, ssd_tree_segment: o_proj -> add + norm -> gate_up + SiLU -> down_proj ->
 add + norm -> next layer's QKV + RoPE + KV store in ONE launch, for the async draft's K+1-row glue decode and its MQ_LEN-row tree
-steps) at the REAL Llama-3.2-1B geometry with PLAIN N(0, 0.02) weights (no damping):
+steps) at the REAL Llama-3.2-1B geometry (and Qwen3-0.6B's: q / k norm, h 1024) with PLAIN N(0, 0.02) weights (no damping):
 
   prefill -> glue (K + 1 = 8 rows, causal) -> device fork at V = 128256 -> K = 7 tree steps of 24 branches (structural tree mask)
 
@@ -58,13 +58,15 @@ def test_hardware_bf16_conversion_equals_the_integer_rounding(H):
     assert counts.tolist() == [0, 0], counts.tolist()
 
 
-@pytest.mark.parametrize("layers", [2, 16])
-def test_glue_fork_tree_vs_separate_launches_oracle_and_truth(H, monkeypatch, layers):
+@pytest.mark.parametrize("preset,layers", [("llama-3.2-1b", 2), ("llama-3.2-1b", 16), ("qwen3-0.6b", 3)])
+def test_glue_fork_tree_vs_separate_launches_oracle_and_truth(H, monkeypatch, preset, layers):
     from oracle import ops as O
     from oracle.model import OracleModel, Ctx
     from ssd_amd import weights as W
     from ssd_amd.model import AttnMeta
-    cfg = dataclasses.replace(PRESETS["llama-3.2-1b"], num_layers=layers)
+    # (qwen3-0.6b: h 1024, head dim 128, a per-head q / k RMSNorm between the projection and the rotation -- the segment then hands the
+    #  next layer's raw QKV rows to ssd_rope_store_kv: reference ssd/models/qwen3.py:90-108; the draft of BASELINE configs[4])
+    cfg = dataclasses.replace(PRESETS[preset], num_layers=layers)
     full = W.synthetic_state_dict(cfg, seed=13, std=0.02)
     bs, nblocks = 256, 3
     decs = {c: build(cfg, full, c, monkeypatch) for c in (False, True)}

@@ -293,10 +293,13 @@ def test_eight_layer_70b_cut_verify_and_tree_step_vs_oracle_and_exact_arithmetic
 def test_full_depth_70b_forward_vs_oracle(H):
     """The headline model at FULL depth (VERDICT r4 "missing" 2): all 80 layers of Llama-3.1-70B shapes, plain N(0, 0.02) weights,
     through HipDecoder -- a 32-token prefill and the metric's M = 8 verify -- against the oracle model (the reference's bf16 pipeline
-    restated, LlamaForCausalLM.forward, ssd/models/llama3.py:248-273) on the host: the logits of all 8 verify rows over the whole
-    vocabulary within the propagated-noise bar of 80 layers of bf16 intermediates, the argmax identical outside near-ties (oracle margin
-    under twice the row's deviation), the K / V rows the last layer wrote.  Not part of the default suite (time and host memory); its
-    log is committed under profiles/."""
+    restated, LlamaForCausalLM.forward, ssd/models/llama3.py:248-273) on the host AND against the float64 forward of the same weights
+    (tests/util.py truth_forward): at depth 80 two bf16 pipelines with different summation orders sit ~0.2 rms apart on a logit of
+    std 1.8 (first run: 0.206; rounding noise accumulates ~ sqrt(layers): 0.09 at 8 layers), so "HIP == oracle" is not a meaningful
+    bar any more -- the criterion of the shallower tests is: every verify row of the HIP logits is as close to EXACT arithmetic as the
+    oracle pipeline's row is (rms <= 1.25 x + 1e-3, max <= 1.5 x + 1e-3, all 128256 logits), an argmax may differ only where the
+    oracle's own margin is inside twice the row's deviation, and the K / V rows the last layer wrote agree to the propagated-noise
+    bar.  Not part of the default suite (time and host memory); its log is committed under profiles/."""
     from oracle.model import OracleModel, Ctx
     from ssd_amd import weights as W
     from ssd_amd.model import HipDecoder, AttnMeta
@@ -348,15 +351,23 @@ def test_full_depth_70b_forward_vs_oracle(H):
     print(f"70B x 80 layers verify M=8: logit std {scale:.3f}, |HIP-oracle| max {d.max().item():.4f} mean {d.mean().item():.5f} rms {d.pow(2).mean().sqrt().item():.5f}; "
           f"argmax equal on {int(same.sum())}/{M} rows, oracle top-2 margins {[round(float(x), 4) for x in (top2[:, 0] - top2[:, 1])]}")
     assert torch.isfinite(got).all()
-    assert d.max().item() <= 0.25 * max(1.0, scale) and d.mean().item() <= 0.04 * max(1.0, scale)      # (8 layers measured: 0.19 max at std 1.8)
+    truth = truth_forward(cfg, host, toks)[P:]
+    e_hip, e_ref = (got.double() - truth).abs(), (ref.double() - truth).abs()
+    rms = lambda e: e.pow(2).mean(-1).sqrt()
+    print(f"   |HIP-truth| max {e_hip.max().item():.4f} rms {rms(e_hip).mean().item():.5f} | |oracle-truth| max {e_ref.max().item():.4f} rms {rms(e_ref).mean().item():.5f}"
+          f" | per row rms HIP {[round(float(x), 4) for x in rms(e_hip)]} oracle {[round(float(x), 4) for x in rms(e_ref)]}")
+    assert bool((rms(e_hip) <= 1.25 * rms(e_ref) + 1e-3).all()), "a HIP row is further from exact arithmetic than the oracle pipeline's"
+    assert e_hip.max().item() <= 1.5 * e_ref.max().item() + 1e-3
     assert bool((same | ((top2[:, 0] - top2[:, 1]) < thr)).all())
+    ta = truth.argmax(-1)
+    print(f"   argmax vs exact arithmetic: HIP {int((got.argmax(-1) == ta).sum())}/{M}, oracle {int((ref.argmax(-1) == ta).sum())}/{M}")
     L = cfg.num_layers
     for which in (0, 1):
         ref_rows = torch.stack([orc.kv_cache[which, L - 1, table[p // bs], p % bs] for p in ps]).float()
         got_rows = torch.stack([dec.kv_cache[L - 1, which, table[p // bs], :, p % bs, :] for p in ps]).cpu().float()
         dkv = (got_rows - ref_rows).abs()
         print(f"   last layer {'KV'[which]} rows: |ref| max {ref_rows.abs().max().item():.3f}, |HIP-oracle| max {dkv.max().item():.4f} mean {dkv.mean().item():.5f}")
-        tol = 2.0 ** (math.floor(math.log2(ref_rows.abs().max().item())) - 3)
+        tol = 2.0 ** (math.floor(math.log2(ref_rows.abs().max().item())) - 2)          # (79 layers of propagated bf16 noise in front)
         assert dkv.max().item() <= tol and dkv.mean().item() <= tol / 8
 
 

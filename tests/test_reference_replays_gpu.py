@@ -232,11 +232,13 @@ def test_full_size_lockstep_with_undamped_layers(gpu, mode):
     every attention / MLP kernel's error reaches the token decisions unattenuated (at 0.05 it arrives 20x smaller: those runs pin the
     protocol, these pin the layer kernels through it).  The decoder layers now drown the shared embedding: the pair agrees rarely,
     nearly every async round is a miss -> JIT chain + glue + fork at V = 128256 + 7 tree steps of 24 branches, all with undamped
-    layers, compared decision by decision with the oracle.  Near-tie threshold: two bf16 pipelines of 32 (target) / 16 (draft)
-    undamped layers differ by up to ~0.1-0.15 on a logit (measured: tests/test_hip_tree_segment.py 16 layers 0.10,
-    test_eight_layer_70b_cut... 8 layers), so a decision whose ORACLE margin is under 0.25 cannot be held to either side; everything
-    else must match, and every excused decision re-synchronises both runs (teacher forcing) so the comparison reaches the last token."""
-    rep = _lockstep_full_size(mode, 24, layer_gain=1.0, thr=0.25, min_rounds=0.6, min_tokens=0.75, max_restarts=24)
+    layers, compared decision by decision with the oracle.  Two bf16 pipelines of 32 (target) / 16 (draft) undamped layers differ by up
+    to ~0.1-0.2 on a logit (measured: tests/test_hip_tree_segment.py 16 layers 0.10, test_eight_layer_70b_cut... 8 layers 0.19), yet the
+    near-tie threshold stays at TWO bf16 ulps of the ORACLE's own margin (0.125): an undamped random model's logits are nearly flat,
+    so near-ties are frequent BY CONSTRUCTION (first runs on MI355X, profiles/r05_lockstep_call8.txt: 10-11 of 24 rounds disputed, every
+    one of them at an oracle margin of 0 - 0.0625) -- hence the lower bar on compared rounds -- while every decision with a real margin
+    must match; an excused decision re-synchronises both runs (teacher forcing), so all 24 tokens are reached."""
+    rep = _lockstep_full_size(mode, 24, layer_gain=1.0, thr=0.125, min_rounds=0.45, min_tokens=0.75, max_restarts=24)
     if mode == "async":
         assert rep.real_misses > 0, rep.summary()
 
