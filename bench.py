@@ -221,7 +221,8 @@ def gemm_roofline(legs):
                     w_qkv_next=w[f"model.layers.{li + 1}.self_attn.qkv_proj.weight"], ln_next=w[f"model.layers.{li + 1}.input_layernorm.weight"],
                     positions=runner.d_pos, cos_sin=m.cos_sin, slots=runner.d_slots, q_out=m.buf_q, k_cache=m.kv_cache[li + 1, 0],
                     v_cache=m.kv_cache[li + 1, 1])
-                H_.chain_segment(m.buf_af, m.buf_res2, m.buf_res if last else m.buf_res2, w[p_ + "self_attn.o_proj.weight"],
+                rin, rout = (m.buf_res2, m.buf_res3) if li % 2 == 0 else (m.buf_res3, m.buf_res2)      # (as HipDecoder._forward_chain)
+                H_.chain_segment(m.buf_af, rin, m.buf_res if last else rout, w[p_ + "self_attn.o_proj.weight"],
                                  w[p_ + "mlp.gate_up_proj.weight"], w[p_ + "mlp.down_proj.weight"], w[p_ + "post_attention_layernorm.weight"],
                                  m.cfg.rms_norm_eps, m.h, m.qn, m.I, m.qkv_n, m.nh, m.nkv, m.hd, m.block_size, li, m.chain_gr, m.chain_gen,
                                  m.chain_err, h_out=m.buf_h if last else None, **nxt)

@@ -1,6 +1,7 @@
 """Round 5: the async draft's round pieces on the 1B draft with the resident M-row layer segment (csrc/tree_segment.hip) on / off, one
 process, the product runner's own hipGraphs: JIT chain (K single-token forwards), glue + fork (K+1 rows), K tree steps of MQ_LEN rows.
-    python profiles/tree_seg_probe.py [ctx] > gpurun_out/r05/tree_seg_probe.txt"""
+    python profiles/tree_seg_probe.py [ctx] [draft preset] [tree width] > gpurun_out/r05/tree_seg_probe.txt
+tree width < MQ_LEN = one member's branch slice under draft data-parallelism (BASELINE configs[4]: Qwen3-0.6B x 4 -> 6 rows per step)."""
 import json
 import os
 import sys
@@ -15,9 +16,8 @@ from ssd_amd.model_config import PRESETS  # noqa: E402
 from ssd_amd.utils.topology import Topology  # noqa: E402
 
 
-def runner(seg: str, K: int, F: int):
+def runner(seg: str, K: int, F: int, name: str = "llama-3.2-1b"):
     os.environ["SSD_TREE_SEG"] = seg
-    name = "llama-3.2-1b"
     cfg = Config(name, hf_config=PRESETS[name], draft=name, draft_hf_config=PRESETS[name], speculate=True, speculate_k=K,
                  draft_async=True, async_fan_out=F, jit_speculate=True, max_num_seqs=1, max_model_len=2048,
                  max_num_batched_tokens=2048, kvcache_block_size=256, num_kvcache_blocks=10, num_draft_kvcache_blocks=10)
@@ -38,19 +38,21 @@ def timed(fn, n=20):
 
 def main():
     ctx = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    name = sys.argv[2] if len(sys.argv) > 2 else "llama-3.2-1b"
     K, F = 7, 3
     MQ = F * (K + 1)
+    width = int(sys.argv[3]) if len(sys.argv) > 3 else MQ
     tables, nt, rec = [list(range(8))], [ctx], [17]
     fan = [[F] * (K + 1)]
-    jl = [[i // F for i in range(MQ)]]
+    jl = [[i // F for i in range(MQ)][:width]]
     res = {}
     for seg in ("0", "1"):
-        dr = runner(seg, K, F)
+        dr = runner(seg, K, F, name)
         assert dr.model.tree_seg == (seg == "1")
         toks = dr.draft_jit(rec, nt, tables)
         glue = torch.cat([torch.tensor([rec], device=toks.device), toks], dim=1)
-        forks = dr.draft_glue_fork(glue, nt, tables, fan)
-        out = {
+        forks = dr.draft_glue_fork(glue, nt, tables, fan)[:, :width].contiguous()
+        out = {"draft": name, "tree_rows": width,
             "jit_chain_ms": round(timed(lambda: dr.draft_jit(rec, nt, tables)), 3),
             "glue_fork_ms": round(timed(lambda: dr.draft_glue_fork(glue, nt, tables, fan)), 3),
             "tree_ms": round(timed(lambda: dr.draft_tree(forks, nt, tables, jl)), 3),
