@@ -140,9 +140,11 @@ class HipDecoder:
         self.tree_seg_rows = 32 if _ts == "1" else 16
         self.tree_seg_colocated = False     # set by the engine for a draft server that shares its GPU with the target (llm_engine.py)
         # (a q / k norm model -- Qwen3-0.6B, the draft of BASELINE configs[4] -- leaves the segment with raw QKV rows; the norm + RoPE +
-        #  KV store stay with ssd_rope_store_kv in front of the attention launch: 3 launches per layer instead of 8)
-        _validated_ts = _validated or _geo == (1024, 2048, 3072, 4096, 128)
-        self.tree_seg = ((_ts == "1" or (_ts == "auto" and _validated_ts)) and tp_size == 1 and not self.use_coll
+        #  KV store stay with ssd_rope_store_kv in front of the attention launch: 3 launches per layer instead of 8.  Parity-green at
+        #  that geometry (tests/test_hip_tree_segment.py) but NOT faster -- a 0.6B layer streams 15 MB, so the segment's fixed edge cost
+        #  is all there is: tree step 1.248 -> 1.240 ms at 6 rows, 1.275 -> 1.299 at 12, 1.363 -> 1.457 at 24,
+        #  profiles/r05_tree_seg_probe_qwen.txt -- so "auto" leaves it off there)
+        self.tree_seg = ((_ts == "1" or (_ts == "auto" and _validated)) and tp_size == 1 and not self.use_coll
                          and taps is None and max_tokens >= 2
                          and H.tree_segment_ok(2, self.h, self.qn, self.I, self.qkv_n, self.nh, self.nkv, self.hd))
         if self.chain_seg:
