@@ -166,6 +166,18 @@ int ssd_attn_paged(const void* q_rows, const void* k_cache, const void* v_cache,
                    int tree_mq, int tree_step, int tree_F, const int32_t* tree_jidx, int splits, int flags,
                    void* ws_o, void* ws_ml, void* out_rows, void* out_frag, void* stream);
 
+/* The same kernel under the names of the reference's two other attention call sites (thin forms: no split workspaces, one key range):
+ *   ssd_attn_prefill_varlen  flash_attn_varlen_func, ssd/layers/attention.py:90-93 -- B packed causal sequences (cu_q int32[B + 1]) over the
+ *                            paged cache this forward has just filled (context_lens = total lengths; T = cu_q[B] rows, max_q the longest)
+ *   ssd_attn_tree            the draft tree's custom-mask prefill, ssd/layers/attention.py:113-125 + ssd/engine/helpers/mask_helpers.py:12-21 --
+ *                            tree_mq branch rows per sequence at step tree_step (T = B * tree_mq), mask computed from (branch, step) */
+int ssd_attn_prefill_varlen(const void* q_rows, const void* k_cache, const void* v_cache, const int32_t* block_tables, int max_blocks,
+                            const int32_t* context_lens, const int32_t* cu_q, int B, int T, int max_q, int nh, int nkv, int hd,
+                            int block_size, float scale, void* out_rows, void* out_frag, void* stream);
+int ssd_attn_tree(const void* q_rows, const void* k_cache, const void* v_cache, const int32_t* block_tables, int max_blocks,
+                  const int32_t* context_lens, int B, int tree_K, int tree_mq, int tree_step, int tree_F, const int32_t* tree_jidx,
+                  int nh, int nkv, int hd, int block_size, float scale, void* out_rows, void* out_frag, void* stream);
+
 /* Attention + o_proj in ONE launch for the single-GPU drafts' decode / glue forwards: flash_attn_with_kvcache
  * (ssd/layers/attention.py:105-111,126-131) followed by RowParallelLinear o_proj (ssd/layers/linear.py:186-199, no all-reduce
  * at tp = 1).  One sequence, T causal (bottom-right aligned) query rows; parts = fp32 slabs [nkv][T][N], slab h = o_proj
@@ -351,6 +363,14 @@ int ssd_allreduce_gr_bf16(const void* in, void* out, long n, int rank, int world
 int ssd_allreduce_add_rmsnorm_gr_bf16(const void* in, const void* res_in, void* res_out, const void* weight, float eps,
                                       void* out_rows, void* out_frag, int T, int H, int rank, int world, void* const* inboxes,
                                       long gr_cap, void* counters, void* err, long spin_budget, void* stream);
+
+/* hipGraph capture for a host that is not PyTorch -- the reference captures its decode / verify / glue / tree steps with
+ * torch.cuda.CUDAGraph (ssd/engine/helpers/cudagraph_helpers.py:20-120); every entry point above only enqueues on `stream`, so the calls
+ * between ssd_graph_begin and ssd_graph_end become ONE replayable graph.  stream: a non-null hipStream_t; *out_exec: the executable graph. */
+int ssd_graph_begin(void* stream);
+int ssd_graph_end(void* stream, void** out_exec);
+int ssd_graph_launch(void* exec, void* stream);
+int ssd_graph_destroy(void* exec);
 
 #ifdef __cplusplus
 }

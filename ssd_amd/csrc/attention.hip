@@ -754,4 +754,25 @@ extern "C" int ssd_attn_paged_qkv(const void* qkv_rows, const int64_t* positions
   return hd == 128 ? attn_launch<128>(p, B, T, q_per_seq, waves, rt1, st) : attn_launch<64>(p, B, T, q_per_seq, waves, rt1, st);
 }
 
+// The reference's two other attention call sites under their own names (SURVEY section 8b's list): thin forms of ssd_attn_paged, which already
+// covers them as modes.
+//   ssd_attn_prefill_varlen -- flash_attn_varlen_func, ssd/layers/attention.py:90-93: causal attention of B packed sequences (cu_q int32 [B + 1])
+//                              over the paged cache the same forward has just filled (context_lens = the sequences' total lengths).
+//   ssd_attn_tree           -- the flashinfer custom-mask prefill of the draft tree, ssd/layers/attention.py:113-125 + mask_helpers.py:12-21:
+//                              tree_mq branch rows per sequence at tree step `tree_step`, structural mask (no mask tensor, no plan()).
+extern "C" int ssd_attn_prefill_varlen(const void* q_rows, const void* k_cache, const void* v_cache, const int32_t* block_tables, int max_blocks,
+                                       const int32_t* context_lens, const int32_t* cu_q, int B, int T, int max_q, int nh, int nkv, int hd,
+                                       int block_size, float scale, void* out_rows, void* out_frag, void* stream) {
+  if (!cu_q) return SSD_ERR_ARG;
+  return ssd_attn_paged(q_rows, k_cache, v_cache, block_tables, max_blocks, context_lens, cu_q, 0, B, T, max_q, nh, nkv, hd, block_size, scale, 0, 0,
+                        0, 0, 1, nullptr, 1, 0, nullptr, nullptr, out_rows, out_frag, stream);
+}
+extern "C" int ssd_attn_tree(const void* q_rows, const void* k_cache, const void* v_cache, const int32_t* block_tables, int max_blocks,
+                             const int32_t* context_lens, int B, int tree_K, int tree_mq, int tree_step, int tree_F, const int32_t* tree_jidx,
+                             int nh, int nkv, int hd, int block_size, float scale, void* out_rows, void* out_frag, void* stream) {
+  if (tree_mq <= 0 || tree_K <= 0 || tree_step < 0) return SSD_ERR_SHAPE;
+  return ssd_attn_paged(q_rows, k_cache, v_cache, block_tables, max_blocks, context_lens, nullptr, tree_mq, B, B * tree_mq, tree_mq, nh, nkv, hd,
+                        block_size, scale, 1, tree_K, tree_mq, tree_step, tree_F, tree_jidx, 1, 0, nullptr, nullptr, out_rows, out_frag, stream);
+}
+
 KT_DEFINE_SETTER(attention)

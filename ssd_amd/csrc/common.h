@@ -72,11 +72,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // chunk -> thread mapping fixes the fp32 summation order, and the fused all-reduce + norm is bit-identical to the unfused
 // pair).  A row is a latency chain (load, reduce, scale, store): hidden sizes >= 4096 get 1024 threads, i.e. at most two
 // 8-element chunks per thread instead of four to eight (profiles/r02_norm_probe.txt).
-static inline int ssd_norm_threads(int H) {
-  static const int forced = [] { const char* e = getenv("SSD_NORM_THREADS"); return e ? atoi(e) : 0; }();   // tuning override
-  if (forced == 256 || forced == 1024) return forced;
-  return H >= 4096 ? 1024 : 256;
-}
+static inline int ssd_norm_threads(int H) { return H >= 4096 ? 1024 : 256; }
 
 // Default decomposition of the skinny (M <= 16 token rows) weight-streaming GEMMs, from the MI355X sweep in
 // profiles/r01_gemm_tune_sweep.txt (python profiles/tune_gemm.py): groups = N / 16 row groups, KT = K / 32 k-tiles.

@@ -102,3 +102,31 @@ extern "C" int ssd_store_step_rows(const void* src_rows, long src_ld, void* dst,
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
+
+// hipGraph capture for a host that is not PyTorch (the reference captures its decode / verify / glue / tree steps with torch.cuda.CUDAGraph,
+// ssd/engine/helpers/cudagraph_helpers.py:20-120; this repo's engine does the same through torch on ROCm, where that IS hipGraph): every
+// entry point of this library only enqueues on `stream`, so whatever sequence of calls lies between begin and end becomes one replayable
+// graph.  ssd_graph_end returns an executable graph handle; launch it as often as wanted, destroy it once.
+extern "C" int ssd_graph_begin(void* stream) {
+  if (!stream) return SSD_ERR_ARG;                          // the legacy null stream cannot be captured
+  return hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal) == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+extern "C" int ssd_graph_end(void* stream, void** out_exec) {
+  if (!stream || !out_exec) return SSD_ERR_ARG;
+  hipGraph_t g = nullptr;
+  if (hipStreamEndCapture((hipStream_t)stream, &g) != hipSuccess || !g) return SSD_ERR_LAUNCH;
+  hipGraphExec_t e = nullptr;
+  const hipError_t rc = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (rc != hipSuccess) return SSD_ERR_LAUNCH;
+  *out_exec = (void*)e;
+  return SSD_OK;
+}
+extern "C" int ssd_graph_launch(void* exec, void* stream) {
+  if (!exec) return SSD_ERR_ARG;
+  return hipGraphLaunch((hipGraphExec_t)exec, (hipStream_t)stream) == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+extern "C" int ssd_graph_destroy(void* exec) {
+  if (!exec) return SSD_ERR_ARG;
+  return hipGraphExecDestroy((hipGraphExec_t)exec) == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}

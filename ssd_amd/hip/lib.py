@@ -53,6 +53,14 @@ SIGNATURES = {
     "ssd_attn_paged_qkv": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int,
                            c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p,
                            c_int, c_void_p, c_void_p, c_void_p],
+    "ssd_attn_prefill_varlen": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                c_int, c_float, c_void_p, c_void_p, c_void_p],
+    "ssd_attn_tree": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int,
+                      c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
+    "ssd_graph_begin": [c_void_p],
+    "ssd_graph_end": [c_void_p, C.POINTER(c_void_p)],
+    "ssd_graph_launch": [c_void_p, c_void_p],
+    "ssd_graph_destroy": [c_void_p],
     "ssd_attn_oproj_parts": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                              c_void_p, c_int, c_void_p, c_void_p],
     "ssd_gemm_wf_argmax_parts": [c_int, c_int, c_int],

@@ -222,6 +222,49 @@ def chain_segment(a_frag, res_in, res_out, w_o, w_gu, w_d, ln_post, eps: float, 
                                             _stream()), "ssd_chain_segment")
 
 
+def attn_prefill_varlen(q_rows, k_cache, v_cache, block_tables, max_blocks, context_lens, cu_q, B, T, max_q, nh, nkv, hd, block_size, scale,
+                        out_rows=None, out_frag=None):
+    _check(load_library().ssd_attn_prefill_varlen(_p(q_rows), _p(k_cache), _p(v_cache), _p(block_tables), max_blocks, _p(context_lens), _p(cu_q),
+                                                  B, T, max_q, nh, nkv, hd, block_size, scale, _p(out_rows), _p(out_frag), _stream()),
+           "ssd_attn_prefill_varlen")
+
+
+def attn_tree(q_rows, k_cache, v_cache, block_tables, max_blocks, context_lens, B, tree_K, tree_mq, tree_step, tree_F, nh, nkv, hd, block_size,
+              scale, tree_jidx=None, out_rows=None, out_frag=None):
+    _check(load_library().ssd_attn_tree(_p(q_rows), _p(k_cache), _p(v_cache), _p(block_tables), max_blocks, _p(context_lens), B, tree_K, tree_mq,
+                                        tree_step, tree_F, _p(tree_jidx), nh, nkv, hd, block_size, scale, _p(out_rows), _p(out_frag), _stream()),
+           "ssd_attn_tree")
+
+
+class CGraph:
+    """hipGraph capture through the C ABI alone (ssd_graph_begin / _end / _launch / _destroy): what a host without torch would use; torch hosts
+    keep torch.cuda.CUDAGraph.  `with CGraph(stream) as g: <libssdhip calls on that stream>`, then g.launch()."""
+
+    def __init__(self, stream: "torch.cuda.Stream"):
+        self.stream, self.exec = stream, None
+
+    def __enter__(self):
+        _check(load_library().ssd_graph_begin(self.stream.cuda_stream), "ssd_graph_begin")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        import ctypes as C
+        out = C.c_void_p()
+        rc = load_library().ssd_graph_end(self.stream.cuda_stream, C.byref(out))
+        if et is None:
+            _check(rc, "ssd_graph_end")
+            self.exec = out.value
+        return False
+
+    def launch(self):
+        _check(load_library().ssd_graph_launch(self.exec, self.stream.cuda_stream), "ssd_graph_launch")
+
+    def destroy(self):
+        if self.exec:
+            _check(load_library().ssd_graph_destroy(self.exec), "ssd_graph_destroy")
+            self.exec = None
+
+
 def tree_segment_ok(M: int, h: int, qn: int, I: int, qkv_n: int, nh: int, nkv: int, hd: int) -> bool:
     return load_library().ssd_tree_segment_ok(M, h, qn, I, qkv_n, nh, nkv, hd) == 0
 

@@ -156,7 +156,6 @@ class HipDecoder:
         if self.tree_seg:
             self.tree_ws = z(H.tree_segment_workspace_bytes(self.h, self.I) // 8, dtype=torch.int64)
             self.buf_res_b = z(min(T, 32), self.h)        # the residual ping-pongs: every workgroup re-reads a layer's input residual
-        self._prefill_waves = int(os.environ.get("SSD_ATTN_PREFILL_WAVES", "0"))
         self._last_parts = False        # set by forward() for the compute_logits that follows it
         pt = min(T, 32)
         self.buf_parts_o = z(16 * pt * self.h, dtype=torch.float32) if self.use_parts else None
@@ -328,8 +327,8 @@ class HipDecoder:
         groups = -(-row_tiles // 2) if row_tiles > 8 else row_tiles       # csrc/attention.hip attn_launch
         base = max(1, groups * meta.B * self.nkv)
         waves = max(1, min(8, 512 // base))
-        if meta.cu_q is not None and self._prefill_waves:       # prefill: tuning override (SSD_ATTN_PREFILL_WAVES).  Measured on c4:
-            waves = self._prefill_waves                         # TTFT 30.92 ms (default, 2 waves) / 30.68 (4) / 30.74 (8): within noise, not adopted
+        # (prefill with 4 / 8 waves per workgroup, measured on c4: TTFT 30.92 ms (this heuristic, 2 waves) / 30.68 / 30.74 -- within noise, and
+        #  another accumulation order: not adopted, the override switch retired in round 5)
         ctx = self.ctx_bucket(meta.ctx_hint if meta.ctx_hint > 0 else self.max_model_len)
         splits = 1 if ctx <= 1024 else max(1, min(self.max_splits, ctx // 512))
         if base >= 256 or T > self.max_split_tokens:

@@ -495,6 +495,58 @@ def test_attn_tree(H, splits):
     assert_close_bf16(got, ref, what="tree non-uniform", **ATTN_TOL)
 
 
+def test_attention_under_the_reference_call_site_names_and_the_c_graph_helpers(H):
+    """ssd_attn_prefill_varlen (attention.py:90-93) and ssd_attn_tree (attention.py:113-125) are ssd_attn_paged under the names of the call
+    sites they replace: bit-equal to the mode they wrap.  ssd_graph_begin / _end / _launch / _destroy capture library calls into a hipGraph
+    without torch's graph machinery: replays reproduce the eager bits."""
+    nh, nkv, hd, bs = 8, 2, 128, 16
+    lens = [5, 128, 33]
+    kc, vc, bt, mb = make_paged(3, lens, nkv, hd, bs, seed=9)
+    torch.manual_seed(1)
+    T = sum(lens)
+    q = torch.randn(T, nh, hd).to(BF)
+    cu = torch.tensor([0, 5, 133, 166], dtype=torch.int32)
+    ctx = torch.tensor(lens, dtype=torch.int32)
+    want = run_attn(H, q.view(T, -1), kc, vc, bt, mb, ctx, nh, nkv, hd, bs, cu_q=cu, splits=1)
+    kd, vd = dev(LY.kv_nhd_to_hnd(kc)), dev(LY.kv_nhd_to_hnd(vc))
+    out = torch.zeros(T, nh * hd, dtype=BF, device="cuda")
+    H.attn_prefill_varlen(dev(q.view(T, -1)), kd, vd, dev(bt), mb, dev(ctx), dev(cu), 3, T, 128, nh, nkv, hd, bs, hd ** -0.5, out_rows=out)
+    assert torch.equal(out.cpu().view(torch.int16), want.view(torch.int16))
+    K, F = 3, 2
+    MQ = F * (K + 1)
+    ctx_lens = [40 + K + 1 + 2 * MQ, 17 + K + 1 + 2 * MQ]
+    kc, vc, bt, mb = make_paged(2, ctx_lens, nkv, hd, bs, seed=5)
+    q = torch.randn(2 * MQ, nh, hd).to(BF)
+    ctx = torch.tensor(ctx_lens, dtype=torch.int32)
+    want = run_attn(H, q.view(2 * MQ, -1), kc, vc, bt, mb, ctx, nh, nkv, hd, bs, q_per_seq=MQ, splits=1, mode=H.MODE_TREE, tree_K=K, tree_mq=MQ,
+                    tree_step=1, tree_F=F)
+    kd, vd = dev(LY.kv_nhd_to_hnd(kc)), dev(LY.kv_nhd_to_hnd(vc))
+    out = torch.zeros(2 * MQ, nh * hd, dtype=BF, device="cuda")
+    qd, btd, ctxd = dev(q.view(2 * MQ, -1)), dev(bt), dev(ctx)
+    H.attn_tree(qd, kd, vd, btd, mb, ctxd, 2, K, MQ, 1, F, nh, nkv, hd, bs, hd ** -0.5, out_rows=out)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu().view(torch.int16), want.view(torch.int16))
+    # the same call + a norm over its output, captured through the C ABI's graph helpers and replayed
+    w = dev((1 + 0.1 * torch.randn(nh * hd)).to(BF))
+    y = torch.zeros(2 * MQ, nh * hd, dtype=BF, device="cuda")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        H.attn_tree(qd, kd, vd, btd, mb, ctxd, 2, K, MQ, 1, F, nh, nkv, hd, bs, hd ** -0.5, out_rows=out)
+        H.rmsnorm(out, w, 1e-6, 2 * MQ, nh * hd, out_rows=y)
+        s.synchronize()
+        eager = y.clone()
+        with H.CGraph(s) as g:
+            H.attn_tree(qd, kd, vd, btd, mb, ctxd, 2, K, MQ, 1, F, nh, nkv, hd, bs, hd ** -0.5, out_rows=out)
+            H.rmsnorm(out, w, 1e-6, 2 * MQ, nh * hd, out_rows=y)
+        for _ in range(3):
+            y.zero_()
+            out.zero_()
+            g.launch()
+            s.synchronize()
+            assert torch.equal(y.view(torch.int16), eager.view(torch.int16))
+        g.destroy()
+
+
 def test_attn_softmax_spike(H):
     """A key that dominates one query row late in the scan forces the online-softmax rescale branch."""
     nh, nkv, hd, bs = 4, 1, 128, 16
