@@ -90,3 +90,53 @@ def test_bench_py_itself_without_a_gpu_prints_one_failure_record():
     rec = lines[0]
     assert rec["value"] is None and rec["n_gpus"] == 2 and "no CPU fallback" in rec["error"] and rec["stage"].startswith("runner_init"), rec
     assert {"metric", "unit", "steps", "warmup", "higher_is_better", "config"} <= set(rec)
+
+
+def test_failure_records_say_which_first_run_paths_were_completed():
+    """a multi-rank record names the rows of DESIGN.md section 7 the rank had been through when it failed."""
+    rc, dt, lines, err = launch("tp2", 2, "rank=1,after=3,kind=raise")
+    assert len(lines) == 1, (lines, err[-2000:])
+    fr = lines[0]["first_run_paths"]
+    assert 1 in fr["completed"] and 2 in fr["completed"], fr            # process group + subgroups were up when the steps started
+    assert set(fr["in_progress"]) == {9, 10}, fr                        # ... and the failure hit inside the timed steps
+    from ssd_amd.utils.watchdog import RunGuard
+    g = RunGuard(0, 2, {})
+    for n in ("process_group_init", "subgroup_creation (tp / async p2p / control / draft groups)", "one_shot_allreduce_validation (helper processes)",
+              "ttft (first prefill + first speculation round: graph captures, first collectives in graphs)"):
+        g.stage(n)
+    assert g.first_run_paths() == {"completed": [1, 2, 4], "in_progress": [6, 7], "of": g.first_run_paths()["of"]}
+
+
+def test_a_signal_to_the_self_launching_bench_reaches_its_ranks(tmp_path):
+    """`python bench.py --gpus N` starts its ranks in a session of their own; SIGTERM to the launcher (a harness time-out, Ctrl-C) must
+    take them down with it instead of leaving them on the GPUs until their own watchdog ends them."""
+    import signal
+    script = tmp_path / "sleepy_bench.py"
+    script.write_text(f"import sys, time\nsys.path.insert(0, {ROOT!r})\nimport bench\n"
+                      "import subprocess\n"
+                      "orig = subprocess.Popen\n"
+                      "def fake(cmd, **kw):\n"
+                      "    return orig([sys.executable, '-c', 'import time, os; open(os.environ[\"PIDFILE\"], \"w\").write(str(os.getpid())); time.sleep(120)'], **kw)\n"
+                      "bench.subprocess.Popen = fake\n"
+                      "class A: gpus = 2\n"
+                      "sys.exit(bench.self_launch(A()))\n")
+    pidfile = tmp_path / "rank.pid"
+    p = subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, PIDFILE=str(pidfile), PYTHONPATH=ROOT), stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE)
+    for _ in range(100):
+        if pidfile.exists() and pidfile.read_text():
+            break
+        time.sleep(0.1)
+    child = int(pidfile.read_text())
+    p.send_signal(signal.SIGTERM)
+    p.wait(timeout=30)
+    for _ in range(50):
+        try:
+            os.kill(child, 0)
+        except ProcessLookupError:
+            break
+        time.sleep(0.1)
+    else:
+        os.kill(child, signal.SIGKILL)
+        raise AssertionError("the rank outlived its launcher")
+    assert p.returncode == 128 + signal.SIGTERM
