@@ -56,8 +56,9 @@ def test_the_dedicated_draft_rank_dies_mid_run():
 
 
 def test_a_rank_that_wedges_without_dying_is_timed_out():
-    rc, dt, lines, err = launch("tp2", 2, "rank=1,after=3,kind=hang", extra_env={"SSD_STAGE_TIMEOUT_S": "8"})
-    assert rc != 0 and dt < 60, (rc, dt)
+    # (the stage limit also covers start-up on a busy box: 15 s, not 8 -- one in-suite run of round 5 failed here under load)
+    rc, dt, lines, err = launch("tp2", 2, "rank=1,after=3,kind=hang", extra_env={"SSD_STAGE_TIMEOUT_S": "15"}, limit=90.0)
+    assert rc != 0 and dt < 90, (rc, dt)
     assert len(lines) == 1, (lines, err[-2000:])
     rec = lines[0]
     assert rec["failure"] == "timeout" and rec["stage"] == "timed_steps" and rec["rank"] == 0, rec
@@ -66,8 +67,8 @@ def test_a_rank_that_wedges_without_dying_is_timed_out():
 def test_three_ranks_target_tp2_plus_draft_the_draft_wedges():
     """TP = 2 + a dedicated draft rank (the shape of configs[3] / [4]): the draft stops answering; the head rank waits in a recv,
     the other target rank in the reply broadcast -- both must be ended by their stage limit, one line on stdout."""
-    rc, dt, lines, err = launch("tp2+draft", 3, "rank=2,after=2,kind=hang", extra_env={"SSD_STAGE_TIMEOUT_S": "10"})
-    assert rc != 0 and dt < 60, (rc, dt)
+    rc, dt, lines, err = launch("tp2+draft", 3, "rank=2,after=2,kind=hang", extra_env={"SSD_STAGE_TIMEOUT_S": "15"}, limit=90.0)
+    assert rc != 0 and dt < 90, (rc, dt)
     assert len(lines) == 1, (lines, err[-2000:])
     assert lines[0]["failure"] == "timeout" and lines[0]["stage"] == "timed_steps", lines[0]
 
