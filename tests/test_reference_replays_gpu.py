@@ -226,6 +226,17 @@ def test_full_size_async_k7_f3_llama8b_target_1b_draft(gpu):
     assert rep.partial_accepts > 0 and max(rep.accepted_lens) > 2, rep.summary()
 
 
+def test_full_size_async_with_the_resident_segments_beside_the_verify(gpu, monkeypatch):
+    """The M-row resident segment at engine level and under the load it is hardest to get right under: SSD_TREE_SEG=1 forces it for
+    the glue decode AND the 24-row tree steps of the co-located draft server, whose round runs on its own stream WHILE the target's
+    verify streams 16 GB next to it -- the 256 workgroups come up one by one, spin on each other's flags and read each other's rows
+    beside foreign traffic (the uneven-load case a hand-off protocol must survive: a stale row would flip a token).  Same lock-step
+    comparison with the oracle engine as above: hit flags, replied tokens, accepted suffixes, near-ties only by the oracle's margin."""
+    monkeypatch.setenv("SSD_TREE_SEG", "1")
+    rep = _lockstep_full_size("async", 48, min_rounds=0.8)
+    assert rep.hits > 0 and rep.partial_accepts > 0, rep.summary()
+
+
 @pytest.mark.parametrize("mode", ["sync", "async"])
 def test_full_size_lockstep_with_undamped_layers(gpu, mode):
     """The same two lock-step runs with layer_gain 1.0: o_proj / down_proj at their plain N(0, 0.02) scale, so
