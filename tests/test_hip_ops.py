@@ -530,6 +530,7 @@ def test_attention_under_the_reference_call_site_names_and_the_c_graph_helpers(H
     w = dev((1 + 0.1 * torch.randn(nh * hd)).to(BF))
     y = torch.zeros(2 * MQ, nh * hd, dtype=BF, device="cuda")
     s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())      # (non-blocking side stream: order it behind the zero fills above)
     with torch.cuda.stream(s):
         H.attn_tree(qd, kd, vd, btd, mb, ctxd, 2, K, MQ, 1, F, nh, nkv, hd, bs, hd ** -0.5, out_rows=out)
         H.rmsnorm(out, w, 1e-6, 2 * MQ, nh * hd, out_rows=y)

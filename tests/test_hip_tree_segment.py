@@ -206,6 +206,8 @@ def test_segment_replays_in_a_graph_bit_identically_under_load(H, monkeypatch):
     dec.kv_cache.normal_(0, 0.5)
     s, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     big = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    s.wait_stream(torch.cuda.current_stream())      # side streams are non-blocking: order the cache fill in front of the forward
+    s2.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
         dec.forward(ids, pos, MQ, meta)
         dec.compute_logits(MQ)
