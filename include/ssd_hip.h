@@ -233,7 +233,7 @@ int ssd_chain_segment(const void* a_frag, const void* res_in, void* res_out, voi
  * read with sc1 loads; x^ of all M rows lives in LDS.  h in {1024, 2048}; no biases.
  * qkv_rows_next (models with a per-head q / k RMSNorm, ssd/models/qwen3.py:96-104: the norm needs a whole head, i.e. eight of this
  * kernel's workgroups): instead of the RoPE + KV-store epilogue the NEXT layer's raw QKV projection rows [M][qkv_n] are written (in the
- * rotation-paired order of its weights, qkv_perm = 1) for ssd_rope_store_kv / ssd_attn_paged_qkv; positions / cos_sin / slots / q_out /
+ * rotation-paired order of its weights, qkv_perm = 1) for ssd_rope_store_kv; positions / cos_sin / slots / q_out /
  * k_cache / v_cache are then NULL.
  *   workspace  ssd_tree_segment_workspace_bytes(h, I) bytes, zeroed ONCE at allocation (flags + the three hand-off buffers)
  *   gen / err  as ssd_chain_segment (one ssd_chain_tick per forward)
@@ -300,7 +300,9 @@ int ssd_fork_topf(const void* logits_rows, long ld, int V, const int64_t* return
                   const int32_t* offsets, int B, int K, int mq, int64_t* out, void* stream);
 /* The same selection spread over the chip (every row cut into slices of <= 4096 logits, per-slice top-F candidates in `workspace`
  * -- ssd_fork_topf_workspace_bytes(V, B, K) bytes -- then one wave per row merges them): bit-equal to ssd_fork_topf, two short
- * launches instead of B*(K+1) workgroups walking whole vocabulary rows F times (84.7 -> ~8 us at V = 128256).  V % 8 == 0. */
+ * launches instead of B*(K+1) workgroups walking whole vocabulary rows F times (84.7 -> ~8 us at V = 128256).  V % 8 == 0 and
+ * V <= 196608 (48 slices): ssd_fork_topf_workspace_bytes returns SSD_ERR_SHAPE (< 0) for a vocabulary the split form refuses --
+ * the predicate a caller gates on before it captures the call in a graph. */
 int ssd_fork_topf_workspace_bytes(int V, int B, int K);
 int ssd_fork_topf_split(const void* logits_rows, long ld, int V, const int64_t* returned_tokens, const int32_t* counts,
                         const int32_t* offsets, int B, int K, int mq, void* workspace, int64_t* out, void* stream);

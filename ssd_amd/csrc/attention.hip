@@ -40,18 +40,6 @@ struct AttnParams {
   const u32x4_t* ow;         // o_proj weights, fragment-major [oN][nh*HD]
   float* oparts;             // fp32 slabs [nkv][Tq][oN]: slab h = W_o[:, columns of kv head h's q heads] . attention output of those heads
   int oN;
-  // QKV = true (round 4): the queries and the NEW keys / values come straight from the QKV projection's rows -- the per-head
-  // q / k RMSNorm (Qwen3), RoPE and the paged KV store of ssd_rope_store_kv happen inside this launch (ssd_attn_paged_qkv)
-  const bf16_t* qkv;         // [T][(nh + 2 nkv) * HD] raw projection rows
-  const int64_t* positions;  // [T]
-  const float* cos_sin;      // [max_pos][HD] fp32 (cos | sin)
-  const int32_t* slots;      // [T] paged-cache slot of each new token (-1: store nothing)
-  const bf16_t* qn_w;        // [HD] or null
-  const bf16_t* kn_w;        // [HD] or null
-  bf16_t* kc_w;              // the same caches, writable
-  bf16_t* vc_w;
-  float eps;
-  int perm;                  // 1: q / k heads in the rotation-paired column order of ssd_rows_to_frag_qkv
 };
 
 // LDS per wave: the V tile (32 keys x HD bf16) during the scan, then the wave's partial (O fp32 [RT*16][HD],
@@ -66,7 +54,7 @@ constexpr int attn_region_bytes() { return RT * 16 * HD * 4 + RT * 16 * 8; }
 // normalised bf16 output of its heads in LDS as an MFMA B operand and multiplies: slab h of the split-K partial sums of
 // o_proj, summed by the consumer like ssd_gemm_parts' slabs.  The weight stream hides behind the attention latency chain and
 // one kernel boundary per layer disappears (a 1B draft decode layer: 6.6 us attention + 3.9 us o_proj as two launches).
-template <int HD, int RT, int KT, bool OPROJ = false, bool QKV = false>
+template <int HD, int RT, int KT, bool OPROJ = false>
 __global__ void __launch_bounds__(512) attn_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KTS = OPROJ ? 7 : 6;        // trace slot (profiling builds only)
@@ -93,64 +81,6 @@ __global__ void __launch_bounds__(512) attn_kernel(const AttnParams p) {
   const int32_t* bt = p.block_tables + (size_t)b * p.max_blocks;
   const int z = blockIdx.z;
 
-  if constexpr (QKV) {
-    // ---- the NEW keys / values of (sequence b, kv head h): norm + RoPE + paged store, rope_store_kernel's code for the k heads
-    // and the v copy.  Every workgroup of this (b, h) -- one per row tile -- writes the same bytes to the same slots and reads
-    // them back through the page table below only after its OWN stores have completed (vmcnt(0) + barrier): whichever copy it
-    // sees is identical.  (Tq <= 32 rows: a few hundred 16-byte items.) ----
-    constexpr int half = HD / 2, c16 = HD >> 4, c8 = HD >> 3;
-    const int row_w = (p.nh + 2 * p.nkv) * HD;
-    for (int it = threadIdx.x; it < Tq * (c16 + c8); it += blockDim.x) {
-      if (it < Tq * c16) {
-        const int t = it / c16, c = it % c16;
-        const bf16_t* row = p.qkv + (size_t)(q0 + t) * row_w + (size_t)(p.nh + h) * HD;
-        const u32x4_t a = *reinterpret_cast<const u32x4_t*>(row + (p.perm ? c * 16 : c * 8));
-        const u32x4_t b2 = *reinterpret_cast<const u32x4_t*>(row + (p.perm ? c * 16 + 8 : half + c * 8));
-        float x1[8], x2[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          x1[2 * j] = bf2f(a[j] & 0xffffu); x1[2 * j + 1] = bf2f(a[j] >> 16);
-          x2[2 * j] = bf2f(b2[j] & 0xffffu); x2[2 * j + 1] = bf2f(b2[j] >> 16);
-        }
-        if (p.kn_w) {
-          float ss = 0.f;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { ss += x1[j] * x1[j]; ss += x2[j] * x2[j]; }
-          for (int o = 1; o < c16; o <<= 1) ss += __shfl_xor(ss, o, 64);
-          const float rs = 1.0f / sqrtf(ss / (float)HD + p.eps);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            x1[j] = round_bf((x1[j] * rs) * bf2f(p.kn_w[c * 8 + j]));
-            x2[j] = round_bf((x2[j] * rs) * bf2f(p.kn_w[half + c * 8 + j]));
-          }
-        }
-        const float* cs = p.cos_sin + (size_t)p.positions[q0 + t] * HD;
-        float y1[8], y2[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float co = cs[c * 8 + j], si = cs[half + c * 8 + j];
-          y1[j] = __fsub_rn(__fmul_rn(x1[j], co), __fmul_rn(x2[j], si));
-          y2[j] = __fadd_rn(__fmul_rn(x2[j], co), __fmul_rn(x1[j], si));
-        }
-        const int slot = p.slots[q0 + t];
-        if (slot >= 0) {
-          bf16_t* dst = p.kc_w + ((size_t)((slot / p.bs) * p.nkv + h) * p.bs + (slot % p.bs)) * HD;
-          *reinterpret_cast<u32x4_t*>(dst + c * 8) = u32x4_t{pack_bf2(y1[0], y1[1]), pack_bf2(y1[2], y1[3]), pack_bf2(y1[4], y1[5]), pack_bf2(y1[6], y1[7])};
-          *reinterpret_cast<u32x4_t*>(dst + half + c * 8) = u32x4_t{pack_bf2(y2[0], y2[1]), pack_bf2(y2[2], y2[3]), pack_bf2(y2[4], y2[5]), pack_bf2(y2[6], y2[7])};
-        }
-      } else {
-        const int vi = it - Tq * c16;
-        const int t = vi / c8, c = vi % c8;
-        const int slot = p.slots[q0 + t];
-        if (slot >= 0) {
-          const u32x4_t v = *reinterpret_cast<const u32x4_t*>(p.qkv + (size_t)(q0 + t) * row_w + (size_t)(p.nh + p.nkv + h) * HD + c * 8);
-          *reinterpret_cast<u32x4_t*>(p.vc_w + ((size_t)((slot / p.bs) * p.nkv + h) * p.bs + (slot % p.bs)) * HD + c * 8) = v;
-        }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
   // ---- per-lane query-row descriptors and Q fragments ----
   u32x4_t qf[RT][DS];
   int tl[RT], hq[RT];
@@ -164,69 +94,9 @@ __global__ void __launch_bounds__(512) attn_kernel(const AttnParams p) {
     const int rr = rvalid[rt] ? rho : 0;
     tl[rt] = rr / G;
     hq[rt] = h * G + (rr % G);
-    if constexpr (!QKV) {
-      const bf16_t* qp = p.q + ((size_t)(q0 + tl[rt]) * p.nh + hq[rt]) * HD + g4 * 8;
+    const bf16_t* qp = p.q + ((size_t)(q0 + tl[rt]) * p.nh + hq[rt]) * HD + g4 * 8;
 #pragma unroll
-      for (int ds = 0; ds < DS; ++ds) qf[rt][ds] = *reinterpret_cast<const u32x4_t*>(qp + ds * 32);
-    } else {
-      // Q from the raw projection row: per-head RMSNorm (optional) + neox RoPE, the arithmetic of rope_store_kernel (rope.hip) step
-      // for step -- same chunk sums, same xor tree over the head's 16-dim chunk pairs, same rounding points -- so the fragment is
-      // bit-identical to the one read back from ssd_rope_store_kv's q_out.  This lane's fragment dims [ds*32 + g4*8, +8) are
-      // chunk c = k*4 + g4 of the first half (ds = k) and of the second half (ds = DS/2 + k): it holds x1 AND x2 of DS/2 chunks,
-      // i.e. every rotation pair it needs; the other chunks of the head sit in the lanes g4 ^ 1, g4 ^ 2 of the same row.
-      constexpr int half = HD / 2, CPL = DS / 2;              // chunks per lane
-      const int row_w = (p.nh + 2 * p.nkv) * HD;
-      const bf16_t* qrow = p.qkv + (size_t)(q0 + tl[rt]) * row_w + (size_t)hq[rt] * HD;
-      const float* cs = p.cos_sin + (size_t)p.positions[q0 + tl[rt]] * HD;
-      float x1[CPL][8], x2[CPL][8], ssc[CPL];
-#pragma unroll
-      for (int k = 0; k < CPL; ++k) {
-        const int c = k * 4 + g4;
-        const u32x4_t a = *reinterpret_cast<const u32x4_t*>(qrow + (p.perm ? c * 16 : c * 8));
-        const u32x4_t b2 = *reinterpret_cast<const u32x4_t*>(qrow + (p.perm ? c * 16 + 8 : half + c * 8));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          x1[k][2 * j] = bf2f(a[j] & 0xffffu); x1[k][2 * j + 1] = bf2f(a[j] >> 16);
-          x2[k][2 * j] = bf2f(b2[j] & 0xffffu); x2[k][2 * j + 1] = bf2f(b2[j] >> 16);
-        }
-      }
-      if (p.qn_w) {
-#pragma unroll
-        for (int k = 0; k < CPL; ++k) {
-          float ss = 0.f;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { ss += x1[k][j] * x1[k][j]; ss += x2[k][j] * x2[k][j]; }
-          ss += __shfl_xor(ss, 16, 64);       // chunk c ^ 1
-          ss += __shfl_xor(ss, 32, 64);       // chunk c ^ 2
-          ssc[k] = ss;
-        }
-        float ss = ssc[0];
-        if constexpr (CPL == 2) ss = ssc[0] + ssc[1];         // chunk c ^ 4 (hd 128); fp addition commutes: the same value in both
-        const float rs = 1.0f / sqrtf(ss / (float)HD + p.eps);
-#pragma unroll
-        for (int k = 0; k < CPL; ++k) {
-          const int c = k * 4 + g4;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            x1[k][j] = round_bf((x1[k][j] * rs) * bf2f(p.qn_w[c * 8 + j]));
-            x2[k][j] = round_bf((x2[k][j] * rs) * bf2f(p.qn_w[half + c * 8 + j]));
-          }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < CPL; ++k) {
-        const int c = k * 4 + g4;
-        float y1[8], y2[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float co = cs[c * 8 + j], si = cs[half + c * 8 + j];
-          y1[j] = __fsub_rn(__fmul_rn(x1[k][j], co), __fmul_rn(x2[k][j], si));
-          y2[j] = __fadd_rn(__fmul_rn(x2[k][j], co), __fmul_rn(x1[k][j], si));
-        }
-        qf[rt][k] = u32x4_t{pack_bf2(y1[0], y1[1]), pack_bf2(y1[2], y1[3]), pack_bf2(y1[4], y1[5]), pack_bf2(y1[6], y1[7])};
-        qf[rt][CPL + k] = u32x4_t{pack_bf2(y2[0], y2[1]), pack_bf2(y2[2], y2[3]), pack_bf2(y2[4], y2[5]), pack_bf2(y2[6], y2[7])};
-      }
-    }
+    for (int ds = 0; ds < DS; ++ds) qf[rt][ds] = *reinterpret_cast<const u32x4_t*>(qp + ds * 32);
     if (p.mode == 0) {
       lim[rt] = ctx - (Tq - 1 - tl[rt]);
       tj[rt] = 0;
@@ -600,10 +470,10 @@ __global__ void attn_combine_kernel(const float* __restrict__ ws_o, const float*
   }
 }
 
-template <int HD, int RT, int KT, bool QKV = false>
+template <int HD, int RT, int KT>
 static int attn_launch_rt(const AttnParams& p, dim3 grid, int waves, hipStream_t st) {
   const int lds = waves * attn_region_bytes<HD, RT>();
-  auto kern = attn_kernel<HD, RT, KT, false, QKV>;
+  auto kern = attn_kernel<HD, RT, KT, false>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
     return SSD_ERR_LAUNCH;
@@ -623,9 +493,7 @@ static int attn_launch(const AttnParams& p, int B, int T, int max_q, int waves, 
   dim3 grid(B * p.nkv, (row_tiles + rt - 1) / rt, p.splits);
   // one key tile in flight per wave (KT = 1): measured on MI355X, KT = 2/4 buy nothing -- with 8 waves per workgroup
   // the scan is bound by the handful of CUs it occupies, not by a single wave's load latency
-  int rc;
-  if (p.qkv) rc = rt == 2 ? attn_launch_rt<HD, 2, 1, true>(p, grid, waves, st) : attn_launch_rt<HD, 1, 1, true>(p, grid, waves, st);
-  else rc = rt == 2 ? attn_launch_rt<HD, 2, 1>(p, grid, waves, st) : attn_launch_rt<HD, 1, 1>(p, grid, waves, st);
+  const int rc = rt == 2 ? attn_launch_rt<HD, 2, 1>(p, grid, waves, st) : attn_launch_rt<HD, 1, 1>(p, grid, waves, st);
   if (rc != SSD_OK) return rc;
   if (p.splits > 1) {
     hipLaunchKernelGGL((attn_combine_kernel<HD>), dim3(T * p.nh), dim3(HD / 4), 0, st, p.ws_o, p.ws_ml, p.splits, p.nh,
@@ -660,7 +528,6 @@ extern "C" int ssd_attn_oproj_parts(const void* q_rows, const void* k_cache, con
   p.splits = 1; p.use_tr = 1; p.p_split = 1;
   p.scale_log2e = scale * 1.4426950408889634f;
   p.ow = (const u32x4_t*)w_o_frag; p.oparts = (float*)parts; p.oN = N;
-  p.qkv = nullptr;
   const dim3 grid(nkv * (N / 128), 1, 1), block(512);
   hipStream_t st = (hipStream_t)stream;
   const int rt = rows > 16 ? 2 : 1;
@@ -702,7 +569,6 @@ extern "C" int ssd_attn_paged(const void* q_rows, const void* k_cache, const voi
   p.splits = splits; p.use_tr = (flags & 1) ? 0 : 1; p.p_split = (flags & 2) ? 0 : 1;
   p.scale_log2e = scale * 1.4426950408889634f;
   p.ow = nullptr; p.oparts = nullptr; p.oN = 0;
-  p.qkv = nullptr;
   hipStream_t st = (hipStream_t)stream;
   // flags bits 8..11: waves per workgroup that split the key range and merge in LDS (default 1; 1..8)
   int waves = (flags >> 8) & 0xf;
@@ -711,47 +577,6 @@ extern "C" int ssd_attn_paged(const void* q_rows, const void* k_cache, const voi
   // flags bit 2: one 16-row tile per workgroup even for wider query blocks (twice the workgroups for the 24-branch tree)
   const int rt1 = (flags >> 2) & 1;
   return hd == 128 ? attn_launch<128>(p, B, T, max_q, waves, rt1, st) : attn_launch<64>(p, B, T, max_q, waves, rt1, st);
-}
-
-// ssd_rope_store_kv + ssd_attn_paged in ONE launch for the decode-side shapes (round 4): q_per_seq <= 32 new tokens per sequence
-// (single-token decode, K+1-row verify / glue, the MQ_LEN-branch tree step), the context scanned inside one workgroup (no grid
-// key-splits: context buckets <= 1024).  qkv_rows = the QKV projection's output [T][(nh + 2 nkv) * hd] (q / k heads in the
-// rotation-paired column order when qkv_perm = 1); every workgroup first norms (q_norm_w / k_norm_w: Qwen3's per-head RMSNorm,
-// or null), rotates and stores the new K / V rows of its (sequence, kv head) exactly as rope_store_kernel does, then forms its Q
-// fragments from the raw rows with the same arithmetic -- results are bit-identical to the two launches.  Replaces
-// ssd/models/qwen3.py:96-104 (q_norm / k_norm) + ssd/layers/rotary_embedding.py:40-60 + ssd/layers/attention.py:10-41 (store) +
-// :105-131 (attention): one launch per layer less wherever RoPE cannot ride the QKV GEMM's epilogue.
-extern "C" int ssd_attn_paged_qkv(const void* qkv_rows, const int64_t* positions, const float* cos_sin, const int32_t* slot_mapping,
-                                  const void* q_norm_w, const void* k_norm_w, float eps, int qkv_perm, void* k_cache, void* v_cache,
-                                  const int32_t* block_tables, int max_blocks, const int32_t* context_lens, int q_per_seq, int B, int T,
-                                  int nh, int nkv, int hd, int block_size, float scale, int mode, int tree_K, int tree_mq,
-                                  int tree_step, int tree_F, const int32_t* tree_jidx, int flags, void* out_rows, void* out_frag,
-                                  void* stream) {
-  if (B <= 0 || T <= 0 || q_per_seq <= 0 || q_per_seq > 32 || T != B * q_per_seq || nh <= 0 || nkv <= 0 || nh % nkv) return SSD_ERR_SHAPE;
-  if (hd != 64 && hd != 128) return SSD_ERR_SHAPE;
-  if (block_size < 16 || (block_size & (block_size - 1)) != 0 || max_blocks <= 0) return SSD_ERR_SHAPE;
-  if (((nh * hd) & 31) != 0) return SSD_ERR_SHAPE;
-  if (!qkv_rows || !positions || !cos_sin || !slot_mapping || !k_cache || !v_cache) return SSD_ERR_ARG;
-  if (mode == 1 && (tree_mq <= 0 || tree_F <= 0)) return SSD_ERR_ARG;
-  AttnParams p;
-  p.q = nullptr; p.kc = (const bf16_t*)k_cache; p.vc = (const bf16_t*)v_cache;
-  p.block_tables = block_tables; p.context_lens = context_lens; p.cu_q = nullptr; p.tree_jidx = tree_jidx;
-  p.ws_o = nullptr; p.ws_ml = nullptr; p.out_rows = (bf16_t*)out_rows; p.out_frag = (u32x2_t*)out_frag;
-  p.max_blocks = max_blocks; p.q_per_seq = q_per_seq; p.nh = nh; p.nkv = nkv; p.bs = block_size;
-  p.bs_shift = __builtin_ctz(block_size);
-  p.mode = mode; p.tree_K = tree_K; p.tree_mq = tree_mq; p.tree_step = tree_step; p.tree_F = tree_F;
-  p.splits = 1; p.use_tr = (flags & 1) ? 0 : 1; p.p_split = (flags & 2) ? 0 : 1;
-  p.scale_log2e = scale * 1.4426950408889634f;
-  p.ow = nullptr; p.oparts = nullptr; p.oN = 0;
-  p.qkv = (const bf16_t*)qkv_rows; p.positions = positions; p.cos_sin = cos_sin; p.slots = slot_mapping;
-  p.qn_w = (const bf16_t*)q_norm_w; p.kn_w = (const bf16_t*)k_norm_w; p.kc_w = (bf16_t*)k_cache; p.vc_w = (bf16_t*)v_cache;
-  p.eps = eps; p.perm = qkv_perm;
-  int waves = (flags >> 8) & 0xf;
-  if (waves < 1) waves = 1;
-  if (waves > 8) waves = 8;
-  const int rt1 = (flags >> 2) & 1;
-  hipStream_t st = (hipStream_t)stream;
-  return hd == 128 ? attn_launch<128>(p, B, T, q_per_seq, waves, rt1, st) : attn_launch<64>(p, B, T, q_per_seq, waves, rt1, st);
 }
 
 // The reference's two other attention call sites under their own names (SURVEY section 8b's list): thin forms of ssd_attn_paged, which already

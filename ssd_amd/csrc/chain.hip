@@ -417,7 +417,7 @@ extern "C" int ssd_chain_segment(const void* a_frag, const void* res_in, void* r
   if (w_qkv_next ? (!ln_next || !positions || !cos_sin || !slots || !q_out || !k_cache || !v_cache || h_out) : !h_out) return SSD_ERR_ARG;
   if (layer < 0 || layer > 63) return SSD_ERR_ARG;
   if (res_out == res_in) return SSD_ERR_ARG;      // every workgroup reads the whole of res_in while chunk owners write res_out
-  static const long budget = [] { const char* e = getenv("SSD_CHAIN_SPIN_BUDGET"); return e ? atol(e) : 200000L; }();
+  constexpr long budget = 200000L;         // polls of >= 64 clocks + one memory round trip each: >= 0.2 s before a wait gives up
   SegParams p;
   p.a_frag = (const u32x4_t*)a_frag; p.res_in = (const bf16_t*)res_in; p.res_out = (bf16_t*)res_out; p.h_out = (bf16_t*)h_out;
   p.Wo = (const u32x4_t*)w_o; p.Wgu = (const u32x4_t*)w_gu; p.Wd = (const u32x4_t*)w_d; p.Wqkv = (const u32x4_t*)w_qkv_next;
@@ -434,15 +434,17 @@ extern "C" int ssd_chain_segment(const void* a_frag, const void* res_in, void* r
   // The 256 workgroups wait for each other: they must ALL be resident at once.  Asked of the runtime once (at the largest LDS image the
   // kernel can be given): occupancy x compute units >= the grid, else refuse -- a partitioned or smaller device would spin every
   // gather to its budget.
-  static int resident = -1;
-  if (resident < 0) {
-    int dev = 0, cus = 0, per_cu = 0;
-    resident = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_segment_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess &&
-               hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-               hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(chain_segment_kernel), SEG_THREADS, 96 * 1024) == hipSuccess &&
-               (long)per_cu * cus >= SEG_GRID;
+  static unsigned char resident[SSD_MAX_DEVICES];      // per device: 0 = not asked yet, 1 = resident, 2 = refused
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SSD_MAX_DEVICES) return SSD_ERR_LAUNCH;
+  if (resident[dev] == 0) {
+    int cus = 0, per_cu = 0;
+    resident[dev] = (hipFuncSetAttribute(reinterpret_cast<const void*>(chain_segment_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess &&
+                     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+                     hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(chain_segment_kernel), SEG_THREADS, 96 * 1024) == hipSuccess &&
+                     (long)per_cu * cus >= SEG_GRID) ? 1 : 2;
   }
-  if (!resident) return SSD_ERR_LAUNCH;
+  if (resident[dev] != 1) return SSD_ERR_LAUNCH;
   hipLaunchKernelGGL(chain_segment_kernel, dim3(SEG_GRID), dim3(SEG_THREADS), lds, (hipStream_t)stream, p);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }

@@ -49,16 +49,11 @@ __device__ __forceinline__ unsigned long long ld_sys64(const unsigned long long*
 // No release fence (an L2 write-back of everything the preceding GEMM left dirty) and no acquire fence (an L2 invalidate
 // that the NEXT GEMM would pay for): measured on MI355X with the TP = 4 shard shapes, the fused all-reduce + norm launch
 // went from 7.6 us to the figure in profiles/r03_tp_shard_per_kind.txt.
-__device__ __forceinline__ void ar_publish_barrier(int fences) {
+// (Rounds 3-5 kept a fenced form behind SSD_AR_FENCES=1 -- a system-scope release before the flag stores and an acquire after the
+// poll; it validated identically in every two-process run and was never needed: deleted in round 6 with its switch.)
+__device__ __forceinline__ void ar_publish_barrier() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  // SSD_AR_FENCES=1: the belt-and-braces form -- a system-scope release before the flag stores and an acquire after
-  // the poll, as until round 2 -- for a platform where the drained write-through stores above should prove insufficient
-  if (fences) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   __syncthreads();
-}
-static int ar_fences() {
-  static const int v = [] { const char* e = getenv("SSD_AR_FENCES"); return (e && e[0] == '1') ? 1 : 0; }();
-  return v;
 }
 
 // W: ranks the peer loops are unrolled over (1 / 2 / 4 / 8, the smallest >= world): every rank's word is requested before the
@@ -68,7 +63,7 @@ template <int W>
 __global__ void __launch_bounds__(AR_THREADS)
 allreduce_bf16_kernel(const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out, long n8,
                       long slot_words, ArPeers peers, int rank, int world, unsigned int* __restrict__ counters,
-                      unsigned int* __restrict__ err, long spin_budget, int gather, int fences) {
+                      unsigned int* __restrict__ err, long spin_budget, int gather) {
   __shared__ unsigned int s_epoch;
   __shared__ int s_fail;
   const int blk = blockIdx.x;
@@ -79,7 +74,7 @@ allreduce_bf16_kernel(const unsigned long long* __restrict__ in, unsigned long l
   const long i0 = blk * per, i1 = min(n8, i0 + per);
   unsigned long long* my = peers.slot[rank] + (long)(epoch & 1u) * slot_words;
   for (long i = i0 + threadIdx.x; i < i1; i += AR_THREADS) st_sys64(my + i, in[i]);
-  ar_publish_barrier(fences);
+  ar_publish_barrier();
   if (threadIdx.x < world) {
     const int peer = threadIdx.x;
     __hip_atomic_store(peers.flags[peer] + blk * AR_MAX_RANKS + rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -93,7 +88,6 @@ allreduce_bf16_kernel(const unsigned long long* __restrict__ in, unsigned long l
       if (++spins > spin_budget) { s_fail = 1; break; }
     }
   }
-  if (fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   __syncthreads();
   if (threadIdx.x == 0) {
     counters[blk] = epoch;           // (default: no acquire fence -- every staged word is read with a system-scope load, see ar_publish_barrier)
@@ -136,7 +130,7 @@ allreduce_add_rmsnorm_kernel(const unsigned long long* __restrict__ in, const u3
                              u32x4_t* __restrict__ res_out, const u32x4_t* __restrict__ w, float eps,
                              u32x4_t* __restrict__ out_rows, u32x4_t* __restrict__ out_frag, int T, int H,
                              long slot_words, ArPeers peers, int rank, int world, unsigned int* __restrict__ counters,
-                             unsigned int* __restrict__ err, long spin_budget, int fences) {
+                             unsigned int* __restrict__ err, long spin_budget) {
   __shared__ unsigned int s_epoch;
   __shared__ int s_fail;
   __shared__ float red[ARN_THREADS / 64];
@@ -150,7 +144,7 @@ allreduce_add_rmsnorm_kernel(const unsigned long long* __restrict__ in, const u3
   const long hw = H >> 2;                       // 8-byte words per row
   unsigned long long* my = peers.slot[rank] + (long)(epoch & 1u) * slot_words;
   for (long i = (long)r0 * hw + threadIdx.x; i < (long)r1 * hw; i += ARN_THREADS) st_sys64(my + i, in[i]);
-  ar_publish_barrier(fences);
+  ar_publish_barrier();
   if (threadIdx.x < world) {
     const int peer = threadIdx.x;
     __hip_atomic_store(peers.flags[peer] + blk * AR_MAX_RANKS + rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -161,7 +155,6 @@ allreduce_add_rmsnorm_kernel(const unsigned long long* __restrict__ in, const u3
       if (++spins > spin_budget) { s_fail = 1; break; }
     }
   }
-  if (fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   __syncthreads();
   if (threadIdx.x == 0) {
     counters[blk] = epoch;
@@ -511,7 +504,7 @@ extern "C" int ssd_allreduce_bf16(const void* in, void* out, long n, int rank, i
 #define AR_GO(WV)                                                                                                        \
   hipLaunchKernelGGL(allreduce_bf16_kernel<WV>, dim3(AR_BLOCKS), dim3(AR_THREADS), 0, (hipStream_t)stream,              \
                      (const unsigned long long*)in, (unsigned long long*)out, n8, slot_elems / 4, peers, rank, world,   \
-                     (unsigned int*)counters, (unsigned int*)err, spin_budget, 0, ar_fences())
+                     (unsigned int*)counters, (unsigned int*)err, spin_budget, 0)
   if (world == 1) AR_GO(1); else if (world == 2) AR_GO(2); else if (world <= 4) AR_GO(4); else AR_GO(8);
 #undef AR_GO
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
@@ -531,7 +524,7 @@ extern "C" int ssd_allgather_u64(const void* in, void* out, long n8, int rank, i
 #define AR_GO(WV)                                                                                                        \
   hipLaunchKernelGGL(allreduce_bf16_kernel<WV>, dim3(AR_BLOCKS), dim3(AR_THREADS), 0, (hipStream_t)stream,              \
                      (const unsigned long long*)in, (unsigned long long*)out, n8, slot_elems / 4, peers, rank, world,   \
-                     (unsigned int*)counters, (unsigned int*)err, spin_budget, 1, ar_fences())
+                     (unsigned int*)counters, (unsigned int*)err, spin_budget, 1)
   if (world == 1) AR_GO(1); else if (world == 2) AR_GO(2); else if (world <= 4) AR_GO(4); else AR_GO(8);
 #undef AR_GO
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
@@ -558,7 +551,7 @@ extern "C" int ssd_allreduce_add_rmsnorm_bf16(const void* in, const void* res_in
   hipLaunchKernelGGL((allreduce_add_rmsnorm_kernel<TH, WV>), dim3(AR_BLOCKS), dim3(TH), 0, (hipStream_t)stream,           \
                      (const unsigned long long*)in, (const u32x4_t*)res_in, (u32x4_t*)res_out, (const u32x4_t*)weight, eps, \
                      (u32x4_t*)out_rows, (u32x4_t*)out_frag, T, H, slot_elems / 4, peers, rank, world,                    \
-                     (unsigned int*)counters, (unsigned int*)err, spin_budget, ar_fences())
+                     (unsigned int*)counters, (unsigned int*)err, spin_budget)
 #define ARN_W(TH) do { if (world == 1) ARN_GO(TH, 1); else if (world == 2) ARN_GO(TH, 2); else if (world <= 4) ARN_GO(TH, 4); else ARN_GO(TH, 8); } while (0)
   if (ssd_norm_threads(H) == 1024) ARN_W(1024); else ARN_W(256);
 #undef ARN_W

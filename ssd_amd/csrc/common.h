@@ -11,6 +11,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+constexpr int SSD_MAX_DEVICES = 16;  // per-device host-side caches (function attributes, residency checks): indexed by the HIP device ordinal
 
 // The public C ABI: every translation unit sees the declarations its extern "C" definitions must match (a mismatch is a compile
 // error: conflicting types), and the error codes / ABI version exist in ONE place.

@@ -398,10 +398,9 @@ extern "C" int ssd_gemm_pf(const void* x_frag, const void* w_frag, const void* b
   if (splits > 0) { s = splits; waves = 4; }
   if (s > 16 || (K >> 5) % s != 0) return SSD_ERR_ARG;
   pf_refine(M, N, K, s, &waves, &bps);
-  // B operands of a two-k-step phase read from LDS up front (BPRE = 2) wherever that form exists; SSD_PF_BPRE=0 selects the plain
-  // loop (A/B measurements: profiles/r04_pf_probe_bpre.txt, every output bit-identical)
-  static const int want_bpre = [] { const char* e = getenv("SSD_PF_BPRE"); return e ? atoi(e) : 2; }();
-  const int bpre = (want_bpre == 2 && bps == 2 && nt == 2 && M > 64 && (waves == 4 || waves == 5 || waves == 8) && ((K >> 5) / s) % 8 == 0) ? 2 : 0;
+  // B operands of a two-k-step phase read from LDS up front (BPRE = 2) wherever that form exists (measured 1-6 % faster, bit-identical:
+  // profiles/r04_pf_probe_bpre.txt; the A/B switch SSD_PF_BPRE is gone since round 6, ssd_gemm_pf_cfg's nt bits 28-29 still select)
+  const int bpre = (bps == 2 && nt == 2 && M > 64 && (waves == 4 || waves == 5 || waves == 8) && ((K >> 5) / s) % 8 == 0) ? 2 : 0;
   return ssd_gemm_pf_cfg(x_frag, w_frag, bias, y, M, N, K, ldy, epilogue, workspace, workspace_bytes,
                          nt | (waves << 8) | (bps << 24) | (bpre << 28), s, stream);
 }

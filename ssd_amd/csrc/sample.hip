@@ -270,9 +270,12 @@ fork_merge_kernel(const float* __restrict__ cand_val, const int* __restrict__ ca
   }
 }
 
+// Also the library's predicate for "ssd_fork_topf_split takes this vocabulary" (ADVICE r5): SSD_ERR_SHAPE where the split form would
+// refuse (V not a multiple of 8, or more than 48 slices = V > 196608) -- the caller then stays on ssd_fork_topf.
 extern "C" int ssd_fork_topf_workspace_bytes(int V, int B, int K) {
-  if (V <= 0 || B <= 0 || K < 0) return SSD_ERR_SHAPE;
+  if (V <= 0 || B <= 0 || K < 0 || (V & 7)) return SSD_ERR_SHAPE;
   const int S = (V + FS_SLICE - 1) / FS_SLICE;
+  if (S > 48) return SSD_ERR_SHAPE;
   return B * (K + 1) * S * FORK_MAXF * 8;
 }
 

@@ -15,7 +15,7 @@
 //     LDS-only barrier with the NEXT phase's first weight tiles already in flight, then every wave reads the payload with `sc1`
 //     loads (L2-served, never from this CU's L1: no acquire fence, no cache invalidate anywhere);
 //   * every workgroup repeats the residual add + RMSNorm of all M rows itself (a wave owns whole rows: the row's sum of squares
-//     is a wave reduction, same order as ssd_rmsnorm) and keeps x^ -- the B operand of gate_up / QKV -- in LDS (96 KB at M = 24);
+//     is a wave reduction -- NOT ssd_rmsnorm's order, see ts_add_norm: tolerance-equal to the separate launches) and keeps x^ -- the B operand of gate_up / QKV -- in LDS (96 KB at M = 24);
 //     the activation, too big for LDS, is read per k-tile from L2 in the fragment-major layout it was published in;
 //   * o_proj / down_proj: row HALVES of a 16-row group per workgroup over the full K (256 units for the 1B: no split-K slabs);
 //   * every global access is `buffer_load / buffer_store` with a scalar base, a scalar tile offset and a 32-bit lane offset: no
@@ -216,7 +216,10 @@ __device__ __forceinline__ void ts_store_rows(const f32x4_t* cred, int mt, ts_rs
 }
 
 // (projection output + residual) of all M rows -> the new bf16 residual (chunk c of every row by workgroup c), the row's sum of
-// squares (chunk sums, lane-strided partials, xor tree: ssd_rmsnorm's order) and x^ = bf16((x * rs) * w) into the LDS image.  Wave w
+// squares and x^ = bf16((x * rs) * w) into the LDS image.  Summation order: each lane first adds the chunk sums of its
+// CPL lane-strided chunks, then one xor tree over the wave -- ssd_rmsnorm<256> at h = 2048 runs the xor tree per 64-chunk block and
+// adds the 4 block totals in order, so rs can differ from the separate launches' in the last ulp: like the projections' fp32 sums,
+// the segment's norm is tolerance-equal to them, not bit-identical (tests/test_hip_tree_segment.py holds it to the oracle).  Wave w
 // owns rows w, w + 8, ...; two rows' loads are in flight at a time.  FIRST: a = o_proj rows (published), b = the layer's input
 // residual (an earlier launch's), the result is published write-through (phase 4 of every workgroup re-reads it); else
 // a = down_proj rows, b = that residual (both published), the result is the next launch's.
@@ -421,7 +424,7 @@ __global__ void __launch_bounds__(TS_THREADS) tree_segment_kernel(const TsParams
         for (int r = 0; r < 4; ++r) x[r] = round_bf_hw(s[r]);   // the reference stores qkv as bf16 before RoPE
         if (p.qkv_rows) {
           // Qwen3: RMSHeadNorm sits between the projection and the rotation and needs a whole head (8 row groups = 8 workgroups here):
-          // the rows leave as the projection wrote them (rotation-paired order) and ssd_rope_store_kv / ssd_attn_paged_qkv go on
+          // the rows leave as the projection wrote them (rotation-paired order) and ssd_rope_store_kv goes on
           if (m < M)
             *reinterpret_cast<u32x2_t*>(p.qkv_rows + (size_t)m * p.qkv_n + grp * 16 + nrow) = u32x2_t{pack_bf2_hw(x[0], x[1]), pack_bf2_hw(x[2], x[3])};
         } else if (grp < qk_groups) {
@@ -515,18 +518,23 @@ extern "C" int ssd_tree_segment(const void* a_frag, const void* res_in, void* re
     return SSD_ERR_ARG;
   if (res_out == res_in) return SSD_ERR_ARG;               // every workgroup re-reads res_in while chunk owners write res_out
   if (layer < 0 || layer > 63) return SSD_ERR_ARG;
-  static const long budget = [] { const char* e = getenv("SSD_CHAIN_SPIN_BUDGET"); return e ? atol(e) : 200000L; }();
+  constexpr long budget = 200000L;         // polls of >= 64 clocks + one memory round trip each: >= 0.2 s before a wait gives up
   const ts_kernel_t kern = ts_pick(M, h);
   if (!kern) return SSD_ERR_SHAPE;
   const size_t lds = ts_lds_bytes(M, h);
-  static int resident[4] = {-1, -1, -1, -1};     // per kernel variant, asked once (at the largest image the variant can be given)
+  // per (device, kernel variant), asked once per device (at the largest image the variant can be given): the function attribute
+  // and the occupancy answer belong to the device that is current at the call (a process-wide flag would skip both
+  // on a second device).  0 = not asked yet, 1 = resident, 2 = refused.
+  static unsigned char resident[SSD_MAX_DEVICES][4];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SSD_MAX_DEVICES) return SSD_ERR_LAUNCH;
   const int vi = (M > 16 ? 1 : 0) + (h == 1024 ? 2 : 0);
-  if (resident[vi] < 0) {
+  if (resident[dev][vi] == 0) {
     int mmax = M > 16 ? 32 : 16;
     while (ts_lds_bytes(mmax, h) > 160 * 1024) --mmax;
-    resident[vi] = ts_resident(kern, ts_lds_bytes(mmax, h)) ? 1 : 0;
+    resident[dev][vi] = ts_resident(kern, ts_lds_bytes(mmax, h)) ? 1 : 2;
   }
-  if (!resident[vi]) return SSD_ERR_LAUNCH;
+  if (resident[dev][vi] != 1) return SSD_ERR_LAUNCH;
   TsParams p;
   char* ws = (char*)workspace;
   p.flags = (unsigned*)ws; ws += 3 * TS_GRID * 4;

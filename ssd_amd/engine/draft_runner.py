@@ -164,6 +164,11 @@ class DraftServer:
             pass
 
     # ---- speculation round ----
+    def _check_segments(self, sync: bool) -> None:
+        check = getattr(self.runner, "check_segments", None)      # (oracle / EAGLE runners have no resident segments)
+        if check is not None:
+            check(sync)
+
     def _lookup(self, keys) -> tuple[list[int], torch.Tensor | None]:
         """Request keys against the cache of the finished round, ON THE DRAFT DEVICE (reference draft_runner.py:215-252): the
         fork tokens never leave it; what comes back is one int32 per request -- the entry index or -1 -- which the host needs
@@ -197,6 +202,9 @@ class DraftServer:
         want_logits = bool(flags & P.FLAG_WANT_LOGITS)
         sample = any(t > 0 for t in temps)
         idx, idx_dev = self._lookup(keys)                                # rows of MY cache shard (-1: miss)
+        # (the lookup's read-back synchronised the draft's stream: the glue + tree round whose cache is about to be served has
+        #  finished -- a resident segment that gave up a wait while building it is reported before any of its tokens is used)
+        self._check_segments(False)
         hits = [1 if i >= 0 else 0 for i in idx]
         owner = [0 if h else -1 for h in hits]                           # group member that holds each row's branch
         if dp is not None:
@@ -247,6 +255,7 @@ class DraftServer:
                 eagle["prev_acts"] = self.runner.jit_acts(B)
             elif lead:
                 tokens = self.runner.draft_jit(rec, num_tokens, tables, temps)  # [B, K] on the draft device
+                self._check_segments(True)      # the chain segment: its tokens leave with the reply below (misses only: one word read back)
                 if want_logits and sample:
                     logits_q = self.runner.logits_q(B)
             else:

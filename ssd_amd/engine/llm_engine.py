@@ -139,7 +139,7 @@ class LLMEngine:
                 # (retired in round 5, both measured on MI355X and not worth a switch: a high-priority draft stream -- 29.0 vs 28.4 ms per
                 # step, profiles/r02_colocated_overlap.txt -- and a CU-mask partition of the chip between draft and target -- 36-38 vs
                 # 30.5 ms: the target's launches are sized for 256 CUs, profiles/r02_cu_partition.txt)
-                side = torch.cuda.Stream(self.topo.device) if on_gpu and os.environ.get("SSD_COLOCATED_OVERLAP", "1") != "0" else None
+                side = torch.cuda.Stream(self.topo.device) if on_gpu else None
                 # the M-row resident segment (csrc/tree_segment.hip) keeps 256 workgroups waiting for each other: beside a verify that owns
                 # the CUs they come up one by one and spin -- measured on c4 (profiles/r05_c4_kernel_stats_with_glue_segment.txt): 85.6 us
                 # per glue launch against 27 us alone, and the CUs they hold are taken from the target.  "auto" keeps it for draft

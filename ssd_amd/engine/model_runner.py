@@ -198,8 +198,11 @@ class ModelRunner:
     # The resident layer segments (csrc/chain.hip, csrc/tree_segment.hip) report a given-up bounded wait in a device word.  The
     # draft-side paths never read tokens on the host themselves (speculate_chain / draft_jit / draft_glue_fork / draft_tree /
     # deposit_pending return device tensors), so each of them mirrors the word into pinned host memory behind its launches
-    # (_post_chain_err: one 4-byte async copy) and looks at the mirror of the PREVIOUS call on entry (_check_chain_host: no sync; a
-    # host sync always lies between two rounds -- the verify read-back, or the draft server's cache-lookup read-back).
+    # (_post_chain_err: one 4-byte async copy), and the word is looked at IN THE ROUND IT BELONGS TO (round 6; until round 5: on
+    # entry of the next call, one round late) -- by `check_segments` at the first host synchronisation that follows the launches and
+    # precedes any use of their tokens: after the verify's read-back (synchronous speculation, step.py), after the speculation-cache
+    # lookup's read-back (the tree round whose cache is about to be served, draft_runner.py), and with a read of the device word
+    # itself before a JIT chain's reply leaves the draft (the one path without a host sync of its own; misses only).
     def _has_chain_err(self) -> bool:
         return getattr(self.model, "chain_seg", False) or getattr(self.model, "tree_seg", False)
 
@@ -213,6 +216,14 @@ class ModelRunner:
 
     def _check_chain_host(self) -> None:
         if self._has_chain_err() and int(self._chain_err_host[0]):
+            self._raise_chain_err()
+
+    def check_segments(self, sync: bool = False) -> None:
+        """Raise if a resident segment launched by this runner gave up a wait.  sync=False: the caller has synchronised the stream
+        since the launches (the pinned mirror is current); sync=True: read the device word (a stream sync)."""
+        if not self._has_chain_err():
+            return
+        if int(self._chain_err_host[0]) or (sync and int(self.model.chain_err.item())):
             self._raise_chain_err()
 
     # ---------------------------------------------------------------------------------------------
@@ -724,7 +735,7 @@ class ModelRunner:
         K, T = self.K, B * (self.K + 1)
         self.model.forward(self.d_ids, self.d_pos, T, self._meta("verify", B))
         self.model.compute_logits(T)
-        if self.model.V % 8 == 0:       # per-slice candidates + one merge launch (csrc/sample.hip): bit-equal, 84.7 -> ~8 us per round
+        if self.fork_split:             # per-slice candidates + one merge launch (csrc/sample.hip): bit-equal, 84.7 -> ~8 us per round
             H.fork_topf_split(self.model.logits, self.model.V, self.model.V, self.d_ids, self.d_fan, self.d_fan_off, B, K, self.mq,
                               self.d_fork_ws, self.d_forks)
         else:
@@ -740,7 +751,9 @@ class ModelRunner:
         self.d_fan = torch.zeros(B, K + 1, dtype=torch.int32, **dev)
         self.d_fan_off = torch.zeros(B, K + 1, dtype=torch.int32, **dev)
         self.d_forks = torch.zeros(B, self.mq, dtype=torch.int64, **dev)
-        self.d_fork_ws = torch.zeros(max(8, H.fork_topf_workspace_bytes(self.model.V, B, K)) // 8, dtype=torch.int64, **dev)
+        ws = H.fork_topf_workspace_bytes(self.model.V, B, K)       # 0: the split fork refuses this vocabulary (V % 8, V > 196608)
+        self.fork_split = ws > 0
+        self.d_fork_ws = torch.zeros(max(8, ws) // 8, dtype=torch.int64, **dev)
         self.d_jidx = torch.zeros(B, self.mq, dtype=torch.int32, **dev)
         self.d_jidx_flat = self.d_jidx.view(-1)      # packed [B][tree width] (the width may be a slice of MQ_LEN)
         self.d_tree_pos = torch.zeros(K, T, dtype=torch.int64, **dev)

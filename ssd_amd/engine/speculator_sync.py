@@ -51,3 +51,10 @@ class SpeculatorSync(SpeculatorBase):
             seq.num_draft_cached_tokens += K + 1
         # logits_q is only read on the temperature > 0 ratio path (ssd/utils/verify.py:50-64)
         return SpeculateResult(speculations, self.draft_model_runner.logits_q(len(seqs)) if sampled else None)
+
+    def check_round(self) -> None:
+        """Called by the step after the verify's host synchronisation: the draft chain of THIS round ran on the same stream, so the
+        mirror of its segments' error word is current (model_runner.check_segments)."""
+        check = getattr(self.draft_model_runner, "check_segments", None)
+        if check is not None:
+            check(False)

@@ -64,6 +64,11 @@ class SpecDecodeStep(InferenceStep):
         spec = self.speculator.speculate(seqs, VerifyResult([], [], True if self.eagle else None))
         t1 = prof.sync_now() if trace else 0.0
         out = self.verifier.verify(seqs, spec, eagle=self.eagle)
+        # (the verify's read-back synchronised the stream the draft chain ran on: a resident segment that gave up a wait while
+        #  producing THIS round's speculations is reported now, before the accepted tokens are committed)
+        check = getattr(self.speculator, "check_round", None)
+        if check is not None:
+            check()
         t2 = prof.sync_now() if trace else 0.0
         for seq, snap in zip(seqs, saved):      # undo the lookahead applied by speculate + verify
             seq.restore(snap)

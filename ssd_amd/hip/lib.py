@@ -50,9 +50,6 @@ SIGNATURES = {
     "ssd_attn_paged": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                        c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int,
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
-    "ssd_attn_paged_qkv": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int,
-                           c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p,
-                           c_int, c_void_p, c_void_p, c_void_p],
     "ssd_attn_prefill_varlen": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                 c_int, c_float, c_void_p, c_void_p, c_void_p],
     "ssd_attn_tree": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int,

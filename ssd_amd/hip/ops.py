@@ -165,17 +165,6 @@ def attn_paged(q_rows, k_cache, v_cache, block_tables, max_blocks, context_lens,
                                          _p(ws_o), _p(ws_ml), _p(out_rows), _p(out_frag), _stream()), "ssd_attn_paged")
 
 
-def attn_paged_qkv(qkv_rows, positions, cos_sin, slot_mapping, k_cache, v_cache, block_tables, max_blocks, context_lens, B, T, q_per_seq,
-                   nh, nkv, hd, block_size, scale, q_norm_w=None, k_norm_w=None, eps: float = 0.0, qkv_perm: int = 0, mode=MODE_CAUSAL,
-                   tree_K=0, tree_mq=0, tree_step=0, tree_F=1, tree_jidx=None, flags=0, out_rows=None, out_frag=None, waves=1):
-    """rope_store_kv + attn_paged in one launch (csrc/attention.hip QKV variant): decode-side shapes, q_per_seq <= 32, no key splits."""
-    flags = (flags & 0xff) | ((waves & 0xf) << 8)
-    _check(load_library().ssd_attn_paged_qkv(_p(qkv_rows), _p(positions), _p(cos_sin), _p(slot_mapping), _p(q_norm_w), _p(k_norm_w), eps,
-                                             qkv_perm, _p(k_cache), _p(v_cache), _p(block_tables), max_blocks, _p(context_lens), q_per_seq,
-                                             B, T, nh, nkv, hd, block_size, scale, mode, tree_K, tree_mq, tree_step, tree_F,
-                                             _p(tree_jidx), flags, _p(out_rows), _p(out_frag), _stream()), "ssd_attn_paged_qkv")
-
-
 def attn_oproj_parts(q_rows, k_cache, v_cache, block_tables, max_blocks: int, context_lens, T: int, nh: int, nkv: int, hd: int,
                      block_size: int, scale: float, w_o_frag, N: int, parts):
     """One sequence's decode / glue attention fused with o_proj: fp32 slabs [nkv][T][N] (csrc/attention.hip OPROJ variant)."""
@@ -254,6 +243,8 @@ class CGraph:
         if et is None:
             _check(rc, "ssd_graph_end")
             self.exec = out.value
+        elif rc == 0 and out.value:          # the body raised: the capture still ended in an executable graph nobody will launch
+            load_library().ssd_graph_destroy(out.value)
         return False
 
     def launch(self):
@@ -332,10 +323,9 @@ def fork_topf(logits, ld: int, V: int, returned, counts, offsets, B: int, K: int
 
 
 def fork_topf_workspace_bytes(V: int, B: int, K: int) -> int:
+    """Workspace of ssd_fork_topf_split; 0 when the split form does not take this vocabulary (the caller uses fork_topf)."""
     n = load_library().ssd_fork_topf_workspace_bytes(V, B, K)
-    if n < 0:
-        raise SsdHipError(f"ssd_fork_topf_workspace_bytes failed with code {n}")
-    return n
+    return max(n, 0)
 
 
 def fork_topf_split(logits, ld: int, V: int, returned, counts, offsets, B: int, K: int, mq: int, workspace, out):

@@ -64,7 +64,7 @@ class HipDecoder:
         # collective + hipGraph-capture path that the multi-GPU runs depend on)
         self.use_coll = tp_size > 1 or (force_collectives and tp_group is not None)
         self.custom_ar = None      # OneShotAllReduce (ssd_amd/utils/custom_ar.py) once the runner has validated it
-        self.fuse_ar_norm = os.environ.get("SSD_FUSE_AR_NORM", "1") != "0"
+        self.fuse_ar_norm = True            # (all-reduce + add + RMSNorm in one launch; a probe may clear the attribute for an A/B run)
         assert cfg.num_heads % tp_size == 0 and cfg.num_kv_heads % tp_size == 0
         assert cfg.intermediate_size % (tp_size * 32) == 0 and cfg.vocab_size % (tp_size * 16) == 0
         self.nh, self.nkv = cfg.num_heads // tp_size, cfg.num_kv_heads // tp_size
@@ -101,7 +101,7 @@ class HipDecoder:
         # Qwen3-32B o_proj 20.6 -> 15.6 us, down_proj 58.1 -> 48.1 us at 16 splits, profiles/r02_parts_probe.txt; at exactly
         # 256 or >= 512 groups the rows kernels are as fast or faster)
         g_ = self.h // 16
-        self.use_parts = os.environ.get("SSD_PARTS", "1") != "0" and (g_ < 256 or 256 < g_ < 512)
+        self.use_parts = g_ < 256 or 256 < g_ < 512
         # ssd_gemm_parts keeps a wave's whole K share in registers: <= 8 k-tiles per wave.  A shape whose (splits, waves) plan
         # cannot meet that (e.g. h = 3072 with I = 14336 under the two-slab fused consumer) runs the rows kernels instead
         def fits(N, K, fused):
@@ -110,15 +110,8 @@ class HipDecoder:
         fused_possible = (not cfg.qk_norm) and self.h // 8 <= 1024          # fusion_plan(): the norm prologue exists at T = 1 only
         if self.use_parts and not all(fits(self.h, k, f) for k in (self.qn, self.I) for f in ((False, True) if fused_possible else (False,))):
             self.use_parts = False
-        self.fuse_attn_o = os.environ.get("SSD_FUSE_ATTN_O", "1") != "0"
-        # models whose RoPE cannot ride the QKV GEMM's epilogue (Qwen3: a per-head q / k RMSNorm sits in between): the norm, the
-        # rotation and the KV store can happen inside the attention launch instead of a launch of their own (csrc/attention.hip
-        # QKV; bit-identical, tests/test_hip_attn_qkv.py).  Measured on MI355X (profiles/r04_bench_c5t_qkvattn_ab.txt, Qwen3-32B +
-        # 0.6B async): 20.54 ms / step fused vs 19.92 separate -- the new K / V rows make a store -> vmcnt(0) -> barrier -> load
-        # round trip through memory in front of the key scan, which costs each of the few attention workgroups more than the
-        # launch it saves.  OFF by default; the way to make it pay (new keys kept in LDS for the tail tile) is noted in DESIGN 8c.
-        self.fuse_qkv_attn = os.environ.get("SSD_FUSE_QKV_ATTN", "0") == "1"
-        self.pf_parts = os.environ.get("SSD_PF_PARTS", "1") != "0"
+        self.fuse_attn_o = True
+        self.pf_parts = True
         # the single-token chain (one sequence, T = 1) with everything between two attention launches in ONE resident launch
         # (csrc/chain.hip): 1 + 2 per layer launches instead of 4 per layer
         # Default ("auto"): on at the geometry it was validated and measured at on the MI355X -- Llama-3.2-1B's, the draft of every
@@ -176,7 +169,7 @@ class HipDecoder:
         self.ws_ml = z(st * self.nh * self.max_splits * 2, dtype=torch.float32)
         # LM-head argmax candidates (csrc/gemm.hip EPI_ROWS_ARGMAX): one (value, index) per token row and workgroup, finished
         # by ssd_argmax_parts* -- on the greedy path for up to 32 logit rows (decode / verify / tree step)
-        self.argmax_fused = os.environ.get("SSD_ARGMAX_FUSED", "1") != "0"
+        self.argmax_fused = True
         self.ap_rows = min(self.max_logit_rows, 32)
         self.ap_stride = max(H.gemm_argmax_nparts(m, self.V, self.h) for m in ({1, self.ap_rows} if self.ap_rows > 16 else {1}))
         self.ap_val = z(self.ap_rows, self.ap_stride, dtype=torch.float32)
@@ -469,19 +462,9 @@ class HipDecoder:
                            cfg.rms_norm_eps, T, self.h, self.qn, self.I, self.qkv_n, self.nh, self.nkv, self.hd, self.block_size, li,
                            self.tree_ws, self.chain_gen, self.chain_err, h_out=self.buf_h if last else None, **nxt)
 
-    def qkv_attn_plan(self, T: int, meta: AttnMeta, splits: int) -> bool:
-        """RoPE (+ Qwen3's q / k norm) + KV store inside the attention launch: decode-side shapes (<= 32 new tokens per sequence,
-        fixed rows per sequence), the context scanned inside one workgroup, and only where launch_qkv would otherwise end in a
-        separate ssd_rope_store_kv launch."""
-        small, _ = self.fusion_plan(T)
-        rope_in_gemm = small or (16 < T <= 32 and not self.cfg.qk_norm)
-        return (self.fuse_qkv_attn and not rope_in_gemm and meta.cu_q is None and 0 < meta.q_per_seq <= 32
-                and T == meta.B * meta.q_per_seq and splits == 1)
-
     def launch_qkv(self, li: int, T: int, positions, slot_mapping, gemm_only: bool = False, pre_normed: bool = False,
-                   parts: bool | None = None, pf_src: int = 0, defer_rope: bool = False) -> None:
+                   parts: bool | None = None, pf_src: int = 0) -> None:
         """gemm_only: skip the separate add+RMSNorm / RoPE launches of the unfused variants (kernel timing).
-        defer_rope: the attention launch that follows does the norm + RoPE + KV store itself (qkv_attn_plan): stop at buf_qkv.
         pre_normed: buf_xf / buf_res already hold this layer's normalised input and residual (written by the fused
         all-reduce + add + RMSNorm that closed the previous layer)."""
         cfg, w = self.cfg, self.w
@@ -512,7 +495,7 @@ class HipDecoder:
         if small or (16 < T <= 32 and not cfg.qk_norm):      # T in 17..32 (tree-decode step): the two-token-tile variant
             H.gemm_fused(w[p + "self_attn.qkv_proj.weight"], T, self.qkv_n, self.h, H.FEPI_QKV_ROPE, x_frag=xf,
                          bias=w.get(p + "self_attn.qkv_proj.bias"), **rope)
-        elif (not gemm_only and not defer_rope and w.get(p + "self_attn.qkv_proj.bias") is None and self._pf_partials_ok(T, self.qkv_n, self.h)
+        elif (not gemm_only and w.get(p + "self_attn.qkv_proj.bias") is None and self._pf_partials_ok(T, self.qkv_n, self.h)
               and self._pf_splits(T, self.qkv_n, self.h) > 1):
             # single-chunk prefill of a big QKV matrix: its split-K slabs stay in the workspace and the RoPE / KV-store kernel
             # sums them (bit-identical to the GEMM's epilogue launch + rope_store_kv; one launch less per layer)
@@ -523,7 +506,7 @@ class HipDecoder:
         else:
             self._gemm(xf, self.h, w[p + "self_attn.qkv_proj.weight"], self.qkv_n, self.buf_qkv, T, self.qkv_n,
                        bias=w.get(p + "self_attn.qkv_proj.bias"))
-            if gemm_only or defer_rope:
+            if gemm_only:
                 return
             H.rope_store_kv(self.buf_qkv, positions, self.cos_sin, slot_mapping, self.buf_q, kc, vc, T, self.nh, self.nkv,
                             self.hd, self.block_size, q_norm_w=w.get(p + "self_attn.q_norm.weight"),
@@ -600,7 +583,6 @@ class HipDecoder:
             self._forward_tree_seg(positions, T, meta, splits, attn_waves)
             return
         fuse_ao = parts and self.attn_o_plan(T, meta, splits)
-        qkv_attn = not fuse_ao and self.qkv_attn_plan(T, meta, splits)
         # tensor parallel with the one-shot collective: the all-reduce after o_proj / down_proj absorbs the residual add
         # and the RMSNorm that follow it (csrc/comm.hip), 2 launches fewer per half layer
         ar = self.custom_ar
@@ -609,7 +591,7 @@ class HipDecoder:
         L = cfg.num_layers
         pf_d = 0            # split-K slabs the previous layer's down_proj left for this layer's input norm (single-chunk prefill)
         for li in range(L):
-            self.launch_qkv(li, T, positions, meta.slot_mapping, pre_normed=fuse and li > 0, parts=parts, pf_src=pf_d, defer_rope=qkv_attn)
+            self.launch_qkv(li, T, positions, meta.slot_mapping, pre_normed=fuse and li > 0, parts=parts, pf_src=pf_d)
             if self.taps is not None and li in self.taps:
                 # launch_qkv has just written x + residual: to buf_res2 on the fused-prologue path, to buf_res otherwise
                 src = self.buf_res2 if self.fusion_plan(T)[1] else res
@@ -620,15 +602,6 @@ class HipDecoder:
                 H.attn_oproj_parts(self.buf_q, self.kv_cache[li, 0], self.kv_cache[li, 1], meta.block_tables, self.max_blocks,
                                    meta.context_lens, T, self.nh, self.nkv, self.hd, self.block_size, scale,
                                    w[f"model.layers.{li}.self_attn.o_proj.weight"], self.h, self.buf_parts_o)
-            elif qkv_attn:
-                p_ = f"model.layers.{li}.self_attn."
-                H.attn_paged_qkv(self.buf_qkv, positions, self.cos_sin, meta.slot_mapping, self.kv_cache[li, 0], self.kv_cache[li, 1],
-                                 meta.block_tables, self.max_blocks, meta.context_lens, meta.B, T, meta.q_per_seq, self.nh, self.nkv,
-                                 self.hd, self.block_size, scale, q_norm_w=w.get(p_ + "q_norm.weight"), k_norm_w=w.get(p_ + "k_norm.weight"),
-                                 eps=cfg.rms_norm_eps, qkv_perm=1, mode=meta.mode, tree_K=meta.tree_K, tree_mq=meta.tree_mq,
-                                 tree_step=meta.tree_step, tree_F=meta.tree_F, tree_jidx=meta.tree_jidx, out_frag=self.buf_af,
-                                 waves=attn_waves)
-                pf_o = self.launch_o(li, T, parts=parts, pf_partials=not parts)
             else:
                 H.attn_paged(self.buf_q, self.kv_cache[li, 0], self.kv_cache[li, 1], meta.block_tables, self.max_blocks,
                              meta.context_lens, meta.B, T, meta.max_q, self.nh, self.nkv, self.hd, self.block_size, scale,

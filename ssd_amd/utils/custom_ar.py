@@ -28,13 +28,14 @@ SPIN_BUDGET = 100_000_000     # polls (~1 us each after the first 4096: ~100 s) 
 
 
 class OneShotAllReduce:
-    def __init__(self, group, device: torch.device):
+    def __init__(self, group, device: torch.device, granules: bool = True):
         self.lib = load_library()
         self.group, self.device = group, device
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        # SSD_AR_PROTO=flag keeps every message on the stage -> flag -> peer-read protocol; default: granules for the small ones
-        self.granules = os.environ.get("SSD_AR_PROTO", "granule") != "flag"
+        # granules for the small messages (the default); False keeps every message on the stage -> flag -> peer-read protocol
+        # (the self-test runs both: `python -m ssd_amd.utils.custom_ar` with SSD_AR_PROTO=flag)
+        self.granules = granules
         torch.cuda.set_device(device)
         self._own, self._opened = [], []
         # Every rank takes part in every collective of this constructor even if a local step failed, and the outcome is
@@ -174,7 +175,7 @@ def _selftest_main() -> int:
     dev = torch.device("cuda", int(os.environ.get("SSD_AR_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
     torch.cuda.set_device(dev)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    ar = OneShotAllReduce(dist.group.WORLD, dev)
+    ar = OneShotAllReduce(dist.group.WORLD, dev, granules=os.environ.get("SSD_AR_PROTO", "granule") != "flag")      # (test plumbing)
     ok = True
     g = torch.Generator().manual_seed(1234)
     for n in (4, 4096, 7 * 8192, 24 * 2048, SLOT_ELEMS):

@@ -388,3 +388,93 @@ def test_the_two_full_node_layouts_of_the_benchmark_gloo(world, ndraft):
     for a, b in zip([o["token_ids"] for o in one], got[0][0]):
         n = next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), len(a))
         assert len(a) == len(b) and n >= 4, (a, b)
+
+
+def _logging_factory(log, fail_at=None):
+    """Oracle runners whose draft side records the order of (speculation-cache lookup | JIT chain | chained speculation) and of the
+    resident-segment error check (ModelRunner.check_segments on the HIP runner) -- optionally failing the n-th check."""
+    from oracle.runner import oracle_runner_factory
+    base = oracle_runner_factory()
+
+    def factory(config, model_cfg, *, is_draft, **kw):
+        r = base(config, model_cfg, is_draft=is_draft, **kw)
+        if not is_draft:
+            return r
+
+        def wrap(name):
+            orig = getattr(r, name)
+
+            def f(*a, **k):
+                log.append(name)
+                return orig(*a, **k)
+            setattr(r, name, f)
+        for name in ("draft_jit", "cache_lookup", "speculate_chain", "draft_tree"):
+            if hasattr(r, name):
+                wrap(name)
+
+        def check(sync=False):
+            log.append(("check", sync))
+            if fail_at is not None and sum(1 for x in log if isinstance(x, tuple)) == fail_at:
+                raise RuntimeError("a bounded wait inside a resident layer segment gave up")
+        r.check_segments = check
+        return r
+    return factory
+
+
+def _run_logged(mode, log, fail_at=None, same=False):
+    from ssd_amd.engine.llm_engine import LLMEngine
+    from ssd_amd.sampling_params import SamplingParams
+    t, d = cfgs()
+    kw = dict(KW, max_num_seqs=1, draft="d", draft_hf_config=t if same else d, speculate=True, speculate_k=3)
+    if same:
+        kw.update(draft_weights_seed=0)
+    if mode == "async":
+        kw.update(draft_async=True, async_fan_out=2, jit_speculate=True)
+    eng = LLMEngine("t", hf_config=t, runner_factory=_logging_factory(log, fail_at), inprocess_draft=mode == "async", **kw)
+    try:
+        out, _ = eng.generate(PROMPTS[:1], SamplingParams(temperature=0.0, max_new_tokens=14, ignore_eos=True), use_tqdm=False)
+    finally:
+        eng.exit()
+    return out[0]["token_ids"]
+
+
+def test_segment_error_word_is_checked_in_the_round_it_belongs_to():
+    """until round 5 the resident segments' error word was looked at on entry of the NEXT draft-side call
+    (one round late).  Now: synchronous speculation checks after the verify's read-back of the SAME round, before the accepted
+    tokens are committed; the draft server checks right after the cache lookup's read-back (the tree round whose cache it is about
+    to serve) and -- reading the device word -- right after a JIT chain, before the reply leaves."""
+    log = []
+    _run_logged("sync", log)
+    kinds = [x for x in log if x == "speculate_chain" or isinstance(x, tuple)]
+    assert kinds and kinds[0] == "speculate_chain"
+    for a, b in zip(kinds[::2], kinds[1::2]):
+        assert a == "speculate_chain" and b == ("check", False), kinds       # every chain is followed by its own round's check
+    assert len(kinds) % 2 == 0
+    # a failure reported by the n-th check ends THAT round: no further chain is launched, generate() raises
+    log2 = []
+    import pytest
+    with pytest.raises(RuntimeError, match="resident layer segment"):
+        _run_logged("sync", log2, fail_at=2)
+    assert [x for x in log2 if x == "speculate_chain"].__len__() == 2
+
+    # asynchronous: misses (independent draft) -> lookup, check(False), JIT chain, check(True) in every round
+    log = []
+    _run_logged("async", log)
+    seq = [x for x in log if x in ("cache_lookup", "draft_jit") or isinstance(x, tuple)]
+    assert "draft_jit" in seq
+    for i, x in enumerate(seq):
+        if x == "draft_jit":
+            assert seq[i + 1] == ("check", True), seq[i:i + 3]
+        if x == "cache_lookup":
+            assert seq[i + 1] == ("check", False), seq[i:i + 3]
+    # hits (draft == target): every served round is preceded by the check of the tree round that built its cache
+    log = []
+    _run_logged("async", log, same=True)
+    seq = [x for x in log if x == "cache_lookup" or isinstance(x, tuple)]
+    assert seq.count("cache_lookup") >= 2
+    for i, x in enumerate(seq):
+        if x == "cache_lookup":
+            assert seq[i + 1] == ("check", False)
+    log2 = []
+    with pytest.raises(RuntimeError, match="resident layer segment"):
+        _run_logged("async", log2, fail_at=3, same=True)
