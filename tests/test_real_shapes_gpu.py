@@ -209,24 +209,34 @@ def test_decoder_layer_and_head_at_real_shapes(H, preset):
         pos0 += M
 
 
-def test_eight_layer_70b_cut_verify_and_tree_step_vs_oracle_and_exact_arithmetic(H):
-    """Depth at the headline model's shapes (VERDICT r4 "missing" 2 / item 2b): an EIGHT-layer cut of Llama-3.1-70B (h 8192, 64 / 8 heads,
-    I 28672, V 128256) with plain N(0, 0.02) weights -- nothing damped -- through HipDecoder (the engine's launch sequence): a 24-token
-    prefill, an M = 8 verify (the metric's K + 1 rows) and one 24-branch tree-decode step (structural mask) against (a) the oracle
-    model and (b) the float64 forward of the same weights under the same visibility: every HIP row must be as close to exact arithmetic
-    as the oracle pipeline's row is (rms <= 1.25 x + 1e-3, max <= 1.5 x + 1e-3), argmax identical outside near-ties, the new K / V rows
-    of the last layer within the propagated-noise bar."""
+def test_sixteen_layer_70b_cut_verify_accept_reject_and_tree_step_vs_oracle_and_exact_arithmetic(H):
+    """Depth at the HEADLINE model's shapes, always on (round 5 ran 8 layers): a SIXTEEN-layer cut of Llama-3.1-70B
+    (h 8192, 64 / 8 heads, I 28672, V 128256) with plain N(0, 0.02) weights -- nothing damped -- through HipDecoder (the engine's
+    launch sequence, the kernels the metric's verify runs): a 24-token prefill, the metric's M = 8 verify INCLUDING greedy accept /
+    reject (the LM head's argmax candidates -> ssd_argmax_parts_verify, reference ssd/utils/verify.py:28-48) and one 24-branch
+    tree-decode step (structural mask) against (a) the oracle model and (b) the float64 forward of the same weights under the same
+    visibility: every HIP row must be as close to exact arithmetic as the oracle pipeline's row is (rms <= 1.25 x + 1e-3, max <= 1.5 x
+    + 1e-3), argmax identical outside near-ties, accepted length and recovery token identical (a difference only where the oracle's
+    own top-2 margin at the deciding row is a near-tie), the new K / V rows of the last layer within the propagated-noise bar.
+    The speculation is built FROM the oracle's greedy continuation (three agreeing draft tokens, then a wrong one), so the accept
+    path, the first-mismatch path and the recovery pick all run.  Weights are generated on the GPU (seconds instead of a minute for
+    29 GB) and copied to the host for the oracle.  Reference: ssd/models/llama3.py:248-273, ssd/utils/verify.py:28-48."""
     from oracle import ops as O
     from oracle.model import OracleModel, Ctx
     from ssd_amd import weights as W
     from ssd_amd.model import HipDecoder, AttnMeta
     from tests.util import truth_forward_masked
-    L = 8
+    L = 16
     cfg = one_layer(PRESETS["llama-3.1-70b"], L)
-    full = W.synthetic_state_dict(cfg, seed=21, std=0.02)
     bs, nblocks = 256, 2
     dec = HipDecoder(cfg, max_tokens=64, max_seqs=1, max_blocks=2, block_size=bs, max_model_len=512, device=torch.device("cuda", 0))
-    dec.load_weights(iter(full.items()))
+    full = {}
+
+    def both():
+        for name, t in W.synthetic_weights(cfg, 21, 0.02, gen_device="cuda"):
+            full[name] = t.cpu()
+            yield name, t
+    dec.load_weights(both())
     dec.alloc_kv(nblocks)
     orc = OracleModel(cfg, full, nblocks, bs)
     random.seed(9)
@@ -252,11 +262,39 @@ def test_eight_layer_70b_cut_verify_and_tree_step_vs_oracle_and_exact_arithmetic
     orc.forward(i64(prompt), i64(range(P)), Ctx("prefill", slot_mapping=slots(range(P)), cu_q=cu, cu_k=cu))
     dec.forward(i64(prompt).cuda(), i64(range(P)).cuda(), P, AttnMeta(H.MODE_CAUSAL, 1, P, slots(range(P)).cuda(), i32([P]).cuda(), bt.cuda(), cu_q=cu.cuda()))
     vp = list(range(P, P + K + 1))
-    ref_v = orc.compute_logits(orc.forward(i64(vt), i64(vp), Ctx("verify", slot_mapping=slots(vp), context_lens=i32([P + K + 1]), block_tables=bt,
-                                                               cu_q=i32([0, K + 1])))).double()
+
+    def oracle_verify(tokens):
+        return orc.compute_logits(orc.forward(i64(tokens), i64(vp), Ctx("verify", slot_mapping=slots(vp), context_lens=i32([P + K + 1]), block_tables=bt,
+                                                                        cu_q=i32([0, K + 1])))).double()
+    # the speculation: vt[0] = the recovery token, then the oracle's own greedy continuation for three positions (row i's argmax depends
+    # only on tokens <= i: causal), then random tokens -> accepted length 3, recovery = the oracle's prediction at row 3
+    AGREE = 3
+    for i in range(AGREE):
+        vt[i + 1] = int(oracle_verify(vt)[i].argmax())
+    ref_v = oracle_verify(vt)
+    spec = i64(vt).view(1, K + 1)
+    ref_acc, ref_rec = O.verify_greedy(ref_v.argmax(-1).view(1, K + 1), spec)
+    assert int(ref_acc) == AGREE, "the oracle itself must accept its own continuation"
     dec.forward(i64(vt).cuda(), i64(vp).cuda(), K + 1, AttnMeta(H.MODE_CAUSAL, 1, K + 1, slots(vp).cuda(), i32([P + K + 1]).cuda(), bt.cuda(), q_per_seq=K + 1))
     n = dec.compute_logits(K + 1)
     got_v = dec.logits[:n].double().cpu()
+    d_preds = torch.zeros(K + 1, dtype=torch.int64, device="cuda")
+    d_acc = torch.zeros(1, dtype=torch.int32, device="cuda")
+    d_rec = torch.zeros(1, dtype=torch.int64, device="cuda")
+    d_packed = torch.zeros(1, K + 3, dtype=torch.int64, device="cuda")
+    dec.argmax_verify(1, K, spec.cuda(), d_preds, d_acc, d_rec, d_packed)
+    torch.cuda.synchronize()
+    top2v = ref_v.topk(2, dim=-1).values
+    margins = (top2v[:, 0] - top2v[:, 1])
+    dev_rows = (got_v - ref_v).abs().max(-1).values
+    assert torch.equal(d_preds.cpu(), got_v.argmax(-1)), "argmax from the LM head's candidates != argmax over the stored logits"
+    hip_acc, hip_rec = int(d_acc.item()), int(d_rec.item())
+    print(f"70B x {L} layers greedy verify: oracle accepts {int(ref_acc)} (recovery {int(ref_rec)}), HIP accepts {hip_acc} (recovery {hip_rec}); "
+          f"oracle top-2 margins of the 8 rows {[round(float(m), 3) for m in margins]}")
+    if (hip_acc, hip_rec) != (int(ref_acc), int(ref_rec)):
+        row = min(hip_acc, int(ref_acc))                # the row whose argmax decided differently
+        assert float(margins[row]) < max(0.0625, 2 * float(dev_rows[row])), \
+            f"accept / reject differs from the oracle's at row {row} whose margin {float(margins[row]):.4f} is no near-tie"
     rope_pos = [P + j + 1 for j in jidx]
     cache_pos = [P + K + 1 + i for i in range(MQ)]
     ctx = Ctx("tree", slot_mapping=slots(cache_pos), context_lens=i32([cache_pos[-1] + 1]), block_tables=bt, tree_step=0, tree_K=K, tree_jidx=[jidx])
@@ -284,9 +322,11 @@ def test_eight_layer_70b_cut_verify_and_tree_step_vs_oracle_and_exact_arithmetic
         for which in (0, 1):
             ref_rows = torch.stack([orc.kv_cache[which, L - 1, table[p // bs], p % bs] for p in ps]).float()
             got_rows = torch.stack([dec.kv_cache[L - 1, which, table[p // bs], :, p % bs, :] for p in ps]).cpu().float()
-            tol = 2.0 ** (math.floor(math.log2(ref_rows.abs().max().item())) - 4)          # (7 layers of propagated bf16 noise in front: measured 0.16 max / 0.029 mean at |k| < 8)
+            tol = 2.0 ** (math.floor(math.log2(ref_rows.abs().max().item())) - 4)          # (15 layers of propagated bf16 noise in front; 8 layers measured 0.16 max / 0.029 mean at |k| < 8)
             dkv = (got_rows - ref_rows).abs()
-            assert dkv.max().item() <= tol and dkv.mean().item() <= tol / 8, (what, which, dkv.max().item(), dkv.mean().item(), tol)
+            print(f"   last layer's new {'KV'[which]} rows ({what}): |HIP-oracle| max {dkv.max():.4f} mean {dkv.mean():.5f} (|ref| max {ref_rows.abs().max():.2f})")
+            # noise grows ~ sqrt(layers): twice the 8-layer bar of round 5 (which sat at 0.16 / 0.029 against 0.25 / 0.031)
+            assert dkv.max().item() <= 2 * tol and dkv.mean().item() <= tol / 4, (what, which, dkv.max().item(), dkv.mean().item(), tol)
 
 
 @pytest.mark.skipif(os.environ.get("SSD_FULL_70B") != "1", reason="one-off (6+ minutes, 139 GB of host memory for the oracle): SSD_FULL_70B=1; log in profiles/")

@@ -152,13 +152,16 @@ def test_hip_draft_server_replays_the_reference_runner_rounds(gpu, golden, name,
         assert compared[0] >= 60 and len(excused) <= 4, f"compared {compared[0]} decisions, excused {excused}"
 
 
-def _full_size_pair(layer_gain: float = 0.05):
+def _full_size_pair(layer_gain: float = 0.05, target: str = "llama-3.1-8b", target_layers: int | None = None):
     """Llama-3.1-8B shapes (32 layers, h 4096, V 128256) + the full Llama-3.2-1B draft (16 layers): the correlated synthetic
-    pair (ssd_amd/weights.py _pair_tensor), generated on the GPU (18.5 GB of bf16) and copied to the host once for the oracle."""
+    pair (ssd_amd/weights.py _pair_tensor), generated on the GPU (18.5 GB of bf16) and copied to the host once for the oracle.
+    target / target_layers: another preset, cut to that many layers (the 70B geometry of the metric's own configuration)."""
     import dataclasses
     from ssd_amd import weights as W
     from ssd_amd.model_config import PRESETS
-    tcfg = PRESETS["llama-3.1-8b"]
+    tcfg = PRESETS[target]
+    if target_layers is not None:
+        tcfg = dataclasses.replace(tcfg, num_layers=target_layers)
     dcfg = dataclasses.replace(PRESETS["llama-3.2-1b"], tie_word_embeddings=False)     # the pair recipe unties the 1B head (DESIGN section 6)
     recipe = {"kind": "pair", "shared": dcfg.hidden_size, "snr": 8.0, "layer_gain": layer_gain}
     wt = {n: t.cpu() for n, t in W.synthetic_weights(tcfg, 0, 0.02, gen_device="cuda", recipe=recipe)}
@@ -167,7 +170,7 @@ def _full_size_pair(layer_gain: float = 0.05):
 
 
 def _lockstep_full_size(mode: str, n_new: int, layer_gain: float = 0.05, thr: float | None = None, min_rounds: float = 0.85,
-                        min_tokens: float = 0.9, max_restarts: int = 16):
+                        min_tokens: float = 0.9, max_restarts: int = 16, target: str = "llama-3.1-8b", target_layers: int | None = None):
     """Product engine on the MI355X against the oracle engine on the host, round by round (tests/lockstep.py): hit flags,
     speculated tokens, accepted suffixes; an excused near-tie re-synchronises both runs on the oracle's tokens."""
     import random
@@ -176,7 +179,8 @@ def _lockstep_full_size(mode: str, n_new: int, layer_gain: float = 0.05, thr: fl
     from ssd_amd.sampling_params import SamplingParams
     from tests.lockstep import compare_lockstep
     from tests.lockstep import NEAR_TIE
-    tcfg, dcfg, wt, wd = _full_size_pair(layer_gain)
+    tcfg, dcfg, wt, wd = _full_size_pair(layer_gain, target, target_layers)
+    label = target + (f" x {target_layers} layers" if target_layers else "") + " + 1B"
     random.seed(5)
     prompt = [random.randint(0, 10000) for _ in range(96)]
     kw = dict(hf_config=tcfg, max_num_seqs=1, max_model_len=1024, max_num_batched_tokens=1024, kvcache_block_size=256,
@@ -195,9 +199,9 @@ def _lockstep_full_size(mode: str, n_new: int, layer_gain: float = 0.05, thr: fl
                         topology=Topology(0, 1, torch.device("cpu"), "target", 0, 1), **kw)      # (the oracle's tensors live on the host)
     rep = compare_lockstep(gpu_eng, cpu_eng, prompt, n_new, lambda n: SamplingParams(temperature=0, max_new_tokens=n, ignore_eos=True),
                            fan_out=3 if mode == "async" else None, thr=NEAR_TIE if thr is None else thr, max_restarts=max_restarts,
-                           what=f"8B+1B {mode} layer_gain {layer_gain}")
+                           what=f"{label} {mode} layer_gain {layer_gain}")
     gpu_eng.exit()
-    print(f"full size 8B + 1B {mode} (layer_gain {layer_gain}): {rep.summary()}")
+    print(f"full size {label} {mode} (layer_gain {layer_gain}): {rep.summary()}")
     assert rep.tokens == n_new
     assert rep.tokens_compared >= min_tokens * rep.tokens, rep.summary()  # only the disputed near-tie tokens themselves go uncompared
     assert rep.rounds_compared >= min_rounds * rep.rounds, rep.summary()  # (round 4 accepted 0.6; measured: sync 27 / 32, async 33 / 37)
@@ -252,6 +256,20 @@ def test_full_size_lockstep_with_undamped_layers(gpu, mode):
     rep = _lockstep_full_size(mode, 24, layer_gain=1.0, thr=0.125, min_rounds=0.45, min_tokens=0.75, max_restarts=24)
     if mode == "async":
         assert rep.real_misses > 0, rep.summary()
+
+
+def test_c4_shaped_async_lockstep_70b_geometry_cut_with_undamped_layers(gpu):
+    """The METRIC's own configuration in shape (BASELINE.json configs[3] / bench.py c4): a target with Llama-3.1-70B's geometry (h 8192,
+    64 / 8 heads, I 28672, V 128256 -- the launch shapes, kernels and dispatch choices of the benchmarked verify; cut to 8 layers so the
+    oracle engine fits the host and the test stays under a minute) + the full 16-layer Llama-3.2-1B draft, asynchronous speculation
+    k = 7, f = 3, jit backup, co-located draft server, hipGraphs, at layer_gain 1.0 (nothing damped: every attention / MLP kernel's error
+    reaches the token decisions) -- lock-step against the oracle engine on the host.  Same criteria as the undamped
+    8B runs above: every decision with a real oracle margin must match, near-ties (<= two bf16 ulps of the ORACLE's own margin) are
+    excused and re-synchronised, all tokens are reached.  Reference: ssd/engine/step.py:91-163, speculator_async.py:92-187,
+    draft_runner.py:186-378,713-812, utils/verify.py:28-48."""
+    rep = _lockstep_full_size("async", 24, layer_gain=1.0, thr=0.125, min_rounds=0.45, min_tokens=0.75, max_restarts=24,
+                              target="llama-3.1-70b", target_layers=8)
+    assert rep.real_misses > 0, rep.summary()
 
 
 def test_full_size_eagle3_llama8b_lockstep(gpu):
