@@ -1,0 +1,92 @@
+"""Round 6: the norm-carrying GEMM forms (csrc/xsum.h) against the launches they replace, at the 70B verify's shapes (M = 8).
+Each kind is a hipGraph of 24 launches rotating through 3 copies of its weights (nothing cache-resident); per-launch time = graph time / 24.
+    python profiles/micro/xsum_probe.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from ssd_amd.hip import ops as H  # noqa: E402
+
+BF = torch.bfloat16
+M, h, qn, I, nh, nkv, hd = 8, 8192, 8192, 28672, 64, 8, 128
+N_QKV = (nh + 2 * nkv) * hd
+COPIES, REPS = 3, 24
+
+
+def w(n, k):
+    return [torch.empty(n * k, dtype=BF, device="cuda").normal_(0, 0.02) for _ in range(COPIES)]
+
+
+def timed(body):
+    body(0)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(REPS):
+            body(i % COPIES)
+    g.replay()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / REPS)
+    return best
+
+
+@torch.inference_mode()
+def main():
+    wo, wgu, wd, wq = w(h, qn), w(2 * I, h), w(h, I), w(N_QKV, h)
+    a_f = torch.empty(H.frag_numel(M, qn), dtype=BF, device="cuda").normal_(0, 1)
+    act_f = torch.empty(H.frag_numel(M, I), dtype=BF, device="cuda").normal_(0, 0.5)
+    xf = torch.empty(H.frag_numel(M, h), dtype=BF, device="cuda").normal_(0, 1)
+    y = torch.zeros(M, h, dtype=BF, device="cuda")
+    res = torch.randn(M, h, device="cuda").to(BF)
+    nw = torch.ones(h, dtype=BF, device="cuda")
+    x32 = torch.zeros(16 * h, dtype=torch.float32, device="cuda")
+    gss = torch.zeros(h, dtype=torch.float32, device="cuda")
+    H.gemm_res(a_f, wo[0], res, res, x32, gss, M, h, qn)          # valid x32 / group sums for the consumers
+    pos = torch.arange(100, 100 + M, dtype=torch.int64, device="cuda")
+    cs = torch.randn(1024, hd, device="cuda")
+    slots = torch.arange(M, dtype=torch.int32, device="cuda")
+    q_out = torch.zeros(M, nh * hd, dtype=BF, device="cuda")
+    kc = torch.zeros(2, nkv, 256, hd, dtype=BF, device="cuda")
+    vc = torch.zeros_like(kc)
+    rope = dict(positions=pos, cos_sin=cs, slots=slots, q_out=q_out, k_cache=kc, v_cache=vc, nh=nh, nkv=nkv, hd=hd, block_size=256)
+    t = {}
+    t["o_proj rows"] = timed(lambda i: H.gemm(a_f, wo[i], y, M, h, qn, h))
+    t["o_proj + add (res)"] = timed(lambda i: H.gemm_res(a_f, wo[i], res, res, x32, gss, M, h, qn))
+    t["down rows"] = timed(lambda i: H.gemm(act_f, wd[i], y, M, h, I, h))
+    t["down + add (res)"] = timed(lambda i: H.gemm_res(act_f, wd[i], res, res, x32, gss, M, h, I))
+    t["rmsnorm"] = timed(lambda i: H.rmsnorm(y, nw, 1e-5, M, h, res_in=res, res_out=res, out_frag=xf))
+    t["gate_up"] = timed(lambda i: H.gemm(xf, wgu[i], act_f, M, 2 * I, h, 0, epilogue=H.EPI_SILU_FRAG))
+    t["gate_up xs"] = timed(lambda i: H.gemm_xs(x32, gss, nw, 1e-5, wgu[i], act_f, M, 2 * I, h))
+    t["qkv+rope"] = timed(lambda i: H.gemm_fused(wq[i], M, N_QKV, h, H.FEPI_QKV_ROPE, x_frag=xf, **rope))
+    t["qkv+rope xs"] = timed(lambda i: H.gemm_fused_xs(x32, gss, nw, 1e-5, wq[i], M, N_QKV, h, **rope))
+
+    def sep(i):
+        H.gemm(a_f, wo[i], y, M, h, qn, h)
+        H.rmsnorm(y, nw, 1e-5, M, h, res_in=res, res_out=res, out_frag=xf)
+        H.gemm(xf, wgu[i], act_f, M, 2 * I, h, 0, epilogue=H.EPI_SILU_FRAG)
+        H.gemm(act_f, wd[i], y, M, h, I, h)
+        H.rmsnorm(y, nw, 1e-5, M, h, res_in=res, res_out=res, out_frag=xf)
+        H.gemm_fused(wq[i], M, N_QKV, h, H.FEPI_QKV_ROPE, x_frag=xf, **rope)
+
+    def xs(i):
+        H.gemm_res(a_f, wo[i], res, res, x32, gss, M, h, qn)
+        H.gemm_xs(x32, gss, nw, 1e-5, wgu[i], act_f, M, 2 * I, h)
+        H.gemm_res(act_f, wd[i], res, res, x32, gss, M, h, I)
+        H.gemm_fused_xs(x32, gss, nw, 1e-5, wq[i], M, N_QKV, h, **rope)
+    t["LAYER minus attention, separate (6 launches)"] = timed(sep)
+    t["LAYER minus attention, xsum (4 launches)"] = timed(xs)
+    for k, v in t.items():
+        print(f"{k:48s} {v:8.2f} us")
+
+
+if __name__ == "__main__":
+    main()

@@ -12,8 +12,11 @@
 //    combine through LDS in a fixed order (deterministic, no atomics, no inter-workgroup traffic).
 //  * Weight loads are non-temporal (each byte is read exactly once per forward).
 #include "common.h"
+#include "xsum.h"
 
-enum { EPI_ROWS = 0, EPI_SILU_FRAG = 1, EPI_ROWS_F32 = 2, EPI_ROWS_ARGMAX = 3 };
+// EPI_ROWS_RES (round 6, xsum.h): the row-parallel projection's epilogue also performs the residual add that follows it and leaves
+// what the NEXT GEMM needs to apply the RMSNorm itself (fp32 x, per-group sums of squares) -- no bf16 rows, no norm launch.
+enum { EPI_ROWS = 0, EPI_SILU_FRAG = 1, EPI_ROWS_F32 = 2, EPI_ROWS_ARGMAX = 3, EPI_ROWS_RES = 4 };
 
 // EPI_ROWS_ARGMAX (the LM head on the greedy path): bf16 rows as EPI_ROWS, plus every workgroup's own (max value, lowest
 // index) of each token row over the features it produced -- compared on the bf16-ROUNDED values, i.e. exactly what an
@@ -33,12 +36,21 @@ struct Stage {
   u32x4_t a[NT];
   u32x4_t b[MT];
 };
+template <int NT>
+struct StageX {                    // XS: a stage IN FLIGHT carries the B operand as fp32 x (32 bytes per lane); it becomes x^ (a Stage)
+  u32x4_t a[NT];                   // when the stage is adopted as the current one
+  f32x4_t xr[2];
+};
 
-template <int MT, int NT, int EPI>
-__global__ void __launch_bounds__(1024)
+// XS (MT = 1): x comes as the producer's fp32 x + group sums of squares (xsum.h); the RMSNorm is applied while the B operand is formed.
+// (XS variants are launched with <= 8 waves -- the tuned decomposition of every gate_up shape -- so they may use up to 256 VGPRs: the
+//  fp32 x of the stages in flight would not fit the 128 of a 16-wave workgroup.)
+template <int MT, int NT, int EPI, bool XS = false>
+__global__ void __launch_bounds__(XS ? 512 : 1024)
 gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
                const bf16_t* __restrict__ bias, void* __restrict__ Yv, int M, int N, int K, int ldy, int tpw,
-               float* __restrict__ part_val, int* __restrict__ part_idx, int part_stride) {
+               float* __restrict__ part_val, int* __restrict__ part_idx, int part_stride, const XsumIn xin, const XsumOut xout) {
+  static_assert(!XS || MT == 1, "the fp32-x operand form exists for one token tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KTS = EPI == EPI_SILU_FRAG ? 8 : 9;        // trace slot (profiling builds only)
   KTRACE(KTS, 0);
@@ -85,7 +97,38 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
       }
     }
   };
-  if (t_begin < t_end && kt0 < kmain) load(cur, kt0);
+  // XS: stages in flight carry fp32 x; `adopt` turns the arrived stage into the current one (x^ = bf16((x32 * rs) * w), norm weights from LDS)
+  StageX<NT> nx[XS ? U : 1];
+  float xs_rs = 0.f;
+  const u32x4_t* xs_w = nullptr;
+  auto loadx = [&](int kt) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        nx[XS ? u : 0].a[nt] = __builtin_nontemporal_load(wp + nt * wstride + ((size_t)(kt + u) << 6));
+      xsum_load(xin.x32f, ((size_t)(kt + u) << 6) + lane, (lane & 15) < M, nx[XS ? u : 0].xr);
+    }
+  };
+  auto adopt = [&](int kt) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) cur[u].a[nt] = nx[XS ? u : 0].a[nt];
+      cur[u].b[0] = xsum_bfrag(nx[XS ? u : 0].xr, xs_rs, xs_w[(kt + u) * 4]);
+    }
+  };
+  if constexpr (XS) {
+    if (t_begin < t_end && kt0 < kmain) loadx(kt0);
+    // row scale + norm weights while the first weight tiles fly (one workgroup barrier; LDS behind the combine area)
+    char* xl = smem + (size_t)nw * NT * MT * 64 * sizeof(f32x4_t);
+    u32x4_t* wl = reinterpret_cast<u32x4_t*>(xl);
+    xs_rs = xsum_prologue(xin, K, wl, reinterpret_cast<float*>(xl + (size_t)K * 2), wave, nw, lane);
+    if ((lane & 15) >= M) xs_rs = 0.f;             // padding token rows: x^ = 0
+    xs_w = wl + (lane >> 4);
+  } else {
+    if (t_begin < t_end && kt0 < kmain) load(cur, kt0);
+  }
   ArgPart run[MT];          // EPI_ROWS_ARGMAX: this wave's best candidate per token row so far (identical in the 4 lanes of a row)
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) run[mt] = ArgPart{-INFINITY, 0x7fffffff};
@@ -108,6 +151,17 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
   };
 
   int kt = kt0;
+  if constexpr (XS) {
+    if (kt < kmain) {
+      adopt(kt);
+      for (; kt + kstep < kmain; kt += kstep) {
+        loadx(kt + kstep);
+        compute(cur);
+        adopt(kt + kstep);
+      }
+      compute(cur);
+    }
+  } else {
   if (kt < kmain) {
     for (; kt + kstep < kmain; kt += kstep) {
       load(nxt, kt + kstep);
@@ -117,6 +171,7 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
     }
     compute(cur);
   }
+  }
   for (kt = (wave == nw - 1) ? kmain : KT; kt < KT; ++kt) {  // K remainder (< U tiles): last wave
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -124,7 +179,13 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         u32x4_t b = {0u, 0u, 0u, 0u};
-        if (mt * 16 + (lane & 15) < M) b = xp[mt * xstride + ((size_t)kt << 6)];
+        if constexpr (XS) {
+          f32x4_t xr[2];
+          xsum_load(xin.x32f, ((size_t)kt << 6) + lane, (lane & 15) < M, xr);
+          b = xsum_bfrag(xr, xs_rs, xs_w[kt * 4]);
+        } else {
+          if (mt * 16 + (lane & 15) < M) b = xp[mt * xstride + ((size_t)kt << 6)];
+        }
         acc[nt][mt] = mfma16(a, b, acc[nt][mt]);
       }
     }
@@ -132,7 +193,11 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
 
   // next tile: advance the weight pointer and put its first loads in flight before the combine
   wp += (size_t)NT * wstride;
-  if (tile + 1 < t_end && kt0 < kmain) load(cur, kt0);
+  if constexpr (XS) {
+    if (tile + 1 < t_end && kt0 < kmain) loadx(kt0);
+  } else {
+    if (tile + 1 < t_end && kt0 < kmain) load(cur, kt0);
+  }
 
   // ---- cross-wave split-K combine through LDS, fixed order ----
   f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);  // [nw][NT*MT][64]
@@ -180,15 +245,19 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
   } else {
     for (int item = wave; item < ITEMS; item += nw) {
       const int nt = item / MT, mt = item % MT;
-      f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      for (int w = 0; w < nw; ++w) s += red[((w * ITEMS) + item) * 64 + lane];
       const int m = mt * 16 + mcol;
       const int n = (tile0 + nt) * 16 + nrow;
+      u32x2_t rv = {0u, 0u};
+      if (EPI == EPI_ROWS_RES && m < M) rv = *reinterpret_cast<const u32x2_t*>(xout.res_in + (size_t)m * N + n);   // in flight across the combine
+      f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int w = 0; w < nw; ++w) s += red[((w * ITEMS) + item) * 64 + lane];
       if (bias) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) s[r] += bf2f(bias[n + r]);
       }
-      if (m < M) {
+      if (EPI == EPI_ROWS_RES) {
+        xsum_epilogue(xout, s, rv, m, n, M, N, lane);
+      } else if (m < M) {
         if (EPI == EPI_ROWS_F32) {
           *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(Yv) + (size_t)m * ldy + n) = s;
         } else {
@@ -241,22 +310,25 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
 // Launch heuristics.  waves/block * blocks should put >= ~8-16 waves on each of the 256 CUs while
 // each wave still streams a few KiB contiguously.
 // ---------------------------------------------------------------------------------------------
-template <int MT, int NT, int EPI>
+template <int MT, int NT, int EPI, bool XS = false>
 static int launch_t(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int ldy,
-                    int waves, int tpw, hipStream_t st, float* part_val = nullptr, int* part_idx = nullptr, int part_stride = 0) {
+                    int waves, int tpw, hipStream_t st, float* part_val = nullptr, int* part_idx = nullptr, int part_stride = 0,
+                    const XsumIn xin = XsumIn{}, const XsumOut xout = XsumOut{}) {
   const int ntiles = (N / 16) / NT;
   if (tpw < 1) tpw = 1;
   const int blocks = (ntiles + tpw - 1) / tpw;
   if (EPI == EPI_ROWS_ARGMAX && (!part_val || !part_idx || part_stride < blocks)) return SSD_ERR_ARG;
   size_t lds = (size_t)waves * NT * MT * 64 * sizeof(f32x4_t);
   if (EPI == EPI_ROWS_ARGMAX) lds += (size_t)waves * MT * 16 * sizeof(ArgPart);      // per-wave argmax candidates behind the combine area
-  auto kern = gemm_wf_kernel<MT, NT, EPI>;
+  if (XS) lds += xsum_lds_bytes(K, waves);
+  if (lds > 160 * 1024) return SSD_ERR_SHAPE;
+  auto kern = gemm_wf_kernel<MT, NT, EPI, XS>;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return SSD_ERR_LAUNCH;
   }
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, st, (const u32x4_t*)w, (const u32x4_t*)x,
-                     (const bf16_t*)bias, y, M, N, K, ldy, tpw, part_val, part_idx, part_stride);
+                     (const bf16_t*)bias, y, M, N, K, ldy, tpw, part_val, part_idx, part_stride, xin, xout);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
@@ -332,6 +404,61 @@ extern "C" int ssd_gemm_wf(const void* x_frag, const void* w_frag, const void* b
   return ssd_gemm_wf_cfg(x_frag, w_frag, bias, y, M, N, K, ldy, epilogue, nt, waves, stream);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// xsum (xsum.h): the residual add + RMSNorm between a row-parallel projection and the next column-parallel one, carried by the
+// two GEMMs.  Decode / verify rows only (M <= 16), the shapes whose default decomposition is the register-streaming kernel above.
+//   ssd_gemm_wf_res : y = x . W^T as ssd_gemm_wf(EPI_ROWS) would store it (bf16-rounded), then x32 = y + res_in; writes
+//                     res_out = bf16(x32) [M][N], x32 (fp32 fragment-major [16][N]) and the group sums of squares [N / 16][16].
+//   ssd_gemm_wf_xs  : ssd_gemm_wf(x^ = RMSNorm(x32) * norm_w, ...) with x^ formed on the fly from the three arrays above.
+// ssd_gemm_wf_res_ok / ssd_gemm_wf_xs_ok: host-side predicates (SSD_OK when the default launch for the shape has the form).
+// ---------------------------------------------------------------------------------------------------------------------
+static bool res_cfg(int M, int N, int K, int* nt, int* waves, int* tpw) {
+  if (M <= 0 || M > 16 || (N & 15) || (K & 31) || N <= 0 || K <= 0) return false;
+  ssd_pick_skinny_cfg(N / 16, K / 32, false, nt, waves, tpw);
+  // (nt = 1 shapes run on gemm_sk.hip's single-buffered kernel by default: measured faster there, not covered here)
+  return (*nt == 2 || *nt == 4) && ((N / 16) % *nt) == 0;
+}
+
+extern "C" int ssd_gemm_wf_res_ok(int M, int N, int K) {
+  int nt, waves, tpw;
+  return res_cfg(M, N, K, &nt, &waves, &tpw) ? SSD_OK : SSD_ERR_SHAPE;
+}
+
+extern "C" int ssd_gemm_wf_res(const void* x_frag, const void* w_frag, const void* bias, const void* res_in, void* res_out,
+                               void* x32_frag, void* group_ss, int M, int N, int K, void* stream) {
+  int nt, waves, tpw;
+  if (!res_cfg(M, N, K, &nt, &waves, &tpw)) return SSD_ERR_SHAPE;
+  if (!x_frag || !w_frag || !res_in || !res_out || !x32_frag || !group_ss) return SSD_ERR_ARG;
+  const XsumOut xo{(const bf16_t*)res_in, (bf16_t*)res_out, (float*)x32_frag, (float*)group_ss};
+  hipStream_t st = (hipStream_t)stream;
+  if (nt == 2) return launch_t<1, 2, EPI_ROWS_RES>(x_frag, w_frag, bias, nullptr, M, N, K, N, waves, tpw, st, nullptr, nullptr, 0, XsumIn{}, xo);
+  return launch_t<1, 4, EPI_ROWS_RES>(x_frag, w_frag, bias, nullptr, M, N, K, N, waves, tpw, st, nullptr, nullptr, 0, XsumIn{}, xo);
+}
+
+static bool xs_cfg(int M, int N, int K, int epilogue, int* nt, int* waves, int* tpw) {
+  if (M <= 0 || M > 16 || (N & 15) || (K & 31) || N <= 0 || K <= 0) return false;
+  if (epilogue != EPI_SILU_FRAG) return false;          // (the gate_up form; the QKV + RoPE consumer is ssd_gemm_fused_xs)
+  ssd_pick_skinny_cfg(N / 16, K / 32, true, nt, waves, tpw);
+  if (!(*nt == 2 || *nt == 4) || ((N / 16) % *nt) != 0 || *waves > 8) return false;
+  return (size_t)*waves * *nt * 64 * sizeof(f32x4_t) + xsum_lds_bytes(K, *waves) <= 160 * 1024;
+}
+
+extern "C" int ssd_gemm_wf_xs_ok(int M, int N, int K, int epilogue) {
+  int nt, waves, tpw;
+  return xs_cfg(M, N, K, epilogue, &nt, &waves, &tpw) ? SSD_OK : SSD_ERR_SHAPE;
+}
+
+extern "C" int ssd_gemm_wf_xs(const void* x32_frag, const void* group_ss, const void* norm_w, float eps, const void* w_frag,
+                              const void* bias, void* y, int M, int N, int K, int ldy, int epilogue, void* stream) {
+  int nt, waves, tpw;
+  if (!xs_cfg(M, N, K, epilogue, &nt, &waves, &tpw)) return SSD_ERR_SHAPE;
+  if (!x32_frag || !group_ss || !norm_w || !w_frag || !y) return SSD_ERR_ARG;
+  const XsumIn xi{(const float*)x32_frag, (const float*)group_ss, (const bf16_t*)norm_w, eps};
+  hipStream_t st = (hipStream_t)stream;
+  if (nt == 2) return launch_t<1, 2, EPI_SILU_FRAG, true>(nullptr, w_frag, bias, y, M, N, K, ldy, waves, tpw, st, nullptr, nullptr, 0, xi);
+  return launch_t<1, 4, EPI_SILU_FRAG, true>(nullptr, w_frag, bias, y, M, N, K, ldy, waves, tpw, st, nullptr, nullptr, 0, xi);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // LM head on the greedy path: logits rows + per-workgroup argmax candidates in one launch (EPI_ROWS_ARGMAX above).
