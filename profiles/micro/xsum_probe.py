@@ -69,6 +69,24 @@ def main():
     t["qkv+rope"] = timed(lambda i: H.gemm_fused(wq[i], M, N_QKV, h, H.FEPI_QKV_ROPE, x_frag=xf, **rope))
     t["qkv+rope xs"] = timed(lambda i: H.gemm_fused_xs(x32, gss, nw, 1e-5, wq[i], M, N_QKV, h, **rope))
 
+    # gate_up decompositions: the default (nt 4, 8 waves, 4 tiles per workgroup: 224 workgroups) against 256-workgroup forms
+    for nt, wv, tpw in ((4, 8, 4), (2, 8, 7), (2, 16, 7), (4, 16, 4), (4, 8, 7)):
+        try:
+            t[f"gate_up cfg nt={nt} waves={wv} tpw={tpw} ({(2 * I // 16) // nt // tpw} wgs)"] = timed(
+                lambda i: H.gemm(xf, wgu[i], act_f, M, 2 * I, h, 0, epilogue=H.EPI_SILU_FRAG, cfg=(nt, wv | (tpw << 8))))
+        except Exception as e:
+            print("cfg", nt, wv, tpw, "->", e)
+
+    # DEEP (twice the k-tiles per stage, <= 8 waves, up to 256 VGPRs) against the plain kernel at its default decomposition
+    t["gate_up DEEP nt=4 waves=8 tpw=4"] = timed(lambda i: H.gemm(xf, wgu[i], act_f, M, 2 * I, h, 0, epilogue=H.EPI_SILU_FRAG, cfg=(4 | 256, 8 | (4 << 8))))
+    t["gate_up DEEP nt=2 waves=8 tpw=7"] = timed(lambda i: H.gemm(xf, wgu[i], act_f, M, 2 * I, h, 0, epilogue=H.EPI_SILU_FRAG, cfg=(2 | 256, 8 | (7 << 8))))
+    t["o_proj plain nt=2 waves=8"] = timed(lambda i: H.gemm(a_f, wo[i], y, M, h, qn, h, cfg=(2, 8)))
+    t["o_proj DEEP nt=2 waves=8"] = timed(lambda i: H.gemm(a_f, wo[i], y, M, h, qn, h, cfg=(2 | 256, 8)))
+    t["o_proj DEEP nt=2 waves=4"] = timed(lambda i: H.gemm(a_f, wo[i], y, M, h, qn, h, cfg=(2 | 256, 4)))
+    t["down plain nt=2 waves=8"] = timed(lambda i: H.gemm(act_f, wd[i], y, M, h, I, h, cfg=(2, 8)))
+    t["down DEEP nt=2 waves=8"] = timed(lambda i: H.gemm(act_f, wd[i], y, M, h, I, h, cfg=(2 | 256, 8)))
+    t["down DEEP nt=4 waves=8 (128 wgs)"] = timed(lambda i: H.gemm(act_f, wd[i], y, M, h, I, h, cfg=(4 | 256, 8)))
+
     def sep(i):
         H.gemm(a_f, wo[i], y, M, h, qn, h)
         H.rmsnorm(y, nw, 1e-5, M, h, res_in=res, res_out=res, out_frag=xf)

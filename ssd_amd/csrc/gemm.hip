@@ -45,8 +45,11 @@ struct StageX {                    // XS: a stage IN FLIGHT carries the B operan
 // XS (MT = 1): x comes as the producer's fp32 x + group sums of squares (xsum.h); the RMSNorm is applied while the B operand is formed.
 // (XS variants are launched with <= 8 waves -- the tuned decomposition of every gate_up shape -- so they may use up to 256 VGPRs: the
 //  fp32 x of the stages in flight would not fit the 128 of a 16-wave workgroup.)
-template <int MT, int NT, int EPI, bool XS = false>
-__global__ void __launch_bounds__(XS ? 512 : 1024)
+// DEEP (round 6): twice the k-tiles per stage -- twice the bytes in flight per wave -- for launches of <= 8 waves per workgroup, which
+// may use 256 VGPRs (the 128-VGPR ceiling of the 16-wave form is what set the depth of the plain kernel; a weight-streaming wave's
+// throughput is its bytes in flight over the memory latency).
+template <int MT, int NT, int EPI, bool XS = false, bool DEEP = false>
+__global__ void __launch_bounds__((XS || DEEP) ? 512 : 1024)
 gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
                const bf16_t* __restrict__ bias, void* __restrict__ Yv, int M, int N, int K, int ldy, int tpw,
                float* __restrict__ part_val, int* __restrict__ part_idx, int part_stride, const XsumIn xin, const XsumOut xout) {
@@ -66,7 +69,7 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
   const u32x4_t* xp = Xf + lane;
   const size_t wstride = (size_t)KT << 6;  // chunks between adjacent row groups
   const size_t xstride = (size_t)KT << 6;
-  constexpr int U = (MT + NT <= 3) ? 4 : ((MT + NT <= 6) ? 2 : 1);
+  constexpr int U = ((MT + NT <= 3) ? 4 : ((MT + NT <= 6) ? 2 : 1)) * (DEEP ? 2 : 1);
   Stage<MT, NT> cur[U], nxt[U];
   // K is dealt to the waves in groups of U k-tiles, round-robin: wave w takes groups w, w + nw, ...  The workgroup as a
   // whole therefore walks each row group's K run linearly (DRAM-friendly: measured 6.4-6.9 TB/s for this pattern against
@@ -97,33 +100,43 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
       }
     }
   };
-  // XS: stages in flight carry fp32 x; `adopt` turns the arrived stage into the current one (x^ = bf16((x32 * rs) * w), norm weights from LDS)
-  StageX<NT> nx[XS ? U : 1];
+  // XS: TWO stages in flight (a ring of two register buffers, as gemm_fused.hip), each carrying the B operand as fp32 x; a stage is
+  // consumed in place (x^ = bf16((x32 * rs) * w), norm weights from LDS) and its buffer refilled with the stage two ahead.  The ring
+  // runs over the FLAT sequence of this wave's stages across the workgroup's tiles (the next tile's first two stages are in flight
+  // during the combine of the current one).  Host-checked: no K remainder, an even number of stages per tile (xs_cfg).
+  StageX<NT> nx0[XS ? U : 1], nx1[XS ? U : 1];
   float xs_rs = 0.f;
   const u32x4_t* xs_w = nullptr;
-  auto loadx = [&](int kt) {
+  const u32x4_t* iwp = wp;              // issue cursor: weight pointer of the tile being requested ...
+  int ikt = kt0;                        // ... and its k-tile
+  int ileft = 0;                        // stages still to request
+  auto issue_now = [&](StageX<NT>(&d)[XS ? U : 1]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-        nx[XS ? u : 0].a[nt] = __builtin_nontemporal_load(wp + nt * wstride + ((size_t)(kt + u) << 6));
-      xsum_load(xin.x32f, ((size_t)(kt + u) << 6) + lane, (lane & 15) < M, nx[XS ? u : 0].xr);
+        d[XS ? u : 0].a[nt] = __builtin_nontemporal_load(iwp + nt * wstride + ((size_t)(ikt + u) << 6));
+      xsum_load(xin.x32f, ((size_t)(ikt + u) << 6) + lane, (lane & 15) < M, d[XS ? u : 0].xr);
     }
+    --ileft;
+    ikt += kstep;
+    if (ikt >= kmain) { ikt = kt0; iwp += (size_t)NT * wstride; }
   };
-  auto adopt = [&](int kt) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) cur[u].a[nt] = nx[XS ? u : 0].a[nt];
-      cur[u].b[0] = xsum_bfrag(nx[XS ? u : 0].xr, xs_rs, xs_w[(kt + u) * 4]);
-    }
+  auto issue = [&](StageX<NT>(&d)[XS ? U : 1]) {
+    if (ileft > 0) issue_now(d);
   };
   if constexpr (XS) {
-    if (t_begin < t_end && kt0 < kmain) loadx(kt0);
-    // row scale + norm weights while the first weight tiles fly (one workgroup barrier; LDS behind the combine area)
+    XsumPre pre;
+    xsum_issue(xin, K, wave, nw, lane, pre);            // the small loads go FIRST: a CU returns its loads in order
+    const int spt = kt0 < kmain ? (kmain - kt0 + kstep - 1) / kstep : 0;     // stages per tile of this wave
+    ileft = spt * max(0, t_end - t_begin);
+    // (unconditional: every workgroup has a tile and every wave >= 2 stages per tile, host-checked -- a branch here would make the
+    //  compiler's wait for the small loads above a wait for these weight loads too: it must assume the path that issued none)
+    issue_now(nx0);
+    issue_now(nx1);
     char* xl = smem + (size_t)nw * NT * MT * 64 * sizeof(f32x4_t);
     u32x4_t* wl = reinterpret_cast<u32x4_t*>(xl);
-    xs_rs = xsum_prologue(xin, K, wl, reinterpret_cast<float*>(xl + (size_t)K * 2), wave, nw, lane);
+    xs_rs = xsum_finish(xin, pre, K, wl, reinterpret_cast<float*>(xl + (size_t)K * 2), wave, nw, lane);
     if ((lane & 15) >= M) xs_rs = 0.f;             // padding token rows: x^ = 0
     xs_w = wl + (lane >> 4);
   } else {
@@ -152,14 +165,19 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
 
   int kt = kt0;
   if constexpr (XS) {
-    if (kt < kmain) {
-      adopt(kt);
-      for (; kt + kstep < kmain; kt += kstep) {
-        loadx(kt + kstep);
-        compute(cur);
-        adopt(kt + kstep);
+    auto consume = [&](StageX<NT>(&d)[XS ? U : 1], int ktc) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const u32x4_t b = xsum_bfrag(d[XS ? u : 0].xr, xs_rs, xs_w[(ktc + u) * 4]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt][0] = mfma16(d[XS ? u : 0].a[nt], b, acc[nt][0]);
       }
-      compute(cur);
+    };
+    for (; kt < kmain; kt += 2 * kstep) {
+      consume(nx0, kt);
+      issue(nx0);
+      consume(nx1, kt + kstep);
+      issue(nx1);
     }
   } else {
   if (kt < kmain) {
@@ -193,9 +211,7 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
 
   // next tile: advance the weight pointer and put its first loads in flight before the combine
   wp += (size_t)NT * wstride;
-  if constexpr (XS) {
-    if (tile + 1 < t_end && kt0 < kmain) loadx(kt0);
-  } else {
+  if constexpr (!XS) {          // (XS: the ring has the next tile's first two stages in flight already)
     if (tile + 1 < t_end && kt0 < kmain) load(cur, kt0);
   }
 
@@ -310,7 +326,7 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
 // Launch heuristics.  waves/block * blocks should put >= ~8-16 waves on each of the 256 CUs while
 // each wave still streams a few KiB contiguously.
 // ---------------------------------------------------------------------------------------------
-template <int MT, int NT, int EPI, bool XS = false>
+template <int MT, int NT, int EPI, bool XS = false, bool DEEP = false>
 static int launch_t(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int ldy,
                     int waves, int tpw, hipStream_t st, float* part_val = nullptr, int* part_idx = nullptr, int part_stride = 0,
                     const XsumIn xin = XsumIn{}, const XsumOut xout = XsumOut{}) {
@@ -322,7 +338,8 @@ static int launch_t(const void* x, const void* w, const void* bias, void* y, int
   if (EPI == EPI_ROWS_ARGMAX) lds += (size_t)waves * MT * 16 * sizeof(ArgPart);      // per-wave argmax candidates behind the combine area
   if (XS) lds += xsum_lds_bytes(K, waves);
   if (lds > 160 * 1024) return SSD_ERR_SHAPE;
-  auto kern = gemm_wf_kernel<MT, NT, EPI, XS>;
+  if ((XS || DEEP) && waves > 8) return SSD_ERR_ARG;
+  auto kern = gemm_wf_kernel<MT, NT, EPI, XS, DEEP>;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return SSD_ERR_LAUNCH;
@@ -354,6 +371,21 @@ extern "C" int ssd_gemm_wf_cfg(const void* x_frag, const void* w_frag, const voi
   if (M <= 0 || M > 128 || (N & 15) || (K & 31) || N <= 0 || K <= 0) return SSD_ERR_SHAPE;
   const int tpw = (waves >> 8) & 0xff;
   waves &= 0xff;
+  const bool deep = (nt >> 8) & 1;          // bit 8 of nt: the DEEP form (M <= 16, <= 8 waves, nt 2 / 4, rows or SiLU epilogue)
+  nt &= 0xff;
+  if (deep) {
+    if (M > 16 || waves > 8 || (nt != 2 && nt != 4) || ((N / 16) % nt) != 0) return SSD_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (epilogue == EPI_ROWS) {
+      if (nt == 2) return launch_t<1, 2, EPI_ROWS, false, true>(x_frag, w_frag, bias, y, M, N, K, ldy, waves, tpw, st);
+      return launch_t<1, 4, EPI_ROWS, false, true>(x_frag, w_frag, bias, y, M, N, K, ldy, waves, tpw, st);
+    }
+    if (epilogue == EPI_SILU_FRAG) {
+      if (nt == 2) return launch_t<1, 2, EPI_SILU_FRAG, false, true>(x_frag, w_frag, bias, y, M, N, K, ldy, waves, tpw, st);
+      return launch_t<1, 4, EPI_SILU_FRAG, false, true>(x_frag, w_frag, bias, y, M, N, K, ldy, waves, tpw, st);
+    }
+    return SSD_ERR_ARG;
+  }
   if (waves < 1 || waves > 16) return SSD_ERR_ARG;
   if (((N / 16) % nt) != 0) return SSD_ERR_ARG;
   if (epilogue == EPI_SILU_FRAG && (nt & 1)) return SSD_ERR_ARG;
@@ -441,6 +473,9 @@ static bool xs_cfg(int M, int N, int K, int epilogue, int* nt, int* waves, int* 
   if (epilogue != EPI_SILU_FRAG) return false;          // (the gate_up form; the QKV + RoPE consumer is ssd_gemm_fused_xs)
   ssd_pick_skinny_cfg(N / 16, K / 32, true, nt, waves, tpw);
   if (!(*nt == 2 || *nt == 4) || ((N / 16) % *nt) != 0 || *waves > 8) return false;
+  // the two-buffer ring: no K remainder and an even number of stages per tile for every wave
+  const int U = *nt == 4 ? 2 : 4, KT = K / 32;
+  if (KT % (*waves * U * 2) != 0 || !xsum_shape_ok(K, *waves)) return false;
   return (size_t)*waves * *nt * 64 * sizeof(f32x4_t) + xsum_lds_bytes(K, *waves) <= 160 * 1024;
 }
 

