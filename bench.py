@@ -208,26 +208,6 @@ def gemm_roofline(legs):
                  ("o", m.h * m.qn * 2, lambda li: m.launch_o(li, M)),
                  ("gate_up", 2 * m.I * m.h * 2, lambda li: m.launch_gate_up(li, M, gemm_only=True)),
                  ("down", m.h * m.I * 2, lambda li: m.launch_down(li, M))]
-        xs_forms = bool(getattr(m, "xsum", False)) and M <= 16 and not m.fusion_plan(M)[1] and not m.parts_plan(M)
-        if xs_forms:
-            # the forward at this row count runs the norm-carrying forms (csrc/xsum.h, HipDecoder._forward_xsum): those are the launches
-            # that are timed -- o_proj / down_proj with the residual add in their epilogue, gate_up / QKV with the RMSNorm in their x operand
-            from ssd_amd.hip import ops as H_
-            eps_ = m.cfg.rms_norm_eps
-
-            def wn(li, name):
-                return m.w[f"model.layers.{li}.{name}"]
-            kinds = [("qkv", m.qkv_n * m.h * 2, lambda li: H_.gemm_fused_xs(m.buf_x32, m.buf_gss, wn(li, "input_layernorm.weight"), eps_,
-                                                                            wn(li, "self_attn.qkv_proj.weight"), M, m.qkv_n, m.h,
-                                                                            positions=runner.d_pos, cos_sin=m.cos_sin, slots=runner.d_slots,
-                                                                            q_out=m.buf_q, k_cache=m.kv_cache[li, 0], v_cache=m.kv_cache[li, 1],
-                                                                            nh=m.nh, nkv=m.nkv, hd=m.hd, block_size=m.block_size)),
-                     ("o", m.h * m.qn * 2, lambda li: H_.gemm_res(m.buf_af, wn(li, "self_attn.o_proj.weight"), m.buf_res, m.buf_res, m.buf_x32,
-                                                                  m.buf_gss, M, m.h, m.qn)),
-                     ("gate_up", 2 * m.I * m.h * 2, lambda li: H_.gemm_xs(m.buf_x32, m.buf_gss, wn(li, "post_attention_layernorm.weight"), eps_,
-                                                                          wn(li, "mlp.gate_up_proj.weight"), m.buf_actf, M, 2 * m.I, m.h)),
-                     ("down", m.h * m.I * 2, lambda li: H_.gemm_res(m.buf_actf, wn(li, "mlp.down_proj.weight"), m.buf_res, m.buf_res, m.buf_x32,
-                                                                    m.buf_gss, M, m.h, m.I))]
         chain = bool(getattr(m, "chain_seg", False)) and M == 1
         if chain:
             # the single-token chain runs the layer's o_proj / gate_up / down_proj and the next layer's QKV as ONE resident launch

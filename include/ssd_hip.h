@@ -135,29 +135,6 @@ int ssd_gemm_fused_parts(const void* h_parts, int splits, const void* res_in, vo
                          const int64_t* positions, const float* cos_sin, const int32_t* slots, void* q_out, void* k_cache,
                          void* v_cache, int nh, int nkv, int hd, int block_size, int nt, int waves, void* stream);
 
-/* "xsum" (round 6, csrc/xsum.h): RMSDNorm.forward's residual add + RMSNorm (ssd/layers/layernorm.py:64-88) between a row-parallel
- * projection (o_proj / down_proj, ssd/layers/linear.py:186-199) and the next column-parallel one (gate_up, linear.py:97-98 +
- * activation.py:11-14; or the next layer's QKV + rotary_emb + store_kvcache) carried BY those two GEMMs -- LlamaDecoderLayer.forward,
- * ssd/models/llama3.py:185-199, as five launches per layer instead of seven, with no cross-workgroup protocol.  Decode / verify rows
- * (M <= 16).  Same rounding points as ssd_rmsnorm; the fp32 summation order of the row's sum of squares differs (tolerance-equal).
- *   ssd_gemm_wf_res     y = x . W^T rounded to bf16 as F.linear stores it, x32 = y + res_in (fp32); writes res_out = bf16(x32) rows
- *                       [M][N] (may alias res_in), x32_frag (fp32, fragment-major [16][N]: 16 * N floats) and group_ss ([N / 16][16]
- *                       floats: the sum of squares of each 16-column group of each row).
- *   ssd_gemm_wf_xs      ssd_gemm_wf(epilogue 1 = SiLU * mul -> fragment-major) whose x operand is bf16((x32 * rs) * norm_w) formed on
- *                       the fly, rs = rsqrt(sum of the row's group sums / K + eps).
- *   ssd_gemm_fused_xs   the same x operand for ssd_gemm_fused's epilogue 3 (RoPE + paged KV store).
- *   ssd_*_ok            host-side predicates: SSD_OK where the default decomposition for the shape has the form. */
-int ssd_gemm_wf_res_ok(int M, int N, int K);
-int ssd_gemm_wf_res(const void* x_frag, const void* w_frag, const void* bias, const void* res_in, void* res_out, void* x32_frag,
-                    void* group_ss, int M, int N, int K, void* stream);
-int ssd_gemm_wf_xs_ok(int M, int N, int K, int epilogue);
-int ssd_gemm_wf_xs(const void* x32_frag, const void* group_ss, const void* norm_w, float eps, const void* w_frag, const void* bias,
-                   void* y, int M, int N, int K, int ldy, int epilogue, void* stream);
-int ssd_gemm_fused_xs_ok(int M, int N, int K);
-int ssd_gemm_fused_xs(const void* x32_frag, const void* group_ss, const void* norm_w, float eps, const void* w_frag, const void* bias,
-                      int M, int N, int K, const int64_t* positions, const float* cos_sin, const int32_t* slots, void* q_out,
-                      void* k_cache, void* v_cache, int nh, int nkv, int hd, int block_size, void* stream);
-
 /* (RMSHeadNorm q/k, Qwen3: ssd/models/qwen3.py:96-104) + RotaryEmbedding.forward
  * (ssd/layers/rotary_embedding.py:40-60) + store_kvcache (ssd/layers/attention.py:10-41).
  * qkv_rows [T][(nh+2nkv)*hd]; cos_sin fp32 [max_pos][hd] (cos || sin); q_norm_w/k_norm_w bf16[hd] or NULL. */

@@ -13,7 +13,8 @@
 extern "C" {
 #endif
 
-/* ssd_gemm_wf with an explicit decomposition: nt = 16-row groups per workgroup (1,2,4), waves = K-split (1..16). */
+/* ssd_gemm_wf with an explicit decomposition: nt = 16-row groups per workgroup (1,2,4), waves = K-split (1..16), bits 8..15 of waves =
+ * consecutive tiles per workgroup; bit 8 of nt = the DEEP form (twice the k-tiles per stage; M <= 16, <= 8 waves, nt 2 / 4, epilogue 0 / 1). */
 int ssd_gemm_wf_cfg(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N, int K, int ldy,
                     int epilogue, int nt, int waves, void* stream);
 

@@ -1,6 +1,8 @@
-"""Round 6: the norm-carrying GEMM forms (csrc/xsum.h) against the launches they replace, at the 70B verify's shapes (M = 8).
-Each kind is a hipGraph of 24 launches rotating through 3 copies of its weights (nothing cache-resident); per-launch time = graph time / 24.
-    python profiles/micro/xsum_probe.py"""
+"""Round 6: the 70B verify's skinny GEMMs (M = 8) -- the default dispatch, explicit decompositions and the DEEP form (twice the k-tiles
+per stage at <= 8 waves, csrc/gemm.hip).  Each kind is a hipGraph of 24 launches rotating through 3 copies of its weights (nothing
+cache-resident); per-launch time = graph time / 24.  (Until commit 2e5cd65 this probe also timed the norm-carrying "xsum" forms: their
+results are profiles/r06_xsum_probe_v1..v3*.txt, the code profiles/r06_xsum_v3.patch.)
+    python profiles/micro/deep_probe.py"""
 import os
 import sys
 
@@ -48,9 +50,6 @@ def main():
     y = torch.zeros(M, h, dtype=BF, device="cuda")
     res = torch.randn(M, h, device="cuda").to(BF)
     nw = torch.ones(h, dtype=BF, device="cuda")
-    x32 = torch.zeros(16 * h, dtype=torch.float32, device="cuda")
-    gss = torch.zeros(h, dtype=torch.float32, device="cuda")
-    H.gemm_res(a_f, wo[0], res, res, x32, gss, M, h, qn)          # valid x32 / group sums for the consumers
     pos = torch.arange(100, 100 + M, dtype=torch.int64, device="cuda")
     cs = torch.randn(1024, hd, device="cuda")
     slots = torch.arange(M, dtype=torch.int32, device="cuda")
@@ -59,15 +58,11 @@ def main():
     vc = torch.zeros_like(kc)
     rope = dict(positions=pos, cos_sin=cs, slots=slots, q_out=q_out, k_cache=kc, v_cache=vc, nh=nh, nkv=nkv, hd=hd, block_size=256)
     t = {}
-    t["o_proj rows"] = timed(lambda i: H.gemm(a_f, wo[i], y, M, h, qn, h))
-    t["o_proj + add (res)"] = timed(lambda i: H.gemm_res(a_f, wo[i], res, res, x32, gss, M, h, qn))
-    t["down rows"] = timed(lambda i: H.gemm(act_f, wd[i], y, M, h, I, h))
-    t["down + add (res)"] = timed(lambda i: H.gemm_res(act_f, wd[i], res, res, x32, gss, M, h, I))
+    t["o_proj rows (default dispatch)"] = timed(lambda i: H.gemm(a_f, wo[i], y, M, h, qn, h))
+    t["down rows (default dispatch)"] = timed(lambda i: H.gemm(act_f, wd[i], y, M, h, I, h))
     t["rmsnorm"] = timed(lambda i: H.rmsnorm(y, nw, 1e-5, M, h, res_in=res, res_out=res, out_frag=xf))
-    t["gate_up"] = timed(lambda i: H.gemm(xf, wgu[i], act_f, M, 2 * I, h, 0, epilogue=H.EPI_SILU_FRAG))
-    t["gate_up xs"] = timed(lambda i: H.gemm_xs(x32, gss, nw, 1e-5, wgu[i], act_f, M, 2 * I, h))
+    t["gate_up (default dispatch)"] = timed(lambda i: H.gemm(xf, wgu[i], act_f, M, 2 * I, h, 0, epilogue=H.EPI_SILU_FRAG))
     t["qkv+rope"] = timed(lambda i: H.gemm_fused(wq[i], M, N_QKV, h, H.FEPI_QKV_ROPE, x_frag=xf, **rope))
-    t["qkv+rope xs"] = timed(lambda i: H.gemm_fused_xs(x32, gss, nw, 1e-5, wq[i], M, N_QKV, h, **rope))
 
     # gate_up decompositions: the default (nt 4, 8 waves, 4 tiles per workgroup: 224 workgroups) against 256-workgroup forms
     for nt, wv, tpw in ((4, 8, 4), (2, 8, 7), (2, 16, 7), (4, 16, 4), (4, 8, 7)):
@@ -95,13 +90,7 @@ def main():
         H.rmsnorm(y, nw, 1e-5, M, h, res_in=res, res_out=res, out_frag=xf)
         H.gemm_fused(wq[i], M, N_QKV, h, H.FEPI_QKV_ROPE, x_frag=xf, **rope)
 
-    def xs(i):
-        H.gemm_res(a_f, wo[i], res, res, x32, gss, M, h, qn)
-        H.gemm_xs(x32, gss, nw, 1e-5, wgu[i], act_f, M, 2 * I, h)
-        H.gemm_res(act_f, wd[i], res, res, x32, gss, M, h, I)
-        H.gemm_fused_xs(x32, gss, nw, 1e-5, wq[i], M, N_QKV, h, **rope)
     t["LAYER minus attention, separate (6 launches)"] = timed(sep)
-    t["LAYER minus attention, xsum (4 launches)"] = timed(xs)
     for k, v in t.items():
         print(f"{k:48s} {v:8.2f} us")
 

@@ -12,11 +12,8 @@
 //    combine through LDS in a fixed order (deterministic, no atomics, no inter-workgroup traffic).
 //  * Weight loads are non-temporal (each byte is read exactly once per forward).
 #include "common.h"
-#include "xsum.h"
 
-// EPI_ROWS_RES (round 6, xsum.h): the row-parallel projection's epilogue also performs the residual add that follows it and leaves
-// what the NEXT GEMM needs to apply the RMSNorm itself (fp32 x, per-group sums of squares) -- no bf16 rows, no norm launch.
-enum { EPI_ROWS = 0, EPI_SILU_FRAG = 1, EPI_ROWS_F32 = 2, EPI_ROWS_ARGMAX = 3, EPI_ROWS_RES = 4 };
+enum { EPI_ROWS = 0, EPI_SILU_FRAG = 1, EPI_ROWS_F32 = 2, EPI_ROWS_ARGMAX = 3 };
 
 // EPI_ROWS_ARGMAX (the LM head on the greedy path): bf16 rows as EPI_ROWS, plus every workgroup's own (max value, lowest
 // index) of each token row over the features it produced -- compared on the bf16-ROUNDED values, i.e. exactly what an
@@ -36,24 +33,18 @@ struct Stage {
   u32x4_t a[NT];
   u32x4_t b[MT];
 };
-template <int NT>
-struct StageX {                    // XS: a stage IN FLIGHT carries the B operand as fp32 x (32 bytes per lane); it becomes x^ (a Stage)
-  u32x4_t a[NT];                   // when the stage is adopted as the current one
-  f32x4_t xr[2];
-};
 
-// XS (MT = 1): x comes as the producer's fp32 x + group sums of squares (xsum.h); the RMSNorm is applied while the B operand is formed.
-// (XS variants are launched with <= 8 waves -- the tuned decomposition of every gate_up shape -- so they may use up to 256 VGPRs: the
-//  fp32 x of the stages in flight would not fit the 128 of a 16-wave workgroup.)
 // DEEP (round 6): twice the k-tiles per stage -- twice the bytes in flight per wave -- for launches of <= 8 waves per workgroup, which
 // may use 256 VGPRs (the 128-VGPR ceiling of the 16-wave form is what set the depth of the plain kernel; a weight-streaming wave's
-// throughput is its bytes in flight over the memory latency).
-template <int MT, int NT, int EPI, bool XS = false, bool DEEP = false>
-__global__ void __launch_bounds__((XS || DEEP) ? 512 : 1024)
+// throughput is its bytes in flight over the memory latency).  Same rounding points; the k-tiles are dealt to the waves in groups
+// twice as large, so the fp32 summation order differs from the plain form (tolerance-equal).  Measured at the 70B verify's shapes,
+// same box, same run (profiles/r06_xsum_probe_v3_hwcvt_and_deep.txt): gate_up 149.3 -> 147.5 us (145.7 as 256 workgroups of 2 row
+// groups x 7 tiles), o_proj 21.9 -> 21.5, down_proj 74.1 -> 72.9.
+template <int MT, int NT, int EPI, bool DEEP = false>
+__global__ void __launch_bounds__(DEEP ? 512 : 1024)
 gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
                const bf16_t* __restrict__ bias, void* __restrict__ Yv, int M, int N, int K, int ldy, int tpw,
-               float* __restrict__ part_val, int* __restrict__ part_idx, int part_stride, const XsumIn xin, const XsumOut xout) {
-  static_assert(!XS || MT == 1, "the fp32-x operand form exists for one token tile");
+               float* __restrict__ part_val, int* __restrict__ part_idx, int part_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KTS = EPI == EPI_SILU_FRAG ? 8 : 9;        // trace slot (profiling builds only)
   KTRACE(KTS, 0);
@@ -100,48 +91,7 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
       }
     }
   };
-  // XS: TWO stages in flight (a ring of two register buffers, as gemm_fused.hip), each carrying the B operand as fp32 x; a stage is
-  // consumed in place (x^ = bf16((x32 * rs) * w), norm weights from LDS) and its buffer refilled with the stage two ahead.  The ring
-  // runs over the FLAT sequence of this wave's stages across the workgroup's tiles (the next tile's first two stages are in flight
-  // during the combine of the current one).  Host-checked: no K remainder, an even number of stages per tile (xs_cfg).
-  StageX<NT> nx0[XS ? U : 1], nx1[XS ? U : 1];
-  float xs_rs = 0.f;
-  const u32x4_t* xs_w = nullptr;
-  const u32x4_t* iwp = wp;              // issue cursor: weight pointer of the tile being requested ...
-  int ikt = kt0;                        // ... and its k-tile
-  int ileft = 0;                        // stages still to request
-  auto issue_now = [&](StageX<NT>(&d)[XS ? U : 1]) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        d[XS ? u : 0].a[nt] = __builtin_nontemporal_load(iwp + nt * wstride + ((size_t)(ikt + u) << 6));
-      xsum_load(xin.x32f, ((size_t)(ikt + u) << 6) + lane, (lane & 15) < M, d[XS ? u : 0].xr);
-    }
-    --ileft;
-    ikt += kstep;
-    if (ikt >= kmain) { ikt = kt0; iwp += (size_t)NT * wstride; }
-  };
-  auto issue = [&](StageX<NT>(&d)[XS ? U : 1]) {
-    if (ileft > 0) issue_now(d);
-  };
-  if constexpr (XS) {
-    XsumPre pre;
-    xsum_issue(xin, K, wave, nw, lane, pre);            // the small loads go FIRST: a CU returns its loads in order
-    const int spt = kt0 < kmain ? (kmain - kt0 + kstep - 1) / kstep : 0;     // stages per tile of this wave
-    ileft = spt * max(0, t_end - t_begin);
-    // (unconditional: every workgroup has a tile and every wave >= 2 stages per tile, host-checked -- a branch here would make the
-    //  compiler's wait for the small loads above a wait for these weight loads too: it must assume the path that issued none)
-    issue_now(nx0);
-    issue_now(nx1);
-    char* xl = smem + (size_t)nw * NT * MT * 64 * sizeof(f32x4_t);
-    u32x4_t* wl = reinterpret_cast<u32x4_t*>(xl);
-    xs_rs = xsum_finish(xin, pre, K, wl, reinterpret_cast<float*>(xl + (size_t)K * 2), wave, nw, lane);
-    if ((lane & 15) >= M) xs_rs = 0.f;             // padding token rows: x^ = 0
-    xs_w = wl + (lane >> 4);
-  } else {
-    if (t_begin < t_end && kt0 < kmain) load(cur, kt0);
-  }
+  if (t_begin < t_end && kt0 < kmain) load(cur, kt0);
   ArgPart run[MT];          // EPI_ROWS_ARGMAX: this wave's best candidate per token row so far (identical in the 4 lanes of a row)
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) run[mt] = ArgPart{-INFINITY, 0x7fffffff};
@@ -164,22 +114,6 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
   };
 
   int kt = kt0;
-  if constexpr (XS) {
-    auto consume = [&](StageX<NT>(&d)[XS ? U : 1], int ktc) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const u32x4_t b = xsum_bfrag(d[XS ? u : 0].xr, xs_rs, xs_w[(ktc + u) * 4]);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt][0] = mfma16(d[XS ? u : 0].a[nt], b, acc[nt][0]);
-      }
-    };
-    for (; kt < kmain; kt += 2 * kstep) {
-      consume(nx0, kt);
-      issue(nx0);
-      consume(nx1, kt + kstep);
-      issue(nx1);
-    }
-  } else {
   if (kt < kmain) {
     for (; kt + kstep < kmain; kt += kstep) {
       load(nxt, kt + kstep);
@@ -189,7 +123,6 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
     }
     compute(cur);
   }
-  }
   for (kt = (wave == nw - 1) ? kmain : KT; kt < KT; ++kt) {  // K remainder (< U tiles): last wave
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -197,13 +130,7 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         u32x4_t b = {0u, 0u, 0u, 0u};
-        if constexpr (XS) {
-          f32x4_t xr[2];
-          xsum_load(xin.x32f, ((size_t)kt << 6) + lane, (lane & 15) < M, xr);
-          b = xsum_bfrag(xr, xs_rs, xs_w[kt * 4]);
-        } else {
-          if (mt * 16 + (lane & 15) < M) b = xp[mt * xstride + ((size_t)kt << 6)];
-        }
+        if (mt * 16 + (lane & 15) < M) b = xp[mt * xstride + ((size_t)kt << 6)];
         acc[nt][mt] = mfma16(a, b, acc[nt][mt]);
       }
     }
@@ -211,9 +138,7 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
 
   // next tile: advance the weight pointer and put its first loads in flight before the combine
   wp += (size_t)NT * wstride;
-  if constexpr (!XS) {          // (XS: the ring has the next tile's first two stages in flight already)
-    if (tile + 1 < t_end && kt0 < kmain) load(cur, kt0);
-  }
+  if (tile + 1 < t_end && kt0 < kmain) load(cur, kt0);
 
   // ---- cross-wave split-K combine through LDS, fixed order ----
   f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);  // [nw][NT*MT][64]
@@ -261,19 +186,15 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
   } else {
     for (int item = wave; item < ITEMS; item += nw) {
       const int nt = item / MT, mt = item % MT;
-      const int m = mt * 16 + mcol;
-      const int n = (tile0 + nt) * 16 + nrow;
-      u32x2_t rv = {0u, 0u};
-      if (EPI == EPI_ROWS_RES && m < M) rv = *reinterpret_cast<const u32x2_t*>(xout.res_in + (size_t)m * N + n);   // in flight across the combine
       f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
       for (int w = 0; w < nw; ++w) s += red[((w * ITEMS) + item) * 64 + lane];
+      const int m = mt * 16 + mcol;
+      const int n = (tile0 + nt) * 16 + nrow;
       if (bias) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) s[r] += bf2f(bias[n + r]);
       }
-      if (EPI == EPI_ROWS_RES) {
-        xsum_epilogue(xout, s, rv, m, n, M, N, lane);
-      } else if (m < M) {
+      if (m < M) {
         if (EPI == EPI_ROWS_F32) {
           *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(Yv) + (size_t)m * ldy + n) = s;
         } else {
@@ -326,26 +247,23 @@ gemm_wf_kernel(const u32x4_t* __restrict__ Wf, const u32x4_t* __restrict__ Xf,
 // Launch heuristics.  waves/block * blocks should put >= ~8-16 waves on each of the 256 CUs while
 // each wave still streams a few KiB contiguously.
 // ---------------------------------------------------------------------------------------------
-template <int MT, int NT, int EPI, bool XS = false, bool DEEP = false>
+template <int MT, int NT, int EPI, bool DEEP = false>
 static int launch_t(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int ldy,
-                    int waves, int tpw, hipStream_t st, float* part_val = nullptr, int* part_idx = nullptr, int part_stride = 0,
-                    const XsumIn xin = XsumIn{}, const XsumOut xout = XsumOut{}) {
+                    int waves, int tpw, hipStream_t st, float* part_val = nullptr, int* part_idx = nullptr, int part_stride = 0) {
   const int ntiles = (N / 16) / NT;
   if (tpw < 1) tpw = 1;
   const int blocks = (ntiles + tpw - 1) / tpw;
   if (EPI == EPI_ROWS_ARGMAX && (!part_val || !part_idx || part_stride < blocks)) return SSD_ERR_ARG;
   size_t lds = (size_t)waves * NT * MT * 64 * sizeof(f32x4_t);
   if (EPI == EPI_ROWS_ARGMAX) lds += (size_t)waves * MT * 16 * sizeof(ArgPart);      // per-wave argmax candidates behind the combine area
-  if (XS) lds += xsum_lds_bytes(K, waves);
-  if (lds > 160 * 1024) return SSD_ERR_SHAPE;
-  if ((XS || DEEP) && waves > 8) return SSD_ERR_ARG;
-  auto kern = gemm_wf_kernel<MT, NT, EPI, XS, DEEP>;
+  if (DEEP && waves > 8) return SSD_ERR_ARG;
+  auto kern = gemm_wf_kernel<MT, NT, EPI, DEEP>;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return SSD_ERR_LAUNCH;
   }
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, st, (const u32x4_t*)w, (const u32x4_t*)x,
-                     (const bf16_t*)bias, y, M, N, K, ldy, tpw, part_val, part_idx, part_stride, xin, xout);
+                     (const bf16_t*)bias, y, M, N, K, ldy, tpw, part_val, part_idx, part_stride);
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
@@ -377,12 +295,12 @@ extern "C" int ssd_gemm_wf_cfg(const void* x_frag, const void* w_frag, const voi
     if (M > 16 || waves > 8 || (nt != 2 && nt != 4) || ((N / 16) % nt) != 0) return SSD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (epilogue == EPI_ROWS) {
-      if (nt == 2) return launch_t<1, 2, EPI_ROWS, false, true>(x_frag, w_frag, bias, y, M, N, K, ldy, waves, tpw, st);
-      return launch_t<1, 4, EPI_ROWS, false, true>(x_frag, w_frag, bias, y, M, N, K, ldy, waves, tpw, st);
+      if (nt == 2) return launch_t<1, 2, EPI_ROWS, true>(x_frag, w_frag, bias, y, M, N, K, ldy, waves, tpw, st);
+      return launch_t<1, 4, EPI_ROWS, true>(x_frag, w_frag, bias, y, M, N, K, ldy, waves, tpw, st);
     }
     if (epilogue == EPI_SILU_FRAG) {
-      if (nt == 2) return launch_t<1, 2, EPI_SILU_FRAG, false, true>(x_frag, w_frag, bias, y, M, N, K, ldy, waves, tpw, st);
-      return launch_t<1, 4, EPI_SILU_FRAG, false, true>(x_frag, w_frag, bias, y, M, N, K, ldy, waves, tpw, st);
+      if (nt == 2) return launch_t<1, 2, EPI_SILU_FRAG, true>(x_frag, w_frag, bias, y, M, N, K, ldy, waves, tpw, st);
+      return launch_t<1, 4, EPI_SILU_FRAG, true>(x_frag, w_frag, bias, y, M, N, K, ldy, waves, tpw, st);
     }
     return SSD_ERR_ARG;
   }
@@ -413,6 +331,16 @@ extern "C" int ssd_gemm_wf(const void* x_frag, const void* w_frag, const void* b
   if (mt == 1) {       // decode / verify rows: the tuned table
     int nt1, waves1, tpw1;
     ssd_pick_skinny_cfg(groups, KT, epilogue == EPI_SILU_FRAG, &nt1, &waves1, &tpw1);
+    // the 70B-class matrices (very long K, >= 512 row groups, 8 waves per workgroup): the DEEP form, measured 1-2.4 % faster on each
+    // (round 6); gate_up additionally as exactly 256 workgroups of 2 row groups x (groups / 512) consecutive tiles where that divides
+    // (only the classes that were measured: N = 8192 rows matrices with K >= 8192 -- o_proj, down_proj -- and the gate_up whose row
+    //  groups are a multiple of 512; tensor-parallel shards and the other models keep the plain form)
+    const bool deep_rows = epilogue == EPI_ROWS && groups == 512 && nt1 == 2;
+    const bool deep_silu = epilogue == EPI_SILU_FRAG && nt1 == 4 && groups % 512 == 0 && groups / 512 <= 8;
+    if (waves1 == 8 && KT >= 256 && (deep_rows || deep_silu)) {
+      if (deep_silu) { nt1 = 2; tpw1 = groups / 512; }
+      return ssd_gemm_wf_cfg(x_frag, w_frag, bias, y, M, N, K, ldy, epilogue, nt1 | 256, waves1 | (tpw1 << 8), stream);
+    }
     // one row group per workgroup, bf16 rows: the single-buffered kernel of gemm_sk.hip (fewer registers -> more resident
     // workgroups) measured 5-17 % faster than the register double buffer below (profiles/micro/splitk_probe.py)
     if (nt1 == 1 && tpw1 == 1 && epilogue == EPI_ROWS)
@@ -436,64 +364,6 @@ extern "C" int ssd_gemm_wf(const void* x_frag, const void* w_frag, const void* b
   return ssd_gemm_wf_cfg(x_frag, w_frag, bias, y, M, N, K, ldy, epilogue, nt, waves, stream);
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------------
-// xsum (xsum.h): the residual add + RMSNorm between a row-parallel projection and the next column-parallel one, carried by the
-// two GEMMs.  Decode / verify rows only (M <= 16), the shapes whose default decomposition is the register-streaming kernel above.
-//   ssd_gemm_wf_res : y = x . W^T as ssd_gemm_wf(EPI_ROWS) would store it (bf16-rounded), then x32 = y + res_in; writes
-//                     res_out = bf16(x32) [M][N], x32 (fp32 fragment-major [16][N]) and the group sums of squares [N / 16][16].
-//   ssd_gemm_wf_xs  : ssd_gemm_wf(x^ = RMSNorm(x32) * norm_w, ...) with x^ formed on the fly from the three arrays above.
-// ssd_gemm_wf_res_ok / ssd_gemm_wf_xs_ok: host-side predicates (SSD_OK when the default launch for the shape has the form).
-// ---------------------------------------------------------------------------------------------------------------------
-static bool res_cfg(int M, int N, int K, int* nt, int* waves, int* tpw) {
-  if (M <= 0 || M > 16 || (N & 15) || (K & 31) || N <= 0 || K <= 0) return false;
-  ssd_pick_skinny_cfg(N / 16, K / 32, false, nt, waves, tpw);
-  // (nt = 1 shapes run on gemm_sk.hip's single-buffered kernel by default: measured faster there, not covered here)
-  return (*nt == 2 || *nt == 4) && ((N / 16) % *nt) == 0;
-}
-
-extern "C" int ssd_gemm_wf_res_ok(int M, int N, int K) {
-  int nt, waves, tpw;
-  return res_cfg(M, N, K, &nt, &waves, &tpw) ? SSD_OK : SSD_ERR_SHAPE;
-}
-
-extern "C" int ssd_gemm_wf_res(const void* x_frag, const void* w_frag, const void* bias, const void* res_in, void* res_out,
-                               void* x32_frag, void* group_ss, int M, int N, int K, void* stream) {
-  int nt, waves, tpw;
-  if (!res_cfg(M, N, K, &nt, &waves, &tpw)) return SSD_ERR_SHAPE;
-  if (!x_frag || !w_frag || !res_in || !res_out || !x32_frag || !group_ss) return SSD_ERR_ARG;
-  const XsumOut xo{(const bf16_t*)res_in, (bf16_t*)res_out, (float*)x32_frag, (float*)group_ss};
-  hipStream_t st = (hipStream_t)stream;
-  if (nt == 2) return launch_t<1, 2, EPI_ROWS_RES>(x_frag, w_frag, bias, nullptr, M, N, K, N, waves, tpw, st, nullptr, nullptr, 0, XsumIn{}, xo);
-  return launch_t<1, 4, EPI_ROWS_RES>(x_frag, w_frag, bias, nullptr, M, N, K, N, waves, tpw, st, nullptr, nullptr, 0, XsumIn{}, xo);
-}
-
-static bool xs_cfg(int M, int N, int K, int epilogue, int* nt, int* waves, int* tpw) {
-  if (M <= 0 || M > 16 || (N & 15) || (K & 31) || N <= 0 || K <= 0) return false;
-  if (epilogue != EPI_SILU_FRAG) return false;          // (the gate_up form; the QKV + RoPE consumer is ssd_gemm_fused_xs)
-  ssd_pick_skinny_cfg(N / 16, K / 32, true, nt, waves, tpw);
-  if (!(*nt == 2 || *nt == 4) || ((N / 16) % *nt) != 0 || *waves > 8) return false;
-  // the two-buffer ring: no K remainder and an even number of stages per tile for every wave
-  const int U = *nt == 4 ? 2 : 4, KT = K / 32;
-  if (KT % (*waves * U * 2) != 0 || !xsum_shape_ok(K, *waves)) return false;
-  return (size_t)*waves * *nt * 64 * sizeof(f32x4_t) + xsum_lds_bytes(K, *waves) <= 160 * 1024;
-}
-
-extern "C" int ssd_gemm_wf_xs_ok(int M, int N, int K, int epilogue) {
-  int nt, waves, tpw;
-  return xs_cfg(M, N, K, epilogue, &nt, &waves, &tpw) ? SSD_OK : SSD_ERR_SHAPE;
-}
-
-extern "C" int ssd_gemm_wf_xs(const void* x32_frag, const void* group_ss, const void* norm_w, float eps, const void* w_frag,
-                              const void* bias, void* y, int M, int N, int K, int ldy, int epilogue, void* stream) {
-  int nt, waves, tpw;
-  if (!xs_cfg(M, N, K, epilogue, &nt, &waves, &tpw)) return SSD_ERR_SHAPE;
-  if (!x32_frag || !group_ss || !norm_w || !w_frag || !y) return SSD_ERR_ARG;
-  const XsumIn xi{(const float*)x32_frag, (const float*)group_ss, (const bf16_t*)norm_w, eps};
-  hipStream_t st = (hipStream_t)stream;
-  if (nt == 2) return launch_t<1, 2, EPI_SILU_FRAG, true>(nullptr, w_frag, bias, y, M, N, K, ldy, waves, tpw, st, nullptr, nullptr, 0, xi);
-  return launch_t<1, 4, EPI_SILU_FRAG, true>(nullptr, w_frag, bias, y, M, N, K, ldy, waves, tpw, st, nullptr, nullptr, 0, xi);
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // LM head on the greedy path: logits rows + per-workgroup argmax candidates in one launch (EPI_ROWS_ARGMAX above).

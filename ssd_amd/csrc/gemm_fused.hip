@@ -19,7 +19,6 @@
 // group of a q/k head holds dims [d0..d0+7] and [d0+hd/2..d0+hd/2+7]: the two halves of a rotation pair sit in
 // lanes l and l^32 of the accumulator and are exchanged with one shuffle.
 #include "common.h"
-#include "xsum.h"
 #include <type_traits>
 
 enum { FEPI_ROWS = 0, FEPI_SILU_FRAG = 1, FEPI_QKV_ROPE = 3 };
@@ -45,7 +44,6 @@ struct FusedParams {
   int M, N, K, ldy;
   int nh, nkv, hd, bs;
   int scratch_bytes;        // LDS bytes in front of the x^ image (split-K combine area, also the prologue scratch)
-  XsumIn xs;                // XS (round 6, xsum.h): x as the producer GEMM's fp32 x + group sums of squares; the norm rides the B operand
 };
 
 // 8-element chunks of (h + res) a thread may hold in registers during the prologue: template parameter MAXC (1 when M*K/8
@@ -79,10 +77,8 @@ __device__ __forceinline__ void fused_load_x32(const FusedParams& p, int mm, int
   }
 }
 
-// XS: launched with <= 8 waves (the fp32 x of the stages in flight needs more than the 128 VGPRs of a 16-wave workgroup)
-template <int NT, int EPI, bool XNORM, int FUSED_MAXC, bool XS = false>
-__global__ void __launch_bounds__(XS ? 512 : 1024) gemm_fused_kernel(const FusedParams p) {
-  static_assert(!(XS && XNORM), "one x source");
+template <int NT, int EPI, bool XNORM, int FUSED_MAXC>
+__global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KTS = !XNORM ? 2 : (EPI == FEPI_QKV_ROPE ? 0 : 1);      // trace slot (profiling builds only)
   KTRACE(KTS, 0);
@@ -105,18 +101,13 @@ __global__ void __launch_bounds__(XS ? 512 : 1024) gemm_fused_kernel(const Fused
   constexpr int U = (NT <= 2) ? 4 : 2;
   u32x4_t wa[2][U][NT];
   u32x4_t xg[2][U];       // fragment-major x travels with the weights when there is no prologue
-  f32x4_t xr[XS ? 2 : 1][XS ? U : 1][2];      // XS: fp32 x travels with the weights
-  float xs_rs = 0.f;
-  const u32x4_t* xs_w = nullptr;
   auto loadw = [&](int buf, int kt) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         wa[buf][u][nt] = __builtin_nontemporal_load(wp + nt * wstride + ((size_t)(kt + u) << 6));
-      if constexpr (XS) {
-        xsum_load(p.xs.x32f, ((size_t)(kt + u) << 6) + lane, mcol < M, xr[XS ? buf : 0][XS ? u : 0]);
-      } else if (!XNORM) {     // padding token rows (>= M) are not loaded: halves the B-operand bytes at M = 7
+      if (!XNORM) {     // padding token rows (>= M) are not loaded: halves the B-operand bytes at M = 7
         u32x4_t b = {0u, 0u, 0u, 0u};
         if (mcol < M) b = p.Xf[((size_t)(kt + u) << 6) + lane];
         xg[buf][u] = b;
@@ -131,15 +122,8 @@ __global__ void __launch_bounds__(XS ? 512 : 1024) gemm_fused_kernel(const Fused
   const int nmain = ngroups > wave ? (ngroups - wave + nw - 1) / nw : 0;   // groups of this wave
   // the first TWO groups of weight tiles fly while the norm prologue runs (for the 1B draft that is the whole K range:
   // one HBM round trip per wave; a kernel this short is a latency chain)
-  XsumPre xpre;
-  if constexpr (XS) xsum_issue(p.xs, K, wave, nw, lane, xpre);        // the prologue's small loads go FIRST (a CU returns its loads in order)
-  if constexpr (XS) {          // unconditional (>= 2 groups per wave, host-checked): no branch between the small loads and their use
-    loadw(0, kt0);
-    loadw(1, kt0 + kstep);
-  } else {
-    if (nmain > 0) loadw(0, kt0);
-    if (nmain > 1) loadw(1, kt0 + kstep);
-  }
+  if (nmain > 0) loadw(0, kt0);
+  if (nmain > 1) loadw(1, kt0 + kstep);
   // RoPE epilogue operands of the wave that will own row group `wave` (positions -> cos/sin rows -> slot: a chain of
   // dependent L2 round trips if left to the epilogue), fetched now, behind the weight stream
   float pre_cs[8];
@@ -159,12 +143,6 @@ __global__ void __launch_bounds__(XS ? 512 : 1024) gemm_fused_kernel(const Fused
     pre_ok = true;
   }
   KTRACE(KTS, 1);
-  if constexpr (XS) {     // row scale + norm weights (LDS behind the combine area) while two groups of weight tiles fly: one barrier
-    u32x4_t* wl = reinterpret_cast<u32x4_t*>(smem + p.scratch_bytes);
-    xs_rs = xsum_finish(p.xs, xpre, K, wl, reinterpret_cast<float*>(smem + p.scratch_bytes + (size_t)K * 2), wave, nw, lane);
-    if (mcol >= M) xs_rs = 0.f;
-    xs_w = wl + q4;
-  }
   if (XNORM) {
     // ---- prologue: x32 = h + res kept in registers; per-chunk sums of squares -> per-row rs (fixed order) ->
     //      x^ = bf16(x32 * rs * w) into the LDS image; residual slice written to res_out ----
@@ -256,7 +234,6 @@ __global__ void __launch_bounds__(XS ? 512 : 1024) gemm_fused_kernel(const Fused
   }
 
   auto xfrag = [&](int buf, int u, int kt) -> u32x4_t {
-    if constexpr (XS) return xsum_bfrag(xr[XS ? buf : 0][XS ? u : 0], xs_rs, xs_w[kt * 4]);
     if (!XNORM) return xg[buf][u];
     u32x4_t o = {0u, 0u, 0u, 0u};
     if (mcol < M) o = xlds[(kt * 4 + q4) * M + mcol];
@@ -284,8 +261,7 @@ __global__ void __launch_bounds__(XS ? 512 : 1024) gemm_fused_kernel(const Fused
   }
   for (kt = (wave == nw - 1) ? ngroups * U : KT; kt < KT; ++kt) {
     u32x4_t xb;
-    if constexpr (XS) { f32x4_t t2[2]; xsum_load(p.xs.x32f, ((size_t)kt << 6) + lane, mcol < M, t2); xb = xsum_bfrag(t2, xs_rs, xs_w[kt * 4]); }
-    else if (!XNORM) { xb = u32x4_t{0u, 0u, 0u, 0u}; if (mcol < M) xb = p.Xf[((size_t)kt << 6) + lane]; }
+    if (!XNORM) { xb = u32x4_t{0u, 0u, 0u, 0u}; if (mcol < M) xb = p.Xf[((size_t)kt << 6) + lane]; }
     else { xb = u32x4_t{0u, 0u, 0u, 0u}; if (mcol < M) xb = xlds[(kt * 4 + q4) * M + mcol]; }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -564,22 +540,6 @@ static int launch_fused_c(const FusedParams& p, int waves, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
-template <int NT, int EPI>
-static int launch_fused_xs(const FusedParams& p, int waves, hipStream_t st) {
-  const int blocks = (p.N / 16) / NT;
-  size_t lds = (size_t)waves * NT * 64 * sizeof(f32x4_t);
-  FusedParams q = p;
-  q.scratch_bytes = (int)lds;
-  lds += xsum_lds_bytes(p.K, waves);
-  if (lds > 160 * 1024 || waves > 8) return SSD_ERR_SHAPE;
-  auto kern = gemm_fused_kernel<NT, EPI, false, 1, true>;
-  if (lds > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return SSD_ERR_LAUNCH;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, st, q);
-  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
-}
-
 template <int NT, int EPI, bool XNORM>
 static int launch_fused(const FusedParams& p, int waves, hipStream_t st) {
   if constexpr (XNORM) {
@@ -668,42 +628,6 @@ extern "C" int ssd_gemm_fused_parts(const void* h_parts, int splits, const void*
                                     void* stream) {
   return fused_impl(nullptr, nullptr, (const float*)h_parts, splits, res_in, res_out, norm_w, eps, w_frag, bias, M, N, K, epilogue,
                     y, ldy, positions, cos_sin, slots, q_out, k_cache, v_cache, nh, nkv, hd, block_size, nt, waves, stream);
-}
-
-// The QKV projection + RoPE + paged KV store with its input RMSNorm carried in (xsum.h): x = the previous down_proj's fp32 x + group
-// sums (ssd_gemm_wf_res).  M <= 16; the decomposition is ssd_gemm_fused's default row-group count with 8 waves per workgroup.
-// Replaces RMSDNorm.forward + QKVParallelLinear.forward + rotary_emb + store_kvcache (ssd/layers/layernorm.py:64-88, linear.py:97-98,
-// rotary_embedding.py:40-60, attention.py:10-41) at the start of LlamaDecoderLayer.forward (ssd/models/llama3.py:185-192).
-static int fused_xs_nt(int N, int K) {
-  int nt, waves, tpw;
-  ssd_pick_skinny_cfg(N / 16, K / 32, false, &nt, &waves, &tpw);
-  return nt;
-}
-extern "C" int ssd_gemm_fused_xs_ok(int M, int N, int K) {
-  if (M <= 0 || M > 16 || (N & 15) || (K & 31) || N <= 0 || K <= 0) return SSD_ERR_SHAPE;
-  const int nt = fused_xs_nt(N, K);
-  if ((N / 16) % nt) return SSD_ERR_SHAPE;
-  if (!xsum_shape_ok(K, 8) || (K / 32) / (nt <= 2 ? 4 : 2) < 2 * 8) return SSD_ERR_SHAPE;       // every wave: >= 2 groups of k-tiles
-  return (size_t)8 * nt * 64 * sizeof(f32x4_t) + xsum_lds_bytes(K, 8) <= 160 * 1024 ? SSD_OK : SSD_ERR_SHAPE;
-}
-extern "C" int ssd_gemm_fused_xs(const void* x32_frag, const void* group_ss, const void* norm_w, float eps, const void* w_frag,
-                                 const void* bias, int M, int N, int K, const int64_t* positions, const float* cos_sin,
-                                 const int32_t* slots, void* q_out, void* k_cache, void* v_cache, int nh, int nkv, int hd,
-                                 int block_size, void* stream) {
-  if (int rc = ssd_gemm_fused_xs_ok(M, N, K)) return rc;
-  if (!x32_frag || !group_ss || !norm_w || !w_frag || !positions || !cos_sin || !slots || !q_out || !k_cache || !v_cache) return SSD_ERR_ARG;
-  if ((hd != 64 && hd != 128 && hd != 256) || N != (nh + 2 * nkv) * hd) return SSD_ERR_SHAPE;
-  FusedParams p{};
-  p.Wf = (const u32x4_t*)w_frag; p.bias = (const bf16_t*)bias;
-  p.positions = positions; p.cos_sin = cos_sin; p.slots = slots;
-  p.q_out = (bf16_t*)q_out; p.k_cache = (bf16_t*)k_cache; p.v_cache = (bf16_t*)v_cache;
-  p.eps = eps; p.M = M; p.N = N; p.K = K; p.ldy = 0; p.nh = nh; p.nkv = nkv; p.hd = hd; p.bs = block_size;
-  p.xs = XsumIn{(const float*)x32_frag, (const float*)group_ss, (const bf16_t*)norm_w, eps};
-  hipStream_t st = (hipStream_t)stream;
-  const int nt = fused_xs_nt(N, K);
-  if (nt == 1) return launch_fused_xs<1, FEPI_QKV_ROPE>(p, 8, st);
-  if (nt == 2) return launch_fused_xs<2, FEPI_QKV_ROPE>(p, 8, st);
-  return launch_fused_xs<4, FEPI_QKV_ROPE>(p, 8, st);
 }
 
 KT_DEFINE_SETTER(gemm_fused)

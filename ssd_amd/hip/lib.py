@@ -36,13 +36,6 @@ SIGNATURES = {
     "ssd_gemm_fused_parts": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int,
                              c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                              c_int, c_int, c_int, c_int, c_void_p],
-    "ssd_gemm_wf_res_ok": [c_int, c_int, c_int],
-    "ssd_gemm_wf_res": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
-    "ssd_gemm_wf_xs_ok": [c_int, c_int, c_int, c_int],
-    "ssd_gemm_wf_xs": [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
-    "ssd_gemm_fused_xs_ok": [c_int, c_int, c_int],
-    "ssd_gemm_fused_xs": [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                          c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "ssd_head_rmsnorm": [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p],
     "ssd_silu_mul": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "ssd_rmsnorm_pair": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p],

@@ -155,31 +155,6 @@ def gemm_fused(w_frag, M: int, N: int, K: int, epilogue: int, *, x_frag=None, h_
                                          _stream()), "ssd_gemm_fused")
 
 
-def xsum_ok(M: int, h: int, qn: int, I: int, qkv_n: int) -> bool:
-    """The norm-carrying GEMM forms (csrc/xsum.h) exist for every matrix of a decoder layer at M rows (host-side query)."""
-    lib = load_library()
-    return (lib.ssd_gemm_wf_res_ok(M, h, qn) == 0 and lib.ssd_gemm_wf_res_ok(M, h, I) == 0
-            and lib.ssd_gemm_wf_xs_ok(M, 2 * I, h, EPI_SILU_FRAG) == 0 and lib.ssd_gemm_fused_xs_ok(M, qkv_n, h) == 0)
-
-
-def gemm_res(x_frag, w_frag, res_in, res_out, x32_frag, group_ss, M: int, N: int, K: int, bias=None):
-    """Row-parallel projection + residual add; leaves fp32 x (fragment-major) + group sums of squares for the next GEMM's norm."""
-    _check(load_library().ssd_gemm_wf_res(_p(x_frag), _p(w_frag), _p(bias), _p(res_in), _p(res_out), _p(x32_frag), _p(group_ss), M, N, K,
-                                          _stream()), "ssd_gemm_wf_res")
-
-
-def gemm_xs(x32_frag, group_ss, norm_w, eps: float, w_frag, y, M: int, N: int, K: int, ldy: int = 0, epilogue: int = EPI_SILU_FRAG, bias=None):
-    _check(load_library().ssd_gemm_wf_xs(_p(x32_frag), _p(group_ss), _p(norm_w), eps, _p(w_frag), _p(bias), _p(y), M, N, K, ldy, epilogue,
-                                         _stream()), "ssd_gemm_wf_xs")
-
-
-def gemm_fused_xs(x32_frag, group_ss, norm_w, eps: float, w_frag, M: int, N: int, K: int, *, positions, cos_sin, slots, q_out, k_cache,
-                  v_cache, nh: int, nkv: int, hd: int, block_size: int, bias=None):
-    _check(load_library().ssd_gemm_fused_xs(_p(x32_frag), _p(group_ss), _p(norm_w), eps, _p(w_frag), _p(bias), M, N, K, _p(positions),
-                                            _p(cos_sin), _p(slots), _p(q_out), _p(k_cache), _p(v_cache), nh, nkv, hd, block_size,
-                                            _stream()), "ssd_gemm_fused_xs")
-
-
 def attn_paged(q_rows, k_cache, v_cache, block_tables, max_blocks, context_lens, B, T, max_q, nh, nkv, hd, block_size,
                scale, cu_q=None, q_per_seq=0, mode=MODE_CAUSAL, tree_K=0, tree_mq=0, tree_step=0, tree_F=1, tree_jidx=None,
                splits=1, flags=0, ws_o=None, ws_ml=None, out_rows=None, out_frag=None, waves=1):

@@ -140,17 +140,6 @@ class HipDecoder:
         self.tree_seg = ((_ts == "1" or (_ts == "auto" and _validated)) and tp_size == 1 and not self.use_coll
                          and taps is None and max_tokens >= 2
                          and H.tree_segment_ok(2, self.h, self.qn, self.I, self.qkv_n, self.nh, self.nkv, self.hd))
-        # "xsum" (csrc/xsum.h, round 6): at <= 16 token rows the residual add + RMSNorm between o_proj / down_proj and the next
-        # gate_up / QKV is carried by those GEMMs (producer epilogue: add + fp32 x + group sums of squares; consumer: row scale from the
-        # group sums, x^ formed while the B operand is loaded) -- 5 launches per layer instead of 7 and no norm launch.  Exists where
-        # the default decomposition of all four matrices is the register-streaming kernel with >= 2 row groups per workgroup: the
-        # 70B-class geometry (h = 8192), i.e. the metric's own verify.  Tolerance-equal to the separate launches (the row's sum of
-        # squares is summed in another fp32 order), tests/test_hip_xsum.py.
-        self.xsum = (tp_size == 1 and not self.use_coll and not cfg.qk_norm and not self.use_parts
-                     and H.xsum_ok(min(16, T), self.h, self.qn, self.I, self.qkv_n))
-        if self.xsum:
-            self.buf_x32 = z(16 * self.h, dtype=torch.float32)
-            self.buf_gss = z(self.h, dtype=torch.float32)
         if self.chain_seg:
             self.chain_gr = z(H.chain_granule_bytes(self.h, self.I) // 8, dtype=torch.int64)
             self.buf_res3 = z(1, self.h)             # the chain's residual ping-pongs between buf_res2 and this (every workgroup re-reads res_in)
@@ -473,43 +462,6 @@ class HipDecoder:
                            cfg.rms_norm_eps, T, self.h, self.qn, self.I, self.qkv_n, self.nh, self.nkv, self.hd, self.block_size, li,
                            self.tree_ws, self.chain_gen, self.chain_err, h_out=self.buf_h if last else None, **nxt)
 
-    def xsum_plan(self, T: int, meta: AttnMeta) -> bool:
-        """The norm-carrying GEMM forms for this forward (see __init__): decode-side row counts, rows (not slabs) between the kernels."""
-        return (self.xsum and T <= 16 and meta.cu_q is None and not self.fusion_plan(T)[1] and not self.parts_plan(T)
-                and "model.layers.0.self_attn.qkv_proj.bias" not in self.w)
-
-    def _forward_xsum(self, positions, T: int, meta: AttnMeta, splits: int, attn_waves: int) -> None:
-        """Per layer: [QKV + RoPE + KV store (layer 0: after the stand-alone input norm; else with the norm carried in)] [attention]
-        [o_proj + add] [norm + gate_up + SiLU] [down_proj + add] -- the last layer's down_proj leaves rows for the final norm."""
-        cfg, w = self.cfg, self.w
-        L, eps = cfg.num_layers, cfg.rms_norm_eps
-        scale = self.hd ** -0.5
-        res, x32, gss = self.buf_res, self.buf_x32, self.buf_gss
-        for li in range(L):
-            p = f"model.layers.{li}."
-            if li == 0:
-                self.launch_qkv(0, T, positions, meta.slot_mapping, parts=False)
-            else:
-                H.gemm_fused_xs(x32, gss, w[p + "input_layernorm.weight"], eps, w[p + "self_attn.qkv_proj.weight"], T, self.qkv_n, self.h,
-                                positions=positions, cos_sin=self.cos_sin, slots=meta.slot_mapping, q_out=self.buf_q,
-                                k_cache=self.kv_cache[li, 0], v_cache=self.kv_cache[li, 1], nh=self.nh, nkv=self.nkv, hd=self.hd,
-                                block_size=self.block_size)
-            if self.taps is not None and li in self.taps:       # the residual stream entering layer li
-                i = self.taps.index(li)
-                self.acts[:T, i * self.h:(i + 1) * self.h].copy_(res[:T])
-            H.attn_paged(self.buf_q, self.kv_cache[li, 0], self.kv_cache[li, 1], meta.block_tables, self.max_blocks,
-                         meta.context_lens, meta.B, T, meta.max_q, self.nh, self.nkv, self.hd, self.block_size, scale,
-                         cu_q=None, q_per_seq=meta.q_per_seq, mode=meta.mode, tree_K=meta.tree_K, tree_mq=meta.tree_mq,
-                         tree_step=meta.tree_step, tree_F=meta.tree_F, tree_jidx=meta.tree_jidx, splits=splits,
-                         ws_o=self.ws_o, ws_ml=self.ws_ml, out_frag=self.buf_af, waves=attn_waves)
-            H.gemm_res(self.buf_af, w[p + "self_attn.o_proj.weight"], res, res, x32, gss, T, self.h, self.qn)
-            H.gemm_xs(x32, gss, w[p + "post_attention_layernorm.weight"], eps, w[p + "mlp.gate_up_proj.weight"], self.buf_actf, T,
-                      2 * self.I, self.h)
-            if li + 1 < L:
-                H.gemm_res(self.buf_actf, w[p + "mlp.down_proj.weight"], res, res, x32, gss, T, self.h, self.I)
-            else:
-                self.launch_down(li, T, parts=False)
-
     def launch_qkv(self, li: int, T: int, positions, slot_mapping, gemm_only: bool = False, pre_normed: bool = False,
                    parts: bool | None = None, pf_src: int = 0) -> None:
         """gemm_only: skip the separate add+RMSNorm / RoPE launches of the unfused variants (kernel timing).
@@ -629,9 +581,6 @@ class HipDecoder:
         if self.tree_plan(T, meta):
             self._last_parts = False            # rows (buf_h) + the residual (buf_res), as above
             self._forward_tree_seg(positions, T, meta, splits, attn_waves)
-            return
-        if self.xsum_plan(T, meta):
-            self._forward_xsum(positions, T, meta, splits, attn_waves)
             return
         fuse_ao = parts and self.attn_o_plan(T, meta, splits)
         # tensor parallel with the one-shot collective: the all-reduce after o_proj / down_proj absorbs the residual add

@@ -93,6 +93,47 @@ def test_gemm_configs_and_bias(H):
     assert torch.equal(y2.view(torch.int16), outs[-1].view(torch.int16))
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 256, 2048), (8, 512, 8192), (16, 1024, 4128), (7, 256, 96)])
+def test_gemm_deep_form_vs_oracle(H, M, N, K):
+    """The DEEP form of the skinny GEMM (round 6: twice the k-tiles per stage at <= 8 waves; bit 8 of ssd_gemm_wf_cfg's nt), rows and
+    SiLU epilogues, with and without a K remainder and consecutive tiles per workgroup: the plain form's bars against the oracle, the
+    plain form's bits on repetition (deterministic), and -- a different dealing of k-tiles to waves, i.e. another fp32 order -- within
+    one ulp of the plain form on a small fraction of the outputs."""
+    torch.manual_seed(M + N + K)
+    x = torch.randn(M, K).to(BF)
+    w = (torch.randn(N, K) * 0.05).to(BF)
+    b = torch.randn(N).to(BF)
+    ref = O.linear(x, w, b)
+    xf, wf = to_frag_dev(x), to_frag_dev(w)
+    for nt in (2, 4):
+        for waves, tpw in ((8, 1), (4, 2), (1, 4), (8, 3)):
+            plain = torch.zeros(M, N, dtype=BF, device="cuda")
+            H.gemm(xf, wf, plain, M, N, K, N, bias=dev(b), cfg=(nt, waves | (tpw << 8)))
+            outs = []
+            for _ in range(2):
+                y = torch.full((M, N), float("nan"), dtype=BF, device="cuda")
+                H.gemm(xf, wf, y, M, N, K, N, bias=dev(b), cfg=(nt | 256, waves | (tpw << 8)))
+                outs.append(y)
+            assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+            assert_close_bf16(outs[0], ref, max_ulp=1, max_frac=0.03, rel_floor=2 ** -7, what=f"deep gemm nt {nt} waves {waves} tpw {tpw}")
+            assert_close_bf16(outs[0], plain, max_ulp=1, max_frac=0.03, rel_floor=2 ** -7, what=f"deep vs plain nt {nt} waves {waves} tpw {tpw}")
+    # SiLU epilogue (gate / up row groups interleaved)
+    wg = (torch.randn(N, K) * 0.05).to(BF)
+    refa = O.silu_mul(O.linear(x, wg))
+    wgf = torch.zeros(N * K, dtype=BF, device="cuda")
+    H.rows_to_frag(dev(wg), wgf, N, K, mode=1)
+    for nt, waves, tpw in ((2, 8, 1), (4, 8, 2), (2, 4, 4)):
+        act_f = torch.zeros(H.frag_numel(M, N // 2), dtype=BF, device="cuda")
+        H.gemm(xf, wgf, act_f, M, N, K, 0, epilogue=H.EPI_SILU_FRAG, cfg=(nt | 256, waves | (tpw << 8)))
+        act = LY.frag_to_rows_ref(act_f.cpu(), M, N // 2)
+        assert_close_bf16(act, refa, max_ulp=2, max_frac=0.04, rel_floor=2 ** -7, what=f"deep silu nt {nt} waves {waves} tpw {tpw}")
+    # what the DEEP form does not take is refused, not mis-launched
+    with pytest.raises(Exception):
+        H.gemm(xf, wf, plain, M, N, K, N, cfg=(2 | 256, 16))
+    with pytest.raises(Exception):
+        H.gemm(xf, wf, plain, M, N, K, N, cfg=(1 | 256, 8))
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 256, 2048), (7, 128, 8192), (16, 2048, 2048), (3, 80, 96), (1, 2048, 8192)])
 def test_gemm_splitk_vs_oracle(H, M, N, K):
     """csrc/gemm_sk.hip: K split across workgroups, last arriver reduces in z order; counters must return to zero and
