@@ -24,6 +24,11 @@ int ssd_gemm_pf_cfg(const void* x_frag, const void* w_frag, const void* bias, vo
                     int epilogue, void* workspace, int64_t workspace_bytes, int nt, int splits, void* stream);
 
 
+/* A/B facility (bench.py --tune-deep, profiles/): ssd_gemm_wf's default dispatch for the 70B-class matrices -- 1 (default) the DEEP
+ * form with gate_up as 256 workgroups, 2 the DEEP form with gate_up's 224-workgroup decomposition, 0 the plain kernels of rounds 1-5.
+ * Process-wide; call before any hipGraph is captured. */
+int ssd_tune_deep(int mode);
+
 /* Diagnostic (tests only): gfx950's v_cvt_pk_bf16_f32 against the integer round-to-nearest-even used everywhere else, over all 2^32
  * fp32 patterns.  counts2: two uint64 device words, zeroed by the caller: [0] mismatches on non-NaN inputs, [1] NaN inputs that did
  * not stay NaN. */

@@ -323,6 +323,16 @@ extern "C" int ssd_gemm_wf_cfg(const void* x_frag, const void* w_frag, const voi
 #undef DISPATCH_MT
 }
 
+// A/B facility for measurements (ssd_hip_tune.h; bench.py --tune-deep): how ssd_gemm_wf's default dispatch treats the 70B-class
+// matrices.  1 (default) = DEEP form, gate_up as 256 workgroups; 2 = DEEP form, gate_up keeps its 224-workgroup decomposition;
+// 0 = the plain kernels of rounds 1-5.  Process-wide; set before any graph is captured.
+static int g_deep_mode = 1;
+extern "C" int ssd_tune_deep(int mode) {
+  if (mode < 0 || mode > 2) return SSD_ERR_ARG;
+  g_deep_mode = mode;
+  return SSD_OK;
+}
+
 // Default configuration: pick (row groups per workgroup, waves per workgroup) from the shape.
 extern "C" int ssd_gemm_wf(const void* x_frag, const void* w_frag, const void* bias, void* y, int M, int N,
                            int K, int ldy, int epilogue, void* stream) {
@@ -337,8 +347,8 @@ extern "C" int ssd_gemm_wf(const void* x_frag, const void* w_frag, const void* b
     //  groups are a multiple of 512; tensor-parallel shards and the other models keep the plain form)
     const bool deep_rows = epilogue == EPI_ROWS && groups == 512 && nt1 == 2;
     const bool deep_silu = epilogue == EPI_SILU_FRAG && nt1 == 4 && groups % 512 == 0 && groups / 512 <= 8;
-    if (waves1 == 8 && KT >= 256 && (deep_rows || deep_silu)) {
-      if (deep_silu) { nt1 = 2; tpw1 = groups / 512; }
+    if (g_deep_mode && waves1 == 8 && KT >= 256 && (deep_rows || deep_silu)) {
+      if (deep_silu && g_deep_mode == 1) { nt1 = 2; tpw1 = groups / 512; }
       return ssd_gemm_wf_cfg(x_frag, w_frag, bias, y, M, N, K, ldy, epilogue, nt1 | 256, waves1 | (tpw1 << 8), stream);
     }
     // one row group per workgroup, bf16 rows: the single-buffered kernel of gemm_sk.hip (fewer registers -> more resident

@@ -36,6 +36,7 @@ SIGNATURES = {
     "ssd_gemm_fused_parts": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int,
                              c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                              c_int, c_int, c_int, c_int, c_void_p],
+    "ssd_tune_deep": [c_int],
     "ssd_head_rmsnorm": [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p],
     "ssd_silu_mul": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "ssd_rmsnorm_pair": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p],
