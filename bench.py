@@ -84,9 +84,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-random-pair", action="store_true", help="skip the independent-draft leg (value_random_pair)")
-    ap.add_argument("--tune-deep", type=int, default=None, choices=(0, 1, 2),
+    ap.add_argument("--tune-deep", type=int, default=None, choices=(0, 1),
                     help="A/B measurement only (include/ssd_hip_tune.h ssd_tune_deep): 0 = the plain skinny GEMMs of rounds 1-5 for the "
-                         "70B-class matrices, 2 = DEEP form with gate_up's 224-workgroup decomposition, 1 = the library default")
+                         "70B-class matrices, 1 = the library default (the DEEP form)")
     ap.add_argument("--ttft-samples", type=int, default=11,
                     help="TTFT runs; the first two are dropped (eager first sighting of the shape, then hipGraph capture)")
     ap.add_argument("--ref-seqs", type=int, default=2, help="sequences of the reference-protocol run (512 output tokens each); 0 = skip")

@@ -25,7 +25,7 @@ int ssd_gemm_pf_cfg(const void* x_frag, const void* w_frag, const void* bias, vo
 
 
 /* A/B facility (bench.py --tune-deep, profiles/): ssd_gemm_wf's default dispatch for the 70B-class matrices -- 1 (default) the DEEP
- * form with gate_up as 256 workgroups, 2 the DEEP form with gate_up's 224-workgroup decomposition, 0 the plain kernels of rounds 1-5.
+ * form, 0 the plain kernels of rounds 1-5.
  * Process-wide; call before any hipGraph is captured. */
 int ssd_tune_deep(int mode);
 

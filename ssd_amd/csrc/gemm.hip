@@ -324,11 +324,13 @@ extern "C" int ssd_gemm_wf_cfg(const void* x_frag, const void* w_frag, const voi
 }
 
 // A/B facility for measurements (ssd_hip_tune.h; bench.py --tune-deep): how ssd_gemm_wf's default dispatch treats the 70B-class
-// matrices.  1 (default) = DEEP form, gate_up as 256 workgroups; 2 = DEEP form, gate_up keeps its 224-workgroup decomposition;
-// 0 = the plain kernels of rounds 1-5.  Process-wide; set before any graph is captured.
+// matrices.  1 (default) = DEEP form at the tuned decompositions; 0 = the plain kernels of rounds 1-5.  Process-wide; set before any
+// graph is captured.  (A third mode -- gate_up as exactly 256 workgroups of 2 row groups x 7 tiles, the fastest gate_up KERNEL in
+// isolation, 145.7 vs 147.5 us -- made the c4 STEP 1.1 ms slower on the same box, profiles/r06_c4_deep_ab_same_box.txt: with the tuned
+// 224 workgroups 32 CUs stay free during half of the verify, and the co-located draft's kernels run there.  Deleted.)
 static int g_deep_mode = 1;
 extern "C" int ssd_tune_deep(int mode) {
-  if (mode < 0 || mode > 2) return SSD_ERR_ARG;
+  if (mode < 0 || mode > 1) return SSD_ERR_ARG;
   g_deep_mode = mode;
   return SSD_OK;
 }
@@ -341,16 +343,14 @@ extern "C" int ssd_gemm_wf(const void* x_frag, const void* w_frag, const void* b
   if (mt == 1) {       // decode / verify rows: the tuned table
     int nt1, waves1, tpw1;
     ssd_pick_skinny_cfg(groups, KT, epilogue == EPI_SILU_FRAG, &nt1, &waves1, &tpw1);
-    // the 70B-class matrices (very long K, >= 512 row groups, 8 waves per workgroup): the DEEP form, measured 1-2.4 % faster on each
-    // (round 6); gate_up additionally as exactly 256 workgroups of 2 row groups x (groups / 512) consecutive tiles where that divides
+    // the 70B-class matrices (very long K, >= 512 row groups, 8 waves per workgroup): the DEEP form at the same decomposition, measured
+    // 1-2 % faster on each kernel and -0.7 ms on the c4 step (round 6, profiles/r06_deep_probe.txt, r06_c4_deep_ab_same_box.txt)
     // (only the classes that were measured: N = 8192 rows matrices with K >= 8192 -- o_proj, down_proj -- and the gate_up whose row
     //  groups are a multiple of 512; tensor-parallel shards and the other models keep the plain form)
     const bool deep_rows = epilogue == EPI_ROWS && groups == 512 && nt1 == 2;
     const bool deep_silu = epilogue == EPI_SILU_FRAG && nt1 == 4 && groups % 512 == 0 && groups / 512 <= 8;
-    if (g_deep_mode && waves1 == 8 && KT >= 256 && (deep_rows || deep_silu)) {
-      if (deep_silu && g_deep_mode == 1) { nt1 = 2; tpw1 = groups / 512; }
+    if (g_deep_mode && waves1 == 8 && KT >= 256 && (deep_rows || deep_silu))
       return ssd_gemm_wf_cfg(x_frag, w_frag, bias, y, M, N, K, ldy, epilogue, nt1 | 256, waves1 | (tpw1 << 8), stream);
-    }
     // one row group per workgroup, bf16 rows: the single-buffered kernel of gemm_sk.hip (fewer registers -> more resident
     // workgroups) measured 5-17 % faster than the register double buffer below (profiles/micro/splitk_probe.py)
     if (nt1 == 1 && tpw1 == 1 && epilogue == EPI_ROWS)
