@@ -77,10 +77,11 @@ __device__ __forceinline__ void fused_load_x32(const FusedParams& p, int mm, int
   }
 }
 
-// DEEP (round 6, as gemm.hip): twice the k-tiles per group at <= 8 waves per workgroup (256 VGPRs available); x_frag input only.
-template <int NT, int EPI, bool XNORM, int FUSED_MAXC, bool DEEP = false>
-__global__ void __launch_bounds__(DEEP ? 512 : 1024) gemm_fused_kernel(const FusedParams p) {
-  static_assert(!(DEEP && XNORM), "the deep form takes fragment-major x");
+// (Round 6 measured a DEEP form of this kernel -- twice the k-tiles per group at 8 waves, as gemm.hip's -- for the 70B QKV launch: the
+//  same 29.5 us in isolation and the same c4 step; 8 PLAIN waves cost the step 0.4 ms.  Not kept: profiles/r06_deep_probe.txt,
+//  profiles/r06_c4_deep_ab_same_box.txt.)
+template <int NT, int EPI, bool XNORM, int FUSED_MAXC>
+__global__ void __launch_bounds__(1024) gemm_fused_kernel(const FusedParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KTS = !XNORM ? 2 : (EPI == FEPI_QKV_ROPE ? 0 : 1);      // trace slot (profiling builds only)
   KTRACE(KTS, 0);
@@ -100,7 +101,7 @@ __global__ void __launch_bounds__(DEEP ? 512 : 1024) gemm_fused_kernel(const Fus
   const u32x4_t* wp = p.Wf + ((size_t)tile0 * KT << 6) + lane;
   const size_t wstride = (size_t)KT << 6;
 
-  constexpr int U = ((NT <= 2) ? 4 : 2) * (DEEP ? 2 : 1);
+  constexpr int U = (NT <= 2) ? 4 : 2;
   u32x4_t wa[2][U][NT];
   u32x4_t xg[2][U];       // fragment-major x travels with the weights when there is no prologue
   auto loadw = [&](int buf, int kt) {
@@ -542,17 +543,6 @@ static int launch_fused_c(const FusedParams& p, int waves, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
 }
 
-template <int NT>
-static int launch_fused_deep_qkv(const FusedParams& p, int waves, hipStream_t st) {
-  if (waves > 8) return SSD_ERR_ARG;
-  const int blocks = (p.N / 16) / NT;
-  const size_t lds = (size_t)waves * NT * 64 * sizeof(f32x4_t);
-  FusedParams q = p;
-  q.scratch_bytes = (int)lds;
-  hipLaunchKernelGGL((gemm_fused_kernel<NT, FEPI_QKV_ROPE, false, 1, true>), dim3(blocks), dim3(waves * 64), lds, st, q);
-  return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
-}
-
 template <int NT, int EPI, bool XNORM>
 static int launch_fused(const FusedParams& p, int waves, hipStream_t st) {
   if constexpr (XNORM) {
@@ -586,8 +576,6 @@ static int fused_impl(const void* x_frag, const void* h_rows, const float* h_par
   if (h_parts && (S < 1 || S > 16)) return SSD_ERR_ARG;
   if (res_out && res_out == res_in) return SSD_ERR_ARG;                   // in-place residual would race
   const int groups = N / 16;
-  const bool deep = nt > 0 && ((nt >> 8) & 1);
-  if (nt > 0) nt &= 0xff;
   if (nt <= 0 || waves <= 0) {
     int nt1, waves1, tpw1;
     ssd_pick_skinny_cfg(groups, K / 32, epilogue == FEPI_SILU_FRAG, &nt1, &waves1, &tpw1);
@@ -614,10 +602,6 @@ static int fused_impl(const void* x_frag, const void* h_rows, const float* h_par
     return nt == 1 ? launch_qkv_m32<1>(p, waves, st) : launch_qkv_m32<2>(p, waves, st);
   }
   const bool xn = h_rows != nullptr || h_parts != nullptr;
-  if (deep) {         // bit 8 of nt: the DEEP form -- QKV + RoPE epilogue, fragment-major x, <= 8 waves, nt 2 / 4
-    if (xn || epilogue != FEPI_QKV_ROPE || (nt != 2 && nt != 4)) return SSD_ERR_ARG;
-    return nt == 2 ? launch_fused_deep_qkv<2>(p, waves, st) : launch_fused_deep_qkv<4>(p, waves, st);
-  }
 #define FUSED_DISPATCH(E)                                                                          \
   return xn ? launch_fused_nt<E, true>(p, nt, waves, st) : launch_fused_nt<E, false>(p, nt, waves, st);
   switch (epilogue) {
