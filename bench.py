@@ -261,7 +261,7 @@ def gemm_roofline(legs):
             tot_launch += L * fwd_per_step
     fam = tot_bytes / tot_time
     # The DOMINANT kernel = the launch kind with the largest share of the step's GPU time (the target's gate_up + SiLU GEMM at
-    # M = k + 1: gemm_wf_kernel<1,4,1> for the 70B): `achieved` / `frac` are ITS algorithmic bytes (2*N*K)
+    # M = k + 1: gemm_wf_kernel<1,4,1,DEEP> for the 70B): `achieved` / `frac` are ITS algorithmic bytes (2*N*K)
     # over ITS average launch duration, measured live above with HIP events.  The launch-weighted mean over the whole skinny-GEMM
     # family (target + draft, every shape of the step) is reported beside it as `family`.
     dom_tag = max(per_kind, key=lambda t: per_kind[t]["us"] * per_kind[t]["launches_per_step"])
@@ -285,11 +285,13 @@ def gemm_roofline(legs):
         for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c4_kernel_stats.txt")), reverse=True):
             try:
                 with open(fn) as f:
-                    hit = next((l for l in f if "gemm_wf_kernel<1, 4, 1>" in l), None)
+                    # (round 6: the kernel has a fourth template argument -- DEEP -- and the 70B gate_up runs the `true` form)
+                    hit = next((l for l in f if "gemm_wf_kernel<1, 4, 1" in l), None)
                 m_ = re.search(r"avg=\s*([0-9.]+)us", hit or "")
                 if m_:
                     us = float(m_.group(1))
-                    out["rocprof"] = {"from_committed_profile": True, "source": os.path.relpath(fn, ROOT), "kernel": "gemm_wf_kernel<1, 4, 1>",
+                    kn = re.search(r"gemm_wf_kernel<[^>]*>", hit)
+                    out["rocprof"] = {"from_committed_profile": True, "source": os.path.relpath(fn, ROOT), "kernel": kn.group(0) if kn else "gemm_wf_kernel<1, 4, 1>",
                                       "avg_us": us, "frac": round(dom_bytes / (us * 1e-6) / HBM_PEAK, 4)}
                     break
             except Exception:

@@ -20,21 +20,21 @@ def rows(name):
 
 # (kernel substring, grid threads) -> (label, algorithmic MB per launch); grids from the launch geometry of each shape
 KNOWN = {
-    ("gemm_wf_kernel<1, 4, 1>", 114688): ("target gate_up+SiLU 57344x8192 (nt=4, 4 tiles/WG)", 939.524),
+    ("gemm_wf_kernel<1, 4, 1,", 114688): ("target gate_up+SiLU 57344x8192 (nt=4, 4 tiles/WG)", 939.524),
     ("gemm_fused_kernel<4, 3, false", 81920): ("target qkv+RoPE+KV-store 10240x8192", 167.772),
-    ("gemm_wf_kernel<1, 2, 0>", 131072): ("target o 8192x8192 / down 8192x28672 (same grid; mean of the two)", (134.218 + 469.762) / 2),
-    ("gemm_wf_kernel<1, 2, 0>", 513024): ("target LM head 128256x8192 (8 tiles/WG)", 2101.346),
-    ("gemm_wf_kernel<1, 2, 0>", 2052096): ("draft LM head 128256x2048", 525.337),
+    ("gemm_wf_kernel<1, 2, 0,", 131072): ("target o 8192x8192 / down 8192x28672 (same grid; mean of the two)", (134.218 + 469.762) / 2),
+    ("gemm_wf_kernel<1, 2, 0,", 513024): ("target LM head 128256x8192 (8 tiles/WG)", 2101.346),
+    ("gemm_wf_kernel<1, 2, 0,", 2052096): ("draft LM head 128256x2048", 525.337),
     ("gemm_fused_kernel<2, 1, true", 262144): ("draft norm+gate_up+SiLU 16384x2048 (slab prologue)", 67.109),
     ("gemm_fused_kernel<1, 3, true", 196608): ("draft norm+qkv+RoPE 3072x2048 (slab prologue)", 12.583),
     ("gemm_sp_kernel<8, 1>", 262144): ("draft down 2048x8192 (2 slabs)", 33.554),
     ("gemm_sp_kernel<2, 1>", 262144): ("draft o 2048x2048 (2 slabs)", 8.389),
     # c4 (round 5): the target at M = 8 launches the QKV kernel with 16 waves; the draft's glue / tree / chain kinds
     ("gemm_fused_kernel<4, 3, false", 163840): ("target qkv+RoPE+KV-store 10240x8192", 167.772),
-    ("gemm_wf_kernel<1, 2, 3>", 513024): ("target LM head 128256x8192 + argmax candidates", 2101.346),
-    ("gemm_wf_kernel<1, 2, 3>", 2052096): ("draft LM head 128256x2048 + argmax candidates (M <= 16)", 525.337),
-    ("gemm_wf_kernel<2, 2, 3>", 2052096): ("draft LM head 128256x2048 + argmax candidates (M = 24)", 525.337),
-    ("gemm_wf_kernel<2, 2, 1>", 131072): ("draft tree-step gate_up+SiLU 16384x2048 (M = 24)", 67.109),
+    ("gemm_wf_kernel<1, 2, 3,", 513024): ("target LM head 128256x8192 + argmax candidates", 2101.346),
+    ("gemm_wf_kernel<1, 2, 3,", 2052096): ("draft LM head 128256x2048 + argmax candidates (M <= 16)", 525.337),
+    ("gemm_wf_kernel<2, 2, 3,", 2052096): ("draft LM head 128256x2048 + argmax candidates (M = 24)", 525.337),
+    ("gemm_wf_kernel<2, 2, 1,", 131072): ("draft tree-step gate_up+SiLU 16384x2048 (M = 24)", 67.109),
     ("gemm_sp_kernel<8, 2>", 262144): ("draft tree-step down 2048x8192 (M = 24, slabs)", 33.554),
     ("gemm_sp_kernel<2, 2>", 262144): ("draft tree-step o 2048x2048 (M = 24, slabs)", 8.389),
     ("gemm_qkv_rope_m32_kernel<1>", 196608): ("draft tree-step qkv+RoPE+KV-store 3072x2048 (M = 24)", 12.583),
