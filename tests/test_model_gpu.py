@@ -465,3 +465,45 @@ def test_prefill_shape_replays_its_hipgraph(gpu, golden):
         ngraphs.append(sum(1 for k in eng.model_runner.graphs if k[0] == "prefill"))
     assert got == want
     assert ngraphs == [0, 0, 1, 1, 2, 2]
+
+
+@pytest.mark.parametrize("mode", ["sync", "async"])
+def test_segment_error_word_ends_the_round_it_belongs_to_on_the_gpu(gpu, monkeypatch, mode):
+    """a resident segment that gives up a bounded wait sets a device word and lets the launch finish with wrong
+    numbers; until round 5 the runner looked at the word one call late.  Here the draft's word is set before the run (it is sticky: the
+    kernels only ever store 1) with the resident chain forced on for a small geometry it accepts: synchronous speculation must raise
+    after the FIRST round's verify read-back (no second chain is launched); the asynchronous draft server must raise before the first
+    JIT chain's reply leaves it.  Without the fault the same engines produce the autoregressive stream (the segment really runs)."""
+    from ssd_amd.engine.llm_engine import LLMEngine
+    from ssd_amd.sampling_params import SamplingParams
+    monkeypatch.setenv("SSD_CHAIN_SEG", "1")
+    t = ModelConfig("llama", 256, 2, 4, 2, 64, 512, 512, 1e-5, 5e5, 8192, False)
+    kw = dict(hf_config=t, max_num_seqs=1, max_model_len=1024, max_num_batched_tokens=1024, kvcache_block_size=256, num_kvcache_blocks=6,
+              num_draft_kvcache_blocks=6, weights_std=0.1, draft="d", draft_hf_config=t, draft_weights_seed=0, speculate=True, speculate_k=3)
+    if mode == "async":
+        kw.update(draft_async=True, async_fan_out=2, jit_speculate=True)
+    prompt = [(7 * j + 1) % 512 for j in range(40)]
+    sp = SamplingParams(temperature=0, max_new_tokens=12, ignore_eos=True)
+    ar, _ = LLMEngine("t", **{k: v for k, v in kw.items() if k not in ("draft", "draft_hf_config", "draft_weights_seed", "speculate", "speculate_k",
+                                                                      "num_draft_kvcache_blocks", "draft_async", "async_fan_out", "jit_speculate")}
+                      ).generate([prompt], sp, use_tqdm=False)
+    eng = LLMEngine("t", inprocess_draft=mode == "async", **kw)
+    assert eng.draft_runner.model.chain_seg, "the small geometry must take the resident chain"
+    ok, _ = eng.generate([prompt], sp, use_tqdm=False)
+    assert ok[0]["token_ids"] == ar[0]["token_ids"]
+    assert int(eng.draft_runner.model.chain_gen.item()) > 0, "no resident chain segment ran"
+    eng.exit()
+    bad = LLMEngine("t", inprocess_draft=mode == "async", **kw)
+    launches = []
+    orig = bad.draft_runner.speculate_chain if mode == "sync" else bad.draft_runner.draft_jit
+
+    def counted(*a, **k):
+        launches.append(1)
+        return orig(*a, **k)
+    setattr(bad.draft_runner, "speculate_chain" if mode == "sync" else "draft_jit", counted)
+    bad.draft_runner.model.chain_err.fill_(1)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="resident layer segment"):
+        bad.generate([prompt], sp, use_tqdm=False)
+    assert len(launches) == 1, f"{len(launches)} chains were launched before the error surfaced"
+    bad.exit()
