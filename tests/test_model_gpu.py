@@ -470,8 +470,8 @@ def test_prefill_shape_replays_its_hipgraph(gpu, golden):
 @pytest.mark.parametrize("mode", ["sync", "async"])
 def test_segment_error_word_ends_the_round_it_belongs_to_on_the_gpu(gpu, monkeypatch, mode):
     """a resident segment that gives up a bounded wait sets a device word and lets the launch finish with wrong
-    numbers; until round 5 the runner looked at the word one call late.  Here the draft's word is set before the run (it is sticky: the
-    kernels only ever store 1) with the resident chain forced on for a small geometry it accepts: synchronous speculation must raise
+    numbers; until round 5 the runner looked at the word one call late.  Here the draft's word is set in front of the FIRST chain's launches (it is
+    sticky: the kernels only ever store 1) with the resident chain forced on for a small geometry it accepts: synchronous speculation must raise
     after the FIRST round's verify read-back (no second chain is launched); the asynchronous draft server must raise before the first
     JIT chain's reply leaves it.  Without the fault the same engines produce the autoregressive stream (the segment really runs)."""
     from ssd_amd.engine.llm_engine import LLMEngine
@@ -498,11 +498,13 @@ def test_segment_error_word_ends_the_round_it_belongs_to_on_the_gpu(gpu, monkeyp
     orig = bad.draft_runner.speculate_chain if mode == "sync" else bad.draft_runner.draft_jit
 
     def counted(*a, **k):
+        # the fault happens DURING the first chain: the word is set on the chain's own stream right in front of its launches (set before
+        # the run it would already end the draft's prefill read-back, which looks at the device word too -- measured: 0 chains launched)
+        if not launches:
+            bad.draft_runner.model.chain_err.fill_(1)
         launches.append(1)
         return orig(*a, **k)
     setattr(bad.draft_runner, "speculate_chain" if mode == "sync" else "draft_jit", counted)
-    bad.draft_runner.model.chain_err.fill_(1)
-    torch.cuda.synchronize()
     with pytest.raises(RuntimeError, match="resident layer segment"):
         bad.generate([prompt], sp, use_tqdm=False)
     assert len(launches) == 1, f"{len(launches)} chains were launched before the error surfaced"
