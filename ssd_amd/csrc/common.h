@@ -120,6 +120,11 @@ static inline void ssd_pick_skinny_cfg(int groups, int KT, bool silu_pairs, int*
     n = 2; w = 8;
   } else if (groups >= 512 && KT >= 256 && groups % 2 == 0) {    // 70B-class o_proj
     n = 2; w = 8;
+  } else if (groups > 256 && groups < 512 && KT >= 256) {
+    // between one and two workgroups per CU over a long K (Qwen3-32B o_proj / down_proj: 320 row groups): 4-wave workgroups of the
+    // single-buffered kernel -- measured at M = 8 (profiles/r06_qwen32b_tune.txt): down_proj [5120 x 25600] 49.3 us against 53-57 with
+    // 8 waves, o_proj [5120 x 8192] 17.8 against 19.5
+    n = 1; w = 4;
   }
   // fewer workgroups than CUs (tensor-parallel shards of qkv, the drafts' qkv): a CU's pull from HBM is bounded by the bytes
   // it has in flight (8 waves x 8 KiB ~ 30 GB/s), so an under-filled launch gets 16 waves per workgroup
