@@ -28,11 +28,23 @@ __global__ void rope_store_kernel(const bf16_t* __restrict__ qkv, const float* _
   // 8 consecutive columns of row t as fp32 values of bf16 numbers
   auto load8 = [&](int col, float (&x)[8]) {
     if (PARTS) {
+      // every slab's loads are issued before the first add (a rolled `for z < S` is load -> wait -> add per slab: S dependent round trips
+      // in a kernel that is a latency chain) -- the same additions in the same order (norm.hip's sum_slabs, the same reasoning)
       const float* src = parts + (size_t)t * row_w + col;
-      f32x4_t lo = *reinterpret_cast<const f32x4_t*>(src), hi = *reinterpret_cast<const f32x4_t*>(src + 4);
-      for (int z = 1; z < S; ++z) {
-        lo += *reinterpret_cast<const f32x4_t*>(src + (size_t)z * slab);
-        hi += *reinterpret_cast<const f32x4_t*>(src + (size_t)z * slab + 4);
+      // (the sum STARTS from slab 0 -- not from +0.0 -- so that a row of -0.0 partials stays -0.0 like the epilogue kernel's)
+      f32x4_t lo, hi;
+      for (int z0 = 0; z0 < S; z0 += 4) {          // block-uniform
+        f32x4_t ta[4], tb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float* sj = src + (size_t)min(z0 + j, S - 1) * slab;
+          ta[j] = *reinterpret_cast<const f32x4_t*>(sj);
+          tb[j] = *reinterpret_cast<const f32x4_t*>(sj + 4);
+        }
+        if (z0 == 0) { lo = ta[0]; hi = tb[0]; } else { lo += ta[0]; hi += tb[0]; }
+#pragma unroll
+        for (int j = 1; j < 4; ++j)
+          if (z0 + j < S) { lo += ta[j]; hi += tb[j]; }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) { x[j] = round_bf(lo[j]); x[4 + j] = round_bf(hi[j]); }
@@ -49,7 +61,8 @@ __global__ void rope_store_kernel(const bf16_t* __restrict__ qkv, const float* _
   long kv_base = -1;
   if (slot >= 0) kv_base = ((long)(slot / bs) * nkv) * bs + (slot % bs);  // + kvh*bs, then * hd
 
-  for (int it = threadIdx.x; it < rot_items + v_items; it += blockDim.x) {
+  // (gridDim.y workgroups share a token row: the single-chunk prefill's 128 rows alone fill half the chip)
+  for (int it = blockIdx.y * blockDim.x + threadIdx.x; it < rot_items + v_items; it += blockDim.x * gridDim.y) {
     if (it < rot_items) {
       const int head = it / c16, c = it % c16;
       const bool is_q = head < nh;
@@ -115,11 +128,16 @@ static int rope_store_launch(const void* qkv_rows, const float* parts, int S, co
   int threads = ((items + 63) / 64) * 64;
   if (threads > 512) threads = 512;
   const size_t slab = (size_t)T * (nh + 2 * nkv) * hd;
-  if (parts)
-    hipLaunchKernelGGL(rope_store_kernel<true>, dim3(T), dim3(threads), 0, (hipStream_t)stream, (const bf16_t*)nullptr, parts, S,
+  if (parts) {
+    // prefill-sized launches: 256-thread workgroups, as many per token row as the row has items (70B: 704 items -> 3 x 128 rows = 384
+    // workgroups instead of 128 of 512 threads; measured 11.6 -> see profiles/r06_prefill_small_kernels.txt).  The c16 threads of a head
+    // (per-head norm shuffles) stay inside one wave: item runs of a head start at multiples of c16 <= 16.
+    threads = 256;
+    const int gy = (items + threads - 1) / threads;
+    hipLaunchKernelGGL(rope_store_kernel<true>, dim3(T, gy), dim3(threads), 0, (hipStream_t)stream, (const bf16_t*)nullptr, parts, S,
                        slab, positions, cos_sin, slot_mapping, (bf16_t*)q_out_rows, (bf16_t*)k_cache, (bf16_t*)v_cache,
                        (const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w, eps, nh, nkv, hd, block_size, qkv_perm);
-  else
+  } else
     hipLaunchKernelGGL(rope_store_kernel<false>, dim3(T), dim3(threads), 0, (hipStream_t)stream, (const bf16_t*)qkv_rows,
                        (const float*)nullptr, 0, slab, positions, cos_sin, slot_mapping, (bf16_t*)q_out_rows, (bf16_t*)k_cache,
                        (bf16_t*)v_cache, (const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w, eps, nh, nkv, hd, block_size, qkv_perm);

@@ -328,6 +328,14 @@ class HipDecoder:
             splits = 1
         return splits, waves
 
+    def _attn_flags(self, meta: AttnMeta) -> int:
+        """ssd_attn_paged flags.  Query blocks of more than 8 row tiles per kv head (prefill chunks) take ONE 16-row tile per workgroup
+        (bit 2) instead of the kernel's default two: twice the workgroups, K tiles prefetched (the two-tile variant of head_dim 128 has no
+        registers for that) -- the same key split per wave, so bit-identical; measured at T = 128 (profiles/r06_prefill_small_kernels.txt):
+        70B 17.0 -> 12.2 us, 8B 16.8 -> 10.6, 1B 12.4 -> 8.1; T = 512: 48.8 -> 46.6."""
+        G = self.nh // self.nkv
+        return 4 if -(-(meta.max_q * G) // 16) > 8 else 0
+
     @staticmethod
     def _parts_cfg(N: int, K: int, fused_consumer: bool = False) -> tuple[int, int]:
         """(K splits, waves) of the split-K partial-slab GEMM for a [N, K] matrix, from profiles/r02_draft_probe.txt (1B
@@ -569,6 +577,7 @@ class HipDecoder:
                     vocab_start=self.tp_rank * self.V if self.tp_size > 1 else 0, vocab_count=self.V if self.tp_size > 1 else cfg.vocab_size)
         self._allreduce(h[:T])
         splits, attn_waves = self._attn_cfg(T, meta)
+        attn_flags = self._attn_flags(meta)
         scale = self.hd ** -0.5
         # a varlen prefill never takes the slab path (its last-token gather reads rows); compute_logits, which always follows
         # in the same Python body, must know whether the last down_proj left rows or partial slabs
@@ -607,7 +616,7 @@ class HipDecoder:
                              meta.context_lens, meta.B, T, meta.max_q, self.nh, self.nkv, self.hd, self.block_size, scale,
                              cu_q=meta.cu_q, q_per_seq=meta.q_per_seq, mode=meta.mode, tree_K=meta.tree_K, tree_mq=meta.tree_mq,
                              tree_step=meta.tree_step, tree_F=meta.tree_F, tree_jidx=meta.tree_jidx, splits=splits,
-                             ws_o=self.ws_o, ws_ml=self.ws_ml, out_frag=self.buf_af, waves=attn_waves)
+                             flags=attn_flags, ws_o=self.ws_o, ws_ml=self.ws_ml, out_frag=self.buf_af, waves=attn_waves)
                 pf_o = self.launch_o(li, T, parts=parts, pf_partials=not parts)
             if fuse:
                 ar.all_reduce_add_rmsnorm(h, res, res, w[f"model.layers.{li}.post_attention_layernorm.weight"], eps, T, self.h, out_frag=xf)
