@@ -159,7 +159,10 @@ int ssd_rope_store_kv_parts(const float* parts, int splits, const int64_t* posit
  * splits = key-range splits per (sequence, kv head) (static per launch; ranges derive from context_lens on
  * device).  ws_o fp32[T*nh*splits*hd], ws_ml fp32[T*nh*splits*2] needed when splits > 1.
  * flags bit0: use scalar LDS gathers instead of ds_read_b64_tr_b16 (diagnostic).
- * flags bit1: single-bf16 probabilities in P.V (FlashAttention's rounding) instead of the default hi+lo split. */
+ * flags bit1: single-bf16 probabilities in P.V (FlashAttention's rounding) instead of the default hi+lo split.
+ * flags bit2: one 16-row tile per workgroup also for query blocks of more than 8 row tiles per kv head (default: two) -- bit-identical,
+ *             twice the workgroups; the host takes it for prefill chunks (ssd_amd/model.py _attn_flags).
+ * flags bits 8..11: waves per workgroup (1..8, 0 = 1) that split the key range and merge in LDS. */
 int ssd_attn_paged(const void* q_rows, const void* k_cache, const void* v_cache, const int32_t* block_tables,
                    int max_blocks, const int32_t* context_lens, const int32_t* cu_q, int q_per_seq, int B, int T,
                    int max_q, int nh, int nkv, int hd, int block_size, float scale, int mode, int tree_K,

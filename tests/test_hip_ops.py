@@ -354,6 +354,41 @@ def test_rope_store_golden(H, golden):
     assert torch.equal(LY.kv_hnd_to_nhd(vc).view(torch.int16), vref.view(torch.int16))
 
 
+@pytest.mark.parametrize("qk_norm,S", [(False, 4), (True, 5), (False, 1), (True, 8)])
+def test_rope_store_from_prefill_partials_with_several_workgroups_per_row(H, qk_norm, S):
+    """Round 6: ssd_rope_store_kv_parts spreads a token row over 256-thread workgroups (70B-like head counts: 3 per row) and issues
+    the slabs' loads four at a time -- still bit-identical to the row form over bf16(slab 0 + slab 1 + ...), for slab counts on both
+    sides of the batch size, with per-head norms (the shuffles of a head stay inside one wave), -0.0 sums and skipped slots."""
+    torch.manual_seed(3 + S)
+    T, nh, nkv, hd, bs, nb = 70, 40, 8, 128, 16, 8
+    N = (nh + 2 * nkv) * hd
+    parts = torch.randn(S, T, N) * 0.5
+    parts[:, 3, :200] = -0.0
+    rows = parts[0].clone()
+    for z in range(1, S):
+        rows = rows + parts[z]
+    rows = rows.to(BF)
+    qn, kn = ((1 + 0.1 * torch.randn(hd)).to(BF), (1 + 0.1 * torch.randn(hd)).to(BF)) if qk_norm else (None, None)
+    pos = torch.randint(0, 250, (T,), dtype=torch.int64)
+    cache = O.make_cos_sin_cache(hd, 256, 5e5)
+    slots = torch.randperm(nb * bs)[:T].to(torch.int32)
+    slots[11] = -1
+
+    def run(fn, src, *extra):
+        q_out = torch.zeros(T, nh * hd, dtype=BF, device="cuda")
+        kc = torch.zeros(nb, nkv, bs, hd, dtype=BF, device="cuda")
+        vc = torch.zeros_like(kc)
+        fn(src, *extra, dev(pos), dev(cache), dev(slots), q_out, kc, vc, T, nh, nkv, hd, bs,
+           q_norm_w=None if qn is None else dev(qn), k_norm_w=None if kn is None else dev(kn), eps=1e-6, qkv_perm=1)
+        torch.cuda.synchronize()
+        return [t.view(torch.int16) for t in (q_out, kc, vc)]
+
+    a = run(H.rope_store_kv, dev(rows))
+    b = run(H.rope_store_kv_parts, dev(parts.contiguous()), S)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("qk_norm,perm", [(False, 1), (True, 1), (False, 0)])
 def test_rope_store_from_prefill_partials_equals_rows(H, qk_norm, perm):
     """ssd_rope_store_kv_parts (round 3): the prefill QKV GEMM leaves its split-K slabs in the workspace and the RoPE / KV-store
@@ -446,7 +481,7 @@ def make_paged(B, ctx_lens, nkv, hd, bs, seed):
     return kc, vc, bt, max_blocks
 
 
-def run_attn(H, q, kc, vc, bt, max_blocks, ctx, nh, nkv, hd, bs, cu_q=None, q_per_seq=0, splits=1, flags=0, **tree):
+def run_attn(H, q, kc, vc, bt, max_blocks, ctx, nh, nkv, hd, bs, cu_q=None, q_per_seq=0, splits=1, flags=0, waves=1, **tree):
     T = q.shape[0]
     B = ctx.numel()
     max_q = q_per_seq if cu_q is None else int((cu_q[1:] - cu_q[:-1]).max())
@@ -456,7 +491,7 @@ def run_attn(H, q, kc, vc, bt, max_blocks, ctx, nh, nkv, hd, bs, cu_q=None, q_pe
     ws_ml = torch.zeros(T * nh * splits * 2, dtype=torch.float32, device="cuda")
     H.attn_paged(dev(q), dev(LY.kv_nhd_to_hnd(kc)), dev(LY.kv_nhd_to_hnd(vc)), dev(bt), max_blocks, dev(ctx), B, T, max_q,
                  nh, nkv, hd, bs, hd ** -0.5, cu_q=None if cu_q is None else dev(cu_q), q_per_seq=q_per_seq, splits=splits,
-                 flags=flags, ws_o=ws_o, ws_ml=ws_ml, out_rows=out, out_frag=outf, **tree)
+                 flags=flags, ws_o=ws_o, ws_ml=ws_ml, out_rows=out, out_frag=outf, waves=waves, **tree)
     torch.cuda.synchronize()
     rows = out.cpu()
     assert torch.equal(LY.frag_to_rows_ref(outf.cpu(), T, nh * hd).view(torch.int16), rows.view(torch.int16))
@@ -503,6 +538,26 @@ def test_attn_prefill_varlen(H):
     ref2 = O.attn_paged(q2, kc, vc, ctx, bt, hd ** -0.5, cu_q=cu2).reshape(70, nh * hd)
     got2 = run_attn(H, q2.reshape(70, -1), kc, vc, bt, mb, ctx, nh, nkv, hd, bs, cu_q=cu2, splits=1)
     assert_close_bf16(got2, ref2, what="prefill suffix", **ATTN_TOL)
+
+
+@pytest.mark.parametrize("nh,nkv,hd,waves", [(16, 2, 128, 2), (16, 4, 64, 2), (16, 2, 128, 4)])
+def test_attn_prefill_one_row_tile_per_workgroup_is_bit_identical(H, nh, nkv, hd, waves):
+    """Round 6 (model._attn_flags): a prefill-sized query block (> 8 row tiles per kv head) run with ONE 16-row tile per workgroup
+    (flags bit 2) instead of the kernel's default two -- the same key split per wave, so the same bits; and both against the oracle.
+    Ragged: the last row tile is partial, the lengths straddle key tiles."""
+    bs = 16
+    lens = [131, 77]
+    kc, vc, bt, mb = make_paged(2, lens, nkv, hd, bs, seed=21)
+    torch.manual_seed(5)
+    T = sum(lens)
+    q = torch.randn(T, nh, hd).to(BF)
+    cu = torch.tensor([0, 131, 208], dtype=torch.int32)
+    ctx = torch.tensor(lens, dtype=torch.int32)
+    ref = O.attn_paged(q, kc, vc, ctx, bt, hd ** -0.5, cu_q=cu).reshape(T, nh * hd)
+    two = run_attn(H, q.view(T, -1), kc, vc, bt, mb, ctx, nh, nkv, hd, bs, cu_q=cu, waves=waves)
+    one = run_attn(H, q.view(T, -1), kc, vc, bt, mb, ctx, nh, nkv, hd, bs, cu_q=cu, flags=4, waves=waves)
+    assert torch.equal(one.view(torch.int16), two.view(torch.int16))
+    assert_close_bf16(one, ref, what="prefill, one row tile per workgroup", **ATTN_TOL)
 
 
 @pytest.mark.parametrize("splits", [1, 3])
