@@ -130,7 +130,7 @@ static int rope_store_launch(const void* qkv_rows, const float* parts, int S, co
   const size_t slab = (size_t)T * (nh + 2 * nkv) * hd;
   if (parts) {
     // prefill-sized launches: 256-thread workgroups, as many per token row as the row has items (70B: 704 items -> 3 x 128 rows = 384
-    // workgroups instead of 128 of 512 threads; measured 11.6 -> see profiles/r06_prefill_small_kernels.txt).  The c16 threads of a head
+    // workgroups instead of 128 of 512 threads; in situ 11.6 -> 9.2 us per 70B layer, profiles/r06_c4_prefill_timeline.txt).  The c16 threads of a head
     // (per-head norm shuffles) stay inside one wave: item runs of a head start at multiples of c16 <= 16.
     threads = 256;
     const int gy = (items + threads - 1) / threads;
